@@ -1,0 +1,83 @@
+"""Deterministic synthetic inputs shared by the golden generator and the tests.
+
+All inputs come from numpy's PCG64 ``default_rng(seed)`` (stable across numpy
+versions and machines), cast to float32 - never from torch's generator.
+"""
+import numpy as np
+
+
+def randn(seed, n, d, scale=1.0, shift=0.0):
+    x = np.random.default_rng(seed).standard_normal((n, d))
+    return (x * scale + shift).astype(np.float32)
+
+
+def unit_norm(seed, n, d, shift=0.5):
+    """CLAP-like rows: offset Gaussian, L2-normalised."""
+    x = np.random.default_rng(seed).standard_normal((n, d)) + shift
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x.astype(np.float32)
+
+
+def decaying(seed, n, d, decades=4.0, scale=1.0, shift=0.0):
+    """Gaussian with a geometrically decaying column scale (ill-conditioned cov)."""
+    x = np.random.default_rng(seed).standard_normal((n, d)) * scale + shift
+    return (x * np.logspace(0.0, -decades, d)).astype(np.float32)
+
+
+def pair(kind, seed, n_ref, n_cand, d):
+    """(reference, candidate) embedding sets of a named family."""
+    if kind == "randn":
+        return randn(seed, n_ref, d), randn(seed + 1, n_cand, d, 1.05, 0.05)
+    if kind == "unit":
+        return unit_norm(seed, n_ref, d, 0.5), unit_norm(seed + 1, n_cand, d, 0.55)
+    if kind == "decay":
+        return decaying(seed, n_ref, d), decaying(seed + 1, n_cand, d, 4.0, 1.05, 0.05)
+    if kind == "shifted":
+        return randn(seed, n_ref, d), randn(seed + 1, n_cand, d, 1.0, 0.1)
+    raise ValueError(kind)
+
+
+# ---- case tables (name -> parameters); the generator stores outputs under the same names
+STATS_CASES = {
+    # name: (seed, d, row-splits fed to add() one after the other)
+    "tiny_1": (11, 8, [1]),
+    "tiny_33": (12, 8, [33]),
+    "chan_1_100_1000": (13, 8, [1, 100, 1000]),          # shape of the reference's tests/test_data.py:10-12
+    "vggish_1000_b32": (14, 128, [32] * 31 + [8]),
+    "clap_4096_b32": (15, 512, [32] * 128),
+    "clap_4096_oneshot": (15, 512, [4096]),
+    "ragged": (16, 24, [5, 1, 17, 2, 64, 1, 1, 300]),
+}
+
+FAD_CASES = {
+    # name: (kind, seed, n_ref, n_cand, d)
+    "vggish_1k": ("shifted", 21, 1000, 1000, 128),        # BASELINE config 1 shape
+    "clap_4k": ("randn", 22, 4096, 4096, 512),
+    "clap_unit_4k": ("unit", 23, 4096, 4096, 512),
+    "decay_2k": ("decay", 24, 2000, 2000, 128),
+    "rankdef_300": ("randn", 25, 300, 300, 512),
+    "rankdef_40_vs_full": ("randn", 26, 40, 2000, 128),
+    "tiny_d8": ("shifted", 27, 50, 60, 8),
+    "clap_100k": ("randn", 28, 100000, 100000, 512),      # BASELINE config 2/3 shape
+}
+
+KD_CASES = {
+    # name: (kind, seed, n1, n2, d)   (set 1 = features_1 = candidate side)
+    "shrink_300_500": ("shifted", 31, 300, 500, 32),      # exercises kd.py:160-168
+    "mid_3000": ("randn", 32, 3000, 3000, 64),
+    "unit_2500": ("unit", 33, 2500, 2200, 128),
+    "clap_100k": ("randn", 28, 100000, 100000, 512),
+}
+
+PRDC_CASES = {
+    # name: (kind, seed, n_ref, n_cand, d, k)
+    "randn_257_128_k1": ("randn", 41, 257, 257, 128, 1),
+    "randn_257_128_k5": ("randn", 41, 257, 257, 128, 5),
+    "shifted_1000_128_k5": ("shifted", 42, 1000, 1000, 128, 5),
+    "randn_2000_512_k5": ("randn", 43, 2000, 2000, 512, 5),
+    "randn_2000_512_k10": ("randn", 43, 2000, 2000, 512, 10),
+    "unit_2000_512_k5": ("unit", 44, 2000, 2000, 512, 5),
+    "unit_2000_512_k10": ("unit", 44, 2000, 2000, 512, 10),
+    "ragged_300_500_24_k3": ("shifted", 45, 300, 500, 24, 3),
+    "tiny_12_9_8_k2": ("shifted", 46, 12, 9, 8, 2),
+}

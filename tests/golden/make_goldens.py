@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own hot-path code.
+
+Runs only in the build container (needs /root/reference).  The reference's
+modules are imported in place, unmodified, through a bare package stub that
+skips ``audio_metrics/__init__.py`` (which would pull in soxr/pyloudnorm/...,
+absent here).  Only inputs' seeds and the reference's OUTPUTS are stored; no
+reference source is copied.  Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import inputs as gi  # noqa: E402
+
+REF = "/root/reference/src/audio_metrics"
+pkg = types.ModuleType("audio_metrics")
+pkg.__path__ = [REF]
+sys.modules["audio_metrics"] = pkg
+r_data = importlib.import_module("audio_metrics.data")
+r_fad = importlib.import_module("audio_metrics.metrics.fad")
+r_kd = importlib.import_module("audio_metrics.metrics.kd")
+r_prdc = importlib.import_module("audio_metrics.metrics.prdc")
+r_apa = importlib.import_module("audio_metrics.metrics.apa")
+
+VERSIONS = f"torch {torch.__version__}; numpy {np.__version__}; threads {torch.get_num_threads()}"
+
+
+def amd(emb, store=True, splits=None):
+    d = r_data.AudioMetricsData(store_embeddings=store)
+    t = torch.as_tensor(emb)
+    if splits is None:
+        d.add(t)
+    else:
+        s = 0
+        for b in splits:
+            d.add(t[s:s + b])
+            s += b
+        assert s == len(t)
+    return d
+
+
+def cov_summary(cov):
+    c = cov.numpy()
+    return dict(trace=np.trace(c), fro=np.linalg.norm(c), block=c[:16, :16].copy(),
+                sample=c[::37, ::41].copy())
+
+
+def gen_stats():
+    out = {"versions": VERSIONS}
+    for name, (seed, d, splits) in gi.STATS_CASES.items():
+        x = gi.randn(seed, sum(splits), d, 1.3, 0.2)
+        a = amd(x, store=True, splits=splits)
+        out[f"{name}/n"] = a.n
+        out[f"{name}/mean"] = a.mean.numpy()
+        if d <= 128:
+            out[f"{name}/cov"] = a.cov.numpy()
+        for k, v in cov_summary(a.cov).items():
+            out[f"{name}/cov_{k}"] = v
+        a.recompute_stats()
+        out[f"{name}/re_mean"] = a.mean.numpy()
+        out[f"{name}/re_cov_shape"] = np.array(a.cov.shape)
+        if tuple(a.cov.shape) == (d, d):
+            for k, v in cov_summary(a.cov).items():
+                out[f"{name}/re_cov_{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "stats.npz"), **out)
+
+
+def gen_fad():
+    out = {"versions": VERSIONS}
+    for name, (kind, seed, nr, nc, d) in gi.FAD_CASES.items():
+        ref, cand = gi.pair(kind, seed, nr, nc, d)
+        a, b = amd(cand, store=False), amd(ref, store=False)
+        out[f"{name}/fad"] = r_fad.frechet_distance(a, b)          # (candidate, reference) as audio_metrics.py:257
+        out[f"{name}/fad_swapped"] = r_fad.frechet_distance(b, a)
+        c = torch.linalg.eigvals(a.cov @ b.cov).sqrt().real.sum().item()
+        out[f"{name}/tr_sqrt"] = c
+        out[f"{name}/tr_sum"] = (a.cov.trace() + b.cov.trace()).item()
+        out[f"{name}/mean_sq"] = (a.mean - b.mean).square().sum().item()
+        print("fad", name, out[f"{name}/fad"])
+    np.savez_compressed(os.path.join(HERE, "fad.npz"), **out)
+
+
+def gen_kd():
+    out = {"versions": VERSIONS}
+    for name, (kind, seed, n1, n2, d) in gi.KD_CASES.items():
+        f2, f1 = gi.pair(kind, seed, n2, n1, d)                      # set 1 = candidate side
+        a, b = amd(f1), amd(f2)
+        res = r_kd.kernel_distance(a, b)
+        out[f"{name}/mean"] = res["kernel_distance_mean"]
+        out[f"{name}/std"] = res["kernel_distance_std"]
+        # per-subset values: replay the reference's own loop body with its own functions
+        m = 1000 if 1000 < min(n1, n2) else max(1, min(n1, n2) // 2)
+        rng = np.random.default_rng(1234)
+        mmds = np.zeros(100)
+        first = None
+        for i in range(100):
+            i1 = rng.choice(n1, m, replace=False)
+            i2 = rng.choice(n2, m, replace=False)
+            if first is None:
+                first = (i1[:8].copy(), i2[:8].copy())
+            mmds[i] = r_kd.kernel_mmd2(f1[i1], f2[i2], r_kd.polynomial_kernel)
+        assert float(np.mean(mmds)) == res["kernel_distance_mean"]
+        out[f"{name}/mmds"] = mmds
+        out[f"{name}/m"] = m
+        out[f"{name}/first_idx1"] = first[0]
+        out[f"{name}/first_idx2"] = first[1]
+        print("kd", name, res)
+    np.savez_compressed(os.path.join(HERE, "kd.npz"), **out)
+
+
+def gen_prdc():
+    out = {"versions": VERSIONS}
+    for name, (kind, seed, nr, nc, d, k) in gi.PRDC_CASES.items():
+        ref, cand = gi.pair(kind, seed, nr, nc, d)
+        a, b = amd(ref), amd(cand)
+        res = r_prdc.prdc(a, b, k)
+        for key, v in res.items():
+            out[f"{name}/{key}"] = v
+        out[f"{name}/r_ref"] = a.radii[f"radii_{k}"].numpy()
+        out[f"{name}/r_cand"] = b.radii[f"radii_{k}"].numpy()
+        dist = torch.cdist(a.embeddings, b.embeddings)
+        out[f"{name}/col_count"] = (dist < a.radii[f"radii_{k}"][:, None]).sum(dim=0).numpy().astype(np.int32)
+        out[f"{name}/row_any"] = (dist < b.radii[f"radii_{k}"][None, :]).any(dim=1).numpy()
+        out[f"{name}/row_min"] = dist.min(dim=1)[0].numpy()
+        print("prdc", name, res)
+    np.savez_compressed(os.path.join(HERE, "prdc.npz"), **out)
+
+
+def gen_apa():
+    out = {"versions": VERSIONS}
+    table = [(1.0, 2.0, 3.0), (2.0, 1.0, 3.0), (1.0, 5.0, 3.0), (5.0, 1.0, 3.0), (-1.0, 2.0, 3.0),
+             (1.0, -2.0, 3.0), (1.0, 2.0, -3.0), (0.0, 0.0, 0.0), (-1.0, -1.0, -1.0), (2.0, 2.0, 0.0),
+             (0.3, 0.3, 1e-9), (1e-3, 2e-3, 5e-4)]
+    out["table_in"] = np.array(table)
+    out["table_out"] = np.array([r_apa._apa(*t) for t in table])
+    d = 64
+    ref = gi.randn(51, 1500, d)
+    anti = gi.randn(52, 1500, d, 1.2, 0.3)
+    for i, (sc, sh) in enumerate([(1.0, 0.02), (1.1, 0.15), (1.2, 0.3), (1.5, 0.8)]):
+        cand = gi.randn(53 + i, 1200, d, sc, sh)
+        a, b, c = amd(cand, False), amd(ref, False), amd(anti, False)
+        out[f"three_set_{i}/apa"] = r_apa.apa(a, b, c)
+        out[f"three_set_{i}/params"] = np.array([sc, sh])
+        print("apa", i, out[f"three_set_{i}/apa"])
+    np.savez_compressed(os.path.join(HERE, "apa.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["stats", "fad", "kd", "prdc", "apa"]
+    for w in which:
+        globals()[f"gen_{w}"]()
+    print("done", VERSIONS)

@@ -1,0 +1,125 @@
+"""The oracle (CPU restatement) must reproduce the reference's own outputs.
+
+Golden vectors were produced by tests/golden/make_goldens.py, which imports the
+reference's hot-path modules (data.py, metrics/{fad,kd,prdc,apa}.py) unmodified.
+Same torch/numpy versions here and there => the same library calls give the
+same bits; tolerances below only allow for thread-count dependent BLAS blocking.
+"""
+import numpy as np
+import pytest
+import torch
+
+import inputs as gi
+import oracle
+
+RT = dict(rtol=1e-9, atol=1e-12)
+
+
+def _feed(x, splits, store=True):
+    d = oracle.OracleData(store)
+    t = torch.as_tensor(x)
+    s = 0
+    for b in splits:
+        d.add(t[s:s + b])
+        s += b
+    return d
+
+
+@pytest.mark.parametrize("name", list(gi.STATS_CASES))
+def test_stats(golden, name):
+    g = golden("stats")
+    seed, d, splits = gi.STATS_CASES[name]
+    x = gi.randn(seed, sum(splits), d, 1.3, 0.2)
+    a = _feed(x, splits)
+    assert a.n == int(g[f"{name}/n"])
+    np.testing.assert_allclose(a.mean.numpy(), g[f"{name}/mean"], **RT)
+    c = a.cov.numpy()
+    if d <= 128:
+        np.testing.assert_allclose(c, g[f"{name}/cov"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.trace(c), g[f"{name}/cov_trace"], rtol=1e-7)
+    np.testing.assert_allclose(c[:16, :16], g[f"{name}/cov_block"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(c[::37, ::41], g[f"{name}/cov_sample"], rtol=1e-6, atol=1e-8)
+    a.recompute_stats()
+    np.testing.assert_allclose(a.mean.numpy(), g[f"{name}/re_mean"], **RT)
+    assert tuple(a.cov.shape) == tuple(g[f"{name}/re_cov_shape"])
+
+
+def test_chan_merge_equals_oneshot():
+    """Property pinned by the reference's tests/test_data.py:6-31 (1e-6)."""
+    x = gi.randn(7, 1101, 8)
+    a = _feed(x, [1, 100, 1000])
+    b = _feed(x, [1101])
+    np.testing.assert_allclose(a.mean.numpy(), b.mean.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(a.cov.numpy(), b.cov.numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", list(gi.FAD_CASES))
+def test_fad(golden, name):
+    g = golden("fad")
+    kind, seed, nr, nc, d = gi.FAD_CASES[name]
+    ref, cand = gi.pair(kind, seed, nr, nc, d)
+    a, b = _feed(cand, [nc], False), _feed(ref, [nr], False)
+    fad = oracle.frechet_distance(a, b)
+    scale = float(g[f"{name}/tr_sum"])
+    # eigvals is LAPACK geev: allow thread-dependent rounding relative to the operands' magnitude
+    assert abs(fad - float(g[f"{name}/fad"])) <= 1e-9 * scale + 1e-7 * abs(fad)
+    assert abs((a.mean - b.mean).square().sum().item() - float(g[f"{name}/mean_sq"])) <= 1e-9 * scale
+
+
+@pytest.mark.parametrize("name", list(gi.KD_CASES))
+def test_kd(golden, name):
+    g = golden("kd")
+    kind, seed, n1, n2, d = gi.KD_CASES[name]
+    f2, f1 = gi.pair(kind, seed, n2, n1, d)
+    i1, i2 = oracle.draw_subsets(n1, n2)
+    assert i1.shape == (100, int(g[f"{name}/m"]))
+    np.testing.assert_array_equal(i1[0, :8], g[f"{name}/first_idx1"])
+    np.testing.assert_array_equal(i2[0, :8], g[f"{name}/first_idx2"])
+    res, mmds = oracle.kid_from_features(f1, f2, return_all=True)
+    floor = 5e-7                                      # f32 noise floor of the reference itself
+    np.testing.assert_allclose(mmds, g[f"{name}/mmds"], rtol=1e-5, atol=floor)
+    assert abs(res["kernel_distance_mean"] - float(g[f"{name}/mean"])) <= 1e-5 * abs(float(g[f"{name}/mean"])) + floor
+    assert abs(res["kernel_distance_std"] - float(g[f"{name}/std"])) <= 1e-4 * abs(float(g[f"{name}/std"])) + floor
+
+
+def test_kd_first_draws_match_survey():
+    """first draws of default_rng(1234) at n=100000."""
+    i1, i2 = oracle.draw_subsets(100000, 100000, subsets=1)
+    assert list(i1[0, :8]) == [57642, 95775, 28099, 5584, 88853, 71821, 71685, 94582]
+    assert list(i2[0, :8]) == [54893, 10548, 28828, 19561, 15832, 25262, 27971, 29690]
+
+
+@pytest.mark.parametrize("name", list(gi.PRDC_CASES))
+def test_prdc(golden, name):
+    g = golden("prdc")
+    kind, seed, nr, nc, d, k = gi.PRDC_CASES[name]
+    ref, cand = gi.pair(kind, seed, nr, nc, d)
+    a, b = _feed(ref, [nr]), _feed(cand, [nc])
+    res = oracle.prdc(a, b, k)
+    np.testing.assert_allclose(a.radii[f"radii_{k}"].numpy(), g[f"{name}/r_ref"], rtol=2e-6)
+    np.testing.assert_allclose(b.radii[f"radii_{k}"].numpy(), g[f"{name}/r_cand"], rtol=2e-6)
+    for key in ("precision", "recall", "density", "coverage"):
+        # one membership flip changes these by 1/N; allow two
+        assert abs(res[key] - float(g[f"{name}/{key}"])) <= 2.0 / min(nr, nc) + 1e-12, key
+
+
+def test_prdc_blocked_agrees():
+    ref, cand = gi.pair("shifted", 42, 1000, 1000, 128)
+    a, b = _feed(ref, [1000]), _feed(cand, [1000])
+    full = oracle.prdc(a, b, 5)
+    blk = oracle.prdc_blocked(ref, cand, 5, block=256)
+    for key in full:
+        assert abs(full[key] - blk[key]) <= 2e-3
+
+
+def test_apa(golden):
+    g = golden("apa")
+    for t, want in zip(g["table_in"], g["table_out"]):
+        assert oracle.apa_from_distances(*t) == want
+    d = 64
+    ref, anti = gi.randn(51, 1500, d), gi.randn(52, 1500, d, 1.2, 0.3)
+    for i in range(4):
+        sc, sh = g[f"three_set_{i}/params"]
+        cand = gi.randn(53 + i, 1200, d, sc, sh)
+        a, b, c = (_feed(v, [len(v)], False) for v in (cand, ref, anti))
+        assert abs(oracle.apa(a, b, c) - float(g[f"three_set_{i}/apa"])) <= 1e-7
