@@ -1,0 +1,75 @@
+"""ctypes binding of include/audio_metrics_hip.h (the C-ABI drop-in boundary).
+
+The product path has NO fallback: if the shared object is missing or a symbol
+cannot be resolved this module raises, it never routes to a CPU implementation.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+
+from ._build import LIB_PATH
+
+_P = c_void_p
+
+# name -> (restype, argtypes); mirrors include/audio_metrics_hip.h one to one
+SIGNATURES = {
+    "am_version": (c_char_p, []),
+    "am_status_string": (c_char_p, [c_int]),
+    "am_last_error": (c_char_p, []),
+    "am_stats_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "am_stats_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
+    "am_colsum_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_size_t, _P]),
+    "am_scatter_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
+    "am_stats_merge_f64": (c_int, [c_int64, _P, _P, c_int64, _P, _P, c_int, _P, _P, _P]),
+    "am_frechet_workspace_bytes": (c_size_t, [c_int]),
+    "am_frechet_f64": (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, _P, _P, c_size_t, _P]),
+    "am_apa_f64": (c_double, [c_double, c_double, c_double]),
+    "am_kd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "am_kd_poly_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, _P, _P, c_int, c_int,
+                               c_double, c_double, c_int, _P, _P, c_size_t, _P]),
+    "am_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "am_knn_radii_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, c_int, _P, _P, c_size_t, _P]),
+    "am_prdc_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "am_prdc_counts_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P,
+                                   _P, c_size_t, _P]),
+    "am_prdc_reduce": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P, _P]),
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def library_path():
+    return LIB_PATH
+
+
+def load():
+    """Load libaudio_metrics_hip.so (built in-tree by ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python __graft_entry__.py build`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        lib = load()
+        msg = lib.am_last_error().decode() or lib.am_status_string(status).decode()
+        raise HipLibraryError(f"{what} failed with status {status}: {msg}")

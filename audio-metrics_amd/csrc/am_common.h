@@ -1,0 +1,63 @@
+// Shared host/device helpers for the gfx950 distribution-distance library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include "../../include/audio_metrics_hip.h"
+
+namespace am {
+
+// thread-local last-error text (am_last_error)
+char* last_error_buf();
+void set_error(const char* fmt, ...);
+
+#define AM_HIP_TRY(expr)                                                             \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) {                                                      \
+            am::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
+                          __FILE__, __LINE__);                                       \
+            return AM_ERR_HIP;                                                       \
+        }                                                                            \
+    } while (0)
+
+#define AM_LAUNCH_CHECK()                                                            \
+    do {                                                                             \
+        hipError_t _e = hipGetLastError();                                           \
+        if (_e != hipSuccess) {                                                      \
+            am::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), \
+                          __FILE__, __LINE__);                                       \
+            return AM_ERR_HIP;                                                       \
+        }                                                                            \
+    } while (0)
+
+#define AM_REQUIRE(cond, status, ...)                                                \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            am::set_error(__VA_ARGS__);                                              \
+            return (status);                                                         \
+        }                                                                            \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Bump allocator over the caller's workspace (256-byte aligned carve-outs).
+struct Carver {
+    char* base;
+    size_t size;
+    size_t off = 0;
+    Carver(void* p, size_t n) : base(static_cast<char*>(p)), size(n) {}
+    template <class T>
+    T* take(size_t count) {
+        size_t bytes = round_up(count * sizeof(T), 256);
+        T* r = (base && off + bytes <= size) ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += bytes;
+        return r;
+    }
+    bool ok() const { return base != nullptr && off <= size; }
+};
+
+}  // namespace am

@@ -1,0 +1,179 @@
+// Kernel distance (KID-style unbiased MMD^2 with a polynomial kernel), reference
+// kd.py:38-83 (mmd2), 112-116 (polynomial_kernel), 119-124, 178-187 (subset loop).
+//
+// One launch covers all S subsets.  Per subset the three m x m Gram blocks
+// Kxx, Kyy, Kxy are cut into 128x128 tiles (Kxx / Kyy: upper-triangular tiles
+// only, off-diagonal tiles weighted 2) and every tile is one workgroup of the
+// f32-MFMA tile engine fed by rows GATHERED through the subset's index list.
+// Epilogue: K = (dot*gamma + coef0)^degree in f64, summed in f64 (the reference
+// forms K in f32 and sums with numpy's pairwise f32 sums; f64 keeps the device
+// on the exact side of the reference's own rounding noise).
+#include "am_common.h"
+#include "tile_engine.h"
+
+namespace am {
+
+struct GatherRows {           // local row -> X[idx[tile*128 + row]], zero rows past m
+    const float* base;
+    int64_t ld;
+    const int64_t* idx;
+    int m, tile;
+    __device__ __forceinline__ const float* operator()(int, int row) const {
+        const int p = tile * TB + row;
+        return p < m ? base + idx[p] * ld : nullptr;
+    }
+};
+
+struct KdEpilogue {
+    double gamma, coef0;
+    int degree, m;
+    int q0, p0;                // first subset position of the Q (register) / P (lane) rows of this tile
+    bool drop_diag;
+    double sum;
+    const LaneInfo& L;
+    __device__ __forceinline__ KdEpilogue(const LaneInfo& l) : L(l) {}
+    __device__ __forceinline__ void aux_issue(int) {}
+    __device__ __forceinline__ void aux_commit(int) {}
+    __device__ __forceinline__ double kval(float dot) const {
+        const double base = (double)dot * gamma + coef0;
+        double k = 1.0;
+        for (int d = 0; d < degree; ++d) k *= base;
+        return k;
+    }
+    // Sums ALL 128x128 entries of the tile; padded (zero) rows give exactly kval(0) each, which the
+    // caller subtracts analytically.  Diagonal entries of Kxx / Kyy are removed here (valid ones only).
+    __device__ __forceinline__ void finish(int, f32x16 (&acc)[2][2]) {
+        double s = 0.0;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s += kval(acc[mt][nt][i]);
+        if (drop_diag && L.wm == L.wn) {                 // wave-uniform: only waves that straddle the diagonal
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int q = q0 + L.wm * 64 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * L.h;
+                    const int p = p0 + L.wn * 64 + mt * 32 + L.r;
+                    if (q == p && p < m) s -= kval(acc[mt][mt][i]);
+                }
+        }
+        sum = s;
+    }
+};
+
+// partial[(s * blocks_per_subset) + b] = weighted tile sum
+__global__ void __launch_bounds__(ENGINE_THREADS, 2)
+kd_tile_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ Y, int64_t ldy, int D,
+               const int64_t* __restrict__ idx1, const int64_t* __restrict__ idx2, int m, int T, int ntri,
+               double gamma, double coef0, int degree, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LaneInfo L;
+    const int per_subset = 2 * ntri + T * T;
+    const int s = blockIdx.x / per_subset;
+    int b = blockIdx.x % per_subset;
+    int which, tq, tp;                       // which: 0 = XX, 1 = YY, 2 = XY
+    if (b < 2 * ntri) {
+        which = b / ntri;
+        int t = b % ntri;
+        tq = 0;
+        while (t >= T - tq) { t -= T - tq; ++tq; }
+        tp = tq + t;
+    } else {
+        which = 2;
+        b -= 2 * ntri;
+        tq = b / T;
+        tp = b % T;
+    }
+    const int64_t* i1 = idx1 + (int64_t)s * m;
+    const int64_t* i2 = idx2 + (int64_t)s * m;
+    // Kxy[a][b] = k(x_a, y_b): Q rows (register axis) from set 1, P rows (lane axis) from set 2
+    const GatherRows qsrc{which == 1 ? Y : X, which == 1 ? ldy : ldx, which == 1 ? i2 : i1, m, tq};
+    const GatherRows psrc{which == 0 ? X : Y, which == 0 ? ldx : ldy, which == 0 ? i1 : i2, m, tp};
+    KdEpilogue epi(L);
+    epi.gamma = gamma;
+    epi.coef0 = coef0;
+    epi.degree = degree;
+    epi.m = m;
+    epi.q0 = tq * TB;
+    epi.p0 = tp * TB;
+    epi.drop_diag = (which != 2) && (tq == tp);
+    epi.sum = 0.0;
+    tile_pipeline(qsrc, psrc, 1, D, lds, L, epi);
+
+    double v = epi.sum;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    double* red = reinterpret_cast<double*>(lds);          // staging slabs are idle after the pipeline's last barrier
+    if (L.lane == 0) red[L.tid >> 6] = v;
+    __syncthreads();
+    if (L.tid == 0) {
+        const double w = (which != 2 && tq != tp) ? 2.0 : 1.0;   // symmetric blocks: count the mirrored tile too
+        const int vq = min(TB, m - tq * TB), vp = min(TB, m - tp * TB);
+        const double pad = (double)(TB * TB - vq * vp) * epi.kval(0.f);
+        partial[blockIdx.x] = w * ((((red[0] + red[1]) + red[2]) + red[3]) - pad);
+    }
+}
+
+__global__ void kd_finish_kernel(const double* __restrict__ partial, int S, int m, int T, int ntri,
+                                 double* __restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int per_subset = 2 * ntri + T * T;
+    const double* p = partial + (int64_t)s * per_subset;
+    double sxx = 0, syy = 0, sxy = 0;
+    for (int i = 0; i < ntri; ++i) sxx += p[i];
+    for (int i = 0; i < ntri; ++i) syy += p[ntri + i];
+    for (int i = 0; i < T * T; ++i) sxy += p[2 * ntri + i];
+    const double dm = (double)m;
+    // kd.py:77-79 (unbiased): within-set sums over m(m-1) off-diagonal pairs, cross term over m^2
+    out[s] = (sxx + syy) / (dm * (dm - 1.0)) - 2.0 * sxy / (dm * dm);
+}
+
+constexpr size_t KD_LDS_BYTES = ENGINE_LDS_FLOATS * sizeof(float);
+
+}  // namespace am
+
+using namespace am;
+
+extern "C" size_t am_kd_workspace_bytes(int S, int m) {
+    if (S < 1 || m < 1) return 0;
+    const int T = (int)ceil_div(m, TB);
+    Carver c(nullptr, 0);
+    c.take<double>((size_t)S * (T * (T + 1) + T * T));
+    return c.off;
+}
+
+extern "C" int am_kd_poly_f32(const float* X, int64_t N1, int64_t ldx, const float* Y, int64_t N2, int64_t ldy, int D,
+                              const int64_t* idx1, const int64_t* idx2, int S, int m, double gamma, double coef0,
+                              int degree, double* out_mmd, void* ws, size_t ws_bytes, am_stream_t stream) {
+    AM_REQUIRE(X && Y && idx1 && idx2 && out_mmd, AM_ERR_BAD_ARG, "null pointer");
+    AM_REQUIRE(N1 >= 1 && N2 >= 1 && D >= 1 && S >= 1 && m >= 1, AM_ERR_BAD_SHAPE,
+               "N1=%lld N2=%lld D=%d S=%d m=%d", (long long)N1, (long long)N2, D, S, m);
+    AM_REQUIRE(m <= N1 && m <= N2, AM_ERR_BAD_SHAPE, "subset size %d exceeds a set size", m);
+    AM_REQUIRE(degree >= 0 && degree <= 16, AM_ERR_BAD_ARG, "degree %d outside [0, 16]", degree);
+    AM_REQUIRE(aligned16(X) && aligned16(Y) && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= D && ldy >= D, AM_ERR_BAD_ARG,
+               "X/Y must be 16-byte aligned with ld %% 4 == 0 and ld >= D");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int T = (int)ceil_div(m, TB);
+    const int ntri = T * (T + 1) / 2;
+    const int per_subset = 2 * ntri + T * T;
+    Carver c(ws, ws_bytes);
+    double* partial = c.take<double>((size_t)S * per_subset);
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    static bool attr_done = false;
+    if (!attr_done) {
+        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_tile_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)KD_LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kd_tile_kernel, dim3((unsigned)((int64_t)S * per_subset)), dim3(ENGINE_THREADS), KD_LDS_BYTES, st,
+                       X, ldx, Y, ldy, D, idx1, idx2, m, T, ntri, gamma, coef0, degree, partial);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(kd_finish_kernel, dim3((unsigned)ceil_div(S, 64)), dim3(64), 0, st, partial, S, m, T, ntri,
+                       out_mmd);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}

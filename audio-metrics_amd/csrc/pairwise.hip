@@ -1,0 +1,520 @@
+// PRDC hot path: k-NN radii (reference prdc.py:4-14) and hypersphere membership
+// counts (reference prdc.py:34-48) without ever materialising an N x M distance
+// matrix.  Both kernels run the 128x128 f32-MFMA tile engine over
+// (row block) x (column chunk) work items and fuse the reduction into the tile
+// epilogue, working on SQUARED distances
+//     d2(i,j) = max(fma(-2, <x_i,y_j>, |x_i|^2 + |y_j|^2), 0)
+// (torch.cdist's matmul form before the sqrt).  The reference's comparisons on
+// sqrt'ed values are reproduced exactly through per-row thresholds:
+//     sqrt_rn(d2) < R   <=>   d2 < T(R),  T(R) = min { t : sqrt_rn(t) >= R }.
+#include "am_common.h"
+#include "tile_engine.h"
+
+namespace am {
+
+// ------------------------------------------------------------------ row norms
+// |x|^2 in f32 with a fixed order (mirrored by oracle/exact_c): lane l of the
+// row's wave fmaf-accumulates elements 4*(64t+l)+c (t = 0,1,..; c = 0..3), then
+// a xor-butterfly (32,16,...,1) of plain adds.
+__global__ void __launch_bounds__(256) row_sqnorm_kernel(const float* __restrict__ X, int64_t N, int64_t ld,
+                                                         int D, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float* x = X + row * ld;
+    float acc = 0.f;
+    for (int k = lane * 4; k < D; k += 256) {
+        const f32x4 v = load_k4(x, k, D);
+        acc = fmaf(v.x, v.x, acc);
+        acc = fmaf(v.y, v.y, acc);
+        acc = fmaf(v.z, v.z, acc);
+        acc = fmaf(v.w, v.w, acc);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
+    if (lane == 0) out[row] = acc;
+}
+
+// ------------------------------------------------- radius -> squared threshold
+__device__ __forceinline__ float sqrt_rn(float x) { return (float)sqrt((double)x); }  // correctly rounded
+
+__device__ __forceinline__ float threshold_of_radius(float R) {
+    if (!(R > 0.f)) return 0.f;                     // R == 0 (or NaN): nothing is strictly inside
+    if (isinf(R)) return R;
+    float c = R * R;
+    for (int it = 0; it < 8; ++it) {                // walk down while the predecessor still reaches R
+        const float p = __uint_as_float(__float_as_uint(c) - 1u);
+        if (c > 0.f && sqrt_rn(p) >= R) c = p; else break;
+    }
+    for (int it = 0; it < 8; ++it) {                // walk up until sqrt_rn(c) >= R
+        if (sqrt_rn(c) < R) c = __uint_as_float(__float_as_uint(c) + 1u); else break;
+    }
+    return c;
+}
+
+__global__ void threshold_kernel(const float* __restrict__ R, int64_t n, float* __restrict__ T) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) T[i] = threshold_of_radius(R[i]);
+}
+
+// ------------------------------------------------------------- row sources
+struct DenseRows {            // rows base + (tile0 + t) * 128 + local row, zero rows past n
+    const float* base;
+    int64_t ld, n, tile0;
+    __device__ __forceinline__ const float* operator()(int t, int row) const {
+        const int64_t g = (tile0 + t) * TB + row;
+        return g < n ? base + g * ld : nullptr;
+    }
+};
+
+struct WorkItem {
+    int64_t prow0;     // first P row of this workgroup
+    int64_t qtile0;    // first Q tile of this workgroup's column chunk
+    int ntiles;
+};
+
+__device__ __forceinline__ WorkItem work_item(int64_t q_tiles, int nchunks) {
+    const int chunk = blockIdx.x % nchunks;        // consecutive blocks (= different XCDs) take different chunks
+    const int64_t rb = blockIdx.x / nchunks;
+    WorkItem w;
+    w.prow0 = rb * TB;
+    w.qtile0 = q_tiles * chunk / nchunks;
+    w.ntiles = (int)(q_tiles * (chunk + 1) / nchunks - w.qtile0);
+    return w;
+}
+
+// ------------------------------------------------------------ k-NN epilogue
+template <int KCAP>
+struct KnnEpilogue {
+    const float* qnorm;
+    int64_t nq, qtile0;
+    float* aux;                 // LDS [2][128] : |y_j|^2 of the tile (+inf past nq)
+    float xn[2];
+    float best[2][KCAP];
+    float aux_reg;
+    const LaneInfo& L;
+
+    __device__ __forceinline__ KnnEpilogue(const LaneInfo& l) : L(l) {}
+    __device__ __forceinline__ void aux_issue(int t) {
+        if (L.tid < TB) {
+            const int64_t j = (qtile0 + t) * TB + L.tid;
+            aux_reg = j < nq ? qnorm[j] : INFINITY;
+        }
+    }
+    __device__ __forceinline__ void aux_commit(int t) {
+        if (L.tid < TB) aux[(t & 1) * TB + L.tid] = aux_reg;
+    }
+    __device__ __forceinline__ void finish(int t, f32x16 (&acc)[2][2]) {
+        const float* a = aux + (t & 1) * TB + L.wm * 64 + L.h * 4;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 yn[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float d2[16];
+                float tmin = INFINITY;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    d2[reg] = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
+                    tmin = fminf(tmin, d2[reg]);
+                }
+                // common case after warm-up: no lane of the wave improves its list with this 32x32 tile
+                if (__any(tmin < best[nt][KCAP - 1])) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        if (__any(d2[reg] < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], d2[reg]);
+                }
+            }
+        }
+    }
+};
+
+// partial[(chunk * n_rows + row) * KCAP + s] = s-th smallest d2 of `row` inside column chunk `chunk`
+template <int KCAP>
+__global__ void __launch_bounds__(ENGINE_THREADS, 2)
+knn_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ldx, const float* __restrict__ xnorm,
+                   const float* __restrict__ Y, int64_t M, int64_t ldy, const float* __restrict__ ynorm,
+                   int D, int nchunks, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LaneInfo L;
+    const int64_t q_tiles = (M + TB - 1) / TB;
+    const WorkItem w = work_item(q_tiles, nchunks);
+
+    KnnEpilogue<KCAP> epi(L);
+    epi.qnorm = ynorm;
+    epi.nq = M;
+    epi.qtile0 = w.qtile0;
+    epi.aux = lds + ENGINE_LDS_FLOATS;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int64_t i = w.prow0 + L.wn * 64 + nt * 32 + L.r;
+        epi.xn[nt] = i < N ? xnorm[i] : 0.f;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = INFINITY;
+    }
+    const DenseRows qsrc{Y, ldy, M, w.qtile0};
+    const DenseRows psrc_base{X, ldx, N, w.prow0 / TB};
+    auto psrc = [&](int, int row) { return psrc_base(0, row); };
+    tile_pipeline(qsrc, psrc, w.ntiles, D, lds, L, epi);
+
+    // merge the 4 lists that cover each P row (2 half-waves x 2 Q-half waves) through LDS
+    float* mg = lds;                                   // [128][4][KCAP], staging slabs are free now
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float* dst = mg + ((L.wn * 64 + nt * 32 + L.r) * 4 + (L.wm * 2 + L.h)) * KCAP;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
+    }
+    __syncthreads();
+    if (L.tid < TB) {
+        const int64_t i = w.prow0 + L.tid;
+        if (i < N) {
+            const float* src = mg + L.tid * 4 * KCAP;
+            float m[KCAP];
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) m[s] = src[s];
+            for (int s = KCAP; s < 4 * KCAP; ++s) list_insert<KCAP>(m, src[s]);
+            const int chunk = blockIdx.x % nchunks;
+            float* out = partial + ((int64_t)chunk * N + i) * KCAP;
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) out[s] = m[s];
+        }
+    }
+}
+
+// radius[i] = sqrt_rn( (k+1)-th smallest d2 over all chunks )
+template <int KCAP>
+__global__ void knn_merge_kernel(const float* __restrict__ partial, int64_t N, int nchunks, int k1,
+                                 float* __restrict__ radii) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float m[KCAP];
+#pragma unroll
+    for (int s = 0; s < KCAP; ++s) m[s] = partial[i * KCAP + s];
+    for (int c = 1; c < nchunks; ++c) {
+        const float* src = partial + ((int64_t)c * N + i) * KCAP;
+        for (int s = 0; s < KCAP; ++s) list_insert<KCAP>(m, src[s]);
+    }
+    float r2 = m[0];
+#pragma unroll
+    for (int s = 1; s < KCAP; ++s)
+        if (s == k1 - 1) r2 = m[s];
+    radii[i] = sqrt_rn(r2);
+}
+
+// --------------------------------------------------------- PRDC counts epilogue
+struct CrossEpilogue {
+    const float* qnorm;
+    const float* qthr;
+    int64_t nq, qtile0;
+    float* aux;                 // LDS [2][2][128] : |c_j|^2 and T(r_cand[j]) of the tile
+    int32_t* col_count;
+    float xn[2], tr[2], rmin[2], margin[2];
+    float aux_n, aux_t;
+    const LaneInfo& L;
+
+    __device__ __forceinline__ CrossEpilogue(const LaneInfo& l) : L(l) {}
+    __device__ __forceinline__ void aux_issue(int t) {
+        if (L.tid < TB) {
+            const int64_t j = (qtile0 + t) * TB + L.tid;
+            aux_n = j < nq ? qnorm[j] : INFINITY;
+            aux_t = j < nq ? qthr[j] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void aux_commit(int t) {
+        if (L.tid < TB) {
+            aux[(t & 1) * 2 * TB + L.tid] = aux_n;
+            aux[(t & 1) * 2 * TB + TB + L.tid] = aux_t;
+        }
+    }
+    __device__ __forceinline__ void finish(int t, f32x16 (&acc)[2][2]) {
+        const float* a = aux + (t & 1) * 2 * TB + L.wm * 64 + L.h * 4;
+        const int64_t jbase = (qtile0 + t) * TB + L.wm * 64;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 yn[4], tc[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
+                tc[g4] = *reinterpret_cast<const f32x4*>(a + TB + mt * 32 + g4 * 8);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float tmin = INFINITY;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float d2 = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
+                    tmin = fminf(tmin, d2);
+                    // d2 - T < 0  <=>  d2 < T (IEEE subtraction never rounds across zero); NaN (inf - inf) is dropped
+                    margin[nt] = fminf(margin[nt], d2 - tc[reg >> 2][reg & 3]);
+                }
+                rmin[nt] = fminf(rmin[nt], tmin);
+                // wave-uniform and rare: k*N inside-pairs among N*M
+                if (__any(tmin < tr[nt])) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float d2 = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
+                        const unsigned long long mask = __ballot(d2 < tr[nt]);
+                        if (mask != 0ull && L.lane == 0) {
+                            const int64_t j = jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3);
+                            const int lo = __popcll(mask & 0xffffffffull);
+                            const int hi = __popcll(mask >> 32);
+                            if (lo) atomicAdd(col_count + j, lo);
+                            if (hi) atomicAdd(col_count + j + 4, hi);
+                        }
+                    }
+                }
+            }
+        }
+    }
+};
+
+__global__ void __launch_bounds__(ENGINE_THREADS, 2)
+prdc_cross_kernel(const float* __restrict__ R, int64_t Nr, int64_t ldr, const float* __restrict__ rnorm,
+                  const float* __restrict__ rthr,
+                  const float* __restrict__ C, int64_t Nc, int64_t ldc, const float* __restrict__ cnorm,
+                  const float* __restrict__ cthr, int D, int nchunks,
+                  int32_t* __restrict__ col_count, unsigned* __restrict__ row_min_bits,
+                  unsigned* __restrict__ row_any) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LaneInfo L;
+    const int64_t q_tiles = (Nc + TB - 1) / TB;
+    const WorkItem w = work_item(q_tiles, nchunks);
+
+    CrossEpilogue epi(L);
+    epi.qnorm = cnorm;
+    epi.qthr = cthr;
+    epi.nq = Nc;
+    epi.qtile0 = w.qtile0;
+    epi.aux = lds + ENGINE_LDS_FLOATS;
+    epi.col_count = col_count;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int64_t i = w.prow0 + L.wn * 64 + nt * 32 + L.r;
+        epi.xn[nt] = i < Nr ? rnorm[i] : 0.f;
+        epi.tr[nt] = i < Nr ? rthr[i] : 0.f;         // rows past Nr can never be "inside"
+        epi.rmin[nt] = INFINITY;
+        epi.margin[nt] = INFINITY;
+    }
+    const DenseRows qsrc{C, ldc, Nc, w.qtile0};
+    const DenseRows psrc_base{R, ldr, Nr, w.prow0 / TB};
+    auto psrc = [&](int, int row) { return psrc_base(0, row); };
+    tile_pipeline(qsrc, psrc, w.ntiles, D, lds, L, epi);
+
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float mn = fminf(epi.rmin[nt], __shfl_xor(epi.rmin[nt], 32));
+        const float mg = fminf(epi.margin[nt], __shfl_xor(epi.margin[nt], 32));
+        const bool any = mg < 0.f;
+        const int64_t i = w.prow0 + L.wn * 64 + nt * 32 + L.r;
+        if (L.h == 0 && i < Nr) {
+            atomicMin(row_min_bits + i, __float_as_uint(mn));    // d2 >= 0: uint order == float order
+            if (any) atomicOr(row_any + i, 1u);
+        }
+    }
+}
+
+__global__ void prdc_finish_kernel(const unsigned* __restrict__ row_min_bits, const unsigned* __restrict__ row_any_w,
+                                   int64_t Nr, float* __restrict__ row_min, uint8_t* __restrict__ row_any) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nr) return;
+    row_min[i] = sqrt_rn(__uint_as_float(row_min_bits[i]));
+    row_any[i] = row_any_w[i] ? 1 : 0;
+}
+
+__global__ void fill_u32_kernel(unsigned* __restrict__ p, int64_t n, unsigned v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// four integer totals: { #cols count>0, #rows any, sum counts, #rows row_min < r_ref }
+__global__ void __launch_bounds__(256) prdc_reduce_kernel(const int32_t* __restrict__ col_count, int64_t Nc,
+                                                          const uint8_t* __restrict__ row_any,
+                                                          const float* __restrict__ row_min,
+                                                          const float* __restrict__ r_ref, int64_t Nr,
+                                                          unsigned long long* __restrict__ out4) {
+    unsigned long long v[4] = {0, 0, 0, 0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < Nc; j += stride) {
+        const int c = col_count[j];
+        v[0] += c > 0;
+        v[2] += (unsigned long long)c;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < Nr; i += stride) {
+        v[1] += row_any[i] != 0;
+        v[3] += row_min[i] < r_ref[i];
+    }
+    __shared__ unsigned long long red[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned long long x = v[q];
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+        if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const unsigned long long s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        if (s) atomicAdd(out4 + threadIdx.x, s);
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static int choose_chunks(int64_t p_rows, int64_t q_rows) {
+    const int64_t row_blocks = ceil_div(p_rows, TB);
+    const int64_t q_tiles = ceil_div(q_rows, TB);
+    int64_t want = ceil_div(2048, row_blocks);           // aim for >= 2048 workgroups (256 CUs x 2 x 4 rounds)
+    if (want < 8) want = 8;                              // one chunk per XCD at least
+    want = ceil_div(want, 8) * 8;
+    if (want > q_tiles) want = q_tiles;
+    if (want > 64) want = 64;
+    return (int)(want < 1 ? 1 : want);
+}
+
+static int kcap_for(int k1) { return k1 <= 6 ? 6 : k1 <= 11 ? 11 : k1 <= 16 ? 16 : 32; }
+
+constexpr size_t PAIRWISE_LDS_BYTES = (ENGINE_LDS_FLOATS + 4 * TB) * sizeof(float);
+
+static int check_matrix(const float* p, int64_t n, int64_t ld, int D, const char* name) {
+    AM_REQUIRE(p != nullptr, AM_ERR_BAD_ARG, "%s is null", name);
+    AM_REQUIRE(n >= 1 && D >= 1, AM_ERR_BAD_SHAPE, "%s has shape %lld x %d", name, (long long)n, D);
+    AM_REQUIRE(aligned16(p) && ld % 4 == 0 && ld >= D, AM_ERR_BAD_ARG,
+               "%s must be 16-byte aligned with ld %% 4 == 0 and ld >= D (ld=%lld, D=%d)", name, (long long)ld, D);
+    return AM_OK;
+}
+
+static int launch_norms(const float* X, int64_t N, int64_t ld, int D, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, st, X, N, ld, D, out);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+template <int KCAP>
+static int launch_knn(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
+                      const float* yn, int D, int k1, int nchunks, float* partial, float* out_r, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_partial_kernel<KCAP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIRWISE_LDS_BYTES));
+        attr_done = true;
+    }
+    const int64_t blocks = ceil_div(N, TB) * nchunks;
+    hipLaunchKernelGGL(knn_partial_kernel<KCAP>, dim3((unsigned)blocks), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES, st,
+                       X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st,
+                       partial, N, nchunks, k1, out_r);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+}  // namespace am
+
+using namespace am;
+
+extern "C" size_t am_knn_workspace_bytes(int64_t N, int64_t M, int k) {
+    if (N < 1 || M < 1 || k < 1 || k > AM_MAX_K) return 0;
+    const int nchunks = choose_chunks(N, M);
+    Carver c(nullptr, 0);
+    c.take<float>(N);
+    c.take<float>(M);
+    c.take<float>((size_t)nchunks * N * kcap_for(k + 1));
+    return c.off;
+}
+
+extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const float* Y, int64_t M, int64_t ldy,
+                                int D, int k, float* out_r, void* ws, size_t ws_bytes, am_stream_t stream) {
+    int rc;
+    if ((rc = check_matrix(X, N, ldx, D, "X")) != AM_OK) return rc;
+    if ((rc = check_matrix(Y, M, ldy, D, "Y")) != AM_OK) return rc;
+    AM_REQUIRE(out_r != nullptr, AM_ERR_BAD_ARG, "out_r is null");
+    AM_REQUIRE(k >= 1, AM_ERR_BAD_SHAPE, "nearest_k must be >= 1 (got %d)", k);
+    AM_REQUIRE(k <= AM_MAX_K, AM_ERR_UNSUPPORTED_K, "nearest_k %d > AM_MAX_K %d", k, AM_MAX_K);
+    AM_REQUIRE((int64_t)k + 1 <= M, AM_ERR_BAD_SHAPE, "k + 1 = %d exceeds the %lld available rows (kthvalue out of range)",
+               k + 1, (long long)M);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nchunks = choose_chunks(N, M);
+    const int k1 = k + 1, kcap = kcap_for(k1);
+    Carver c(ws, ws_bytes);
+    float* xn = c.take<float>(N);
+    float* yn = c.take<float>(M);
+    float* partial = c.take<float>((size_t)nchunks * N * kcap);
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    if ((rc = launch_norms(X, N, ldx, D, xn, st)) != AM_OK) return rc;
+    const bool self = (Y == X && M == N && ldy == ldx);
+    if (self) yn = xn;
+    else if ((rc = launch_norms(Y, M, ldy, D, yn, st)) != AM_OK) return rc;
+    switch (kcap) {
+        case 6:  return launch_knn<6>(X, N, ldx, xn, Y, M, ldy, yn, D, k1, nchunks, partial, out_r, st);
+        case 11: return launch_knn<11>(X, N, ldx, xn, Y, M, ldy, yn, D, k1, nchunks, partial, out_r, st);
+        case 16: return launch_knn<16>(X, N, ldx, xn, Y, M, ldy, yn, D, k1, nchunks, partial, out_r, st);
+        default: return launch_knn<32>(X, N, ldx, xn, Y, M, ldy, yn, D, k1, nchunks, partial, out_r, st);
+    }
+}
+
+extern "C" size_t am_prdc_workspace_bytes(int64_t Nr, int64_t Nc) {
+    if (Nr < 1 || Nc < 1) return 0;
+    Carver c(nullptr, 0);
+    c.take<float>(Nr); c.take<float>(Nr);          // |r|^2, T(r_ref)
+    c.take<float>(Nc); c.take<float>(Nc);          // |c|^2, T(r_cand)
+    c.take<unsigned>(Nr); c.take<unsigned>(Nr);    // row_min bits, row_any words
+    return c.off;
+}
+
+extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const float* C, int64_t Nc, int64_t ldc,
+                                  int D, const float* r_ref, const float* r_cand, int32_t* out_col_count,
+                                  uint8_t* out_row_any, float* out_row_min, void* ws, size_t ws_bytes,
+                                  am_stream_t stream) {
+    int rc;
+    if ((rc = check_matrix(R, Nr, ldr, D, "R")) != AM_OK) return rc;
+    if ((rc = check_matrix(C, Nc, ldc, D, "C")) != AM_OK) return rc;
+    AM_REQUIRE(r_ref && r_cand && out_col_count && out_row_any && out_row_min, AM_ERR_BAD_ARG, "null radius/output pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carver c(ws, ws_bytes);
+    float* rn = c.take<float>(Nr);
+    float* rt = c.take<float>(Nr);
+    float* cn = c.take<float>(Nc);
+    float* ct = c.take<float>(Nc);
+    unsigned* rmin = c.take<unsigned>(Nr);
+    unsigned* rany = c.take<unsigned>(Nr);
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    if ((rc = launch_norms(R, Nr, ldr, D, rn, st)) != AM_OK) return rc;
+    if ((rc = launch_norms(C, Nc, ldc, D, cn, st)) != AM_OK) return rc;
+    hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, r_ref, Nr, rt);
+    hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)ceil_div(Nc, 256)), dim3(256), 0, st, r_cand, Nc, ct);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, rmin, Nr, 0x7f800000u);
+    AM_LAUNCH_CHECK();
+    AM_HIP_TRY(hipMemsetAsync(rany, 0, (size_t)Nr * sizeof(unsigned), st));
+    AM_HIP_TRY(hipMemsetAsync(out_col_count, 0, (size_t)Nc * sizeof(int32_t), st));
+    static bool attr_done = false;
+    if (!attr_done) {
+        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&prdc_cross_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIRWISE_LDS_BYTES));
+        attr_done = true;
+    }
+    const int nchunks = choose_chunks(Nr, Nc);
+    const int64_t blocks = ceil_div(Nr, TB) * nchunks;
+    hipLaunchKernelGGL(prdc_cross_kernel, dim3((unsigned)blocks), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES, st,
+                       R, Nr, ldr, rn, rt, C, Nc, ldc, cn, ct, D, nchunks, out_col_count, rmin, rany);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(prdc_finish_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, rmin, rany, Nr,
+                       out_row_min, out_row_any);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+extern "C" int am_prdc_reduce(const int32_t* col_count, int64_t Nc, const uint8_t* row_any, const float* row_min,
+                              const float* r_ref, int64_t Nr, int64_t* out4, am_stream_t stream) {
+    AM_REQUIRE(col_count && row_any && row_min && r_ref && out4, AM_ERR_BAD_ARG, "null pointer");
+    AM_REQUIRE(Nc >= 1 && Nr >= 1, AM_ERR_BAD_SHAPE, "empty input");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AM_HIP_TRY(hipMemsetAsync(out4, 0, 4 * sizeof(int64_t), st));
+    const int64_t n = Nc > Nr ? Nc : Nr;
+    int blocks = (int)ceil_div(n, 256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(prdc_reduce_kernel, dim3(blocks), dim3(256), 0, st, col_count, Nc, row_any, row_min, r_ref, Nr,
+                       reinterpret_cast<unsigned long long*>(out4));
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}

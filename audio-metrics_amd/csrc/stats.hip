@@ -1,0 +1,361 @@
+// Per-set sufficient statistics: column means and unbiased covariance of an
+// N x D f32 embedding matrix (reference data.py:37-58), and the Chan merge of two
+// (n, mean, cov) triples (reference data.py:77-94).
+//
+//   pass 1  column sums, f64 accumulation                     (HBM-bound, N*D*4 bytes)
+//   pass 2  centred scatter  S = sum_n (x_n-mu)(x_n-mu)^T      (f32 MFMA, 2*N*D^2 flop)
+//           - only the upper-triangular 128x128 output tiles are computed,
+//           - each workgroup owns (tile, row slab); products run on
+//             v_mfma_f32_32x32x2_f32 in chains of FLUSH*32 rows that are then
+//             added into f64 accumulators, so rounding does not grow with N,
+//           - per-slab f64 partial tiles go to the workspace and are summed in a
+//             fixed order (deterministic, no float atomics).
+#include "am_common.h"
+#include "tile_engine.h"
+
+namespace am {
+
+constexpr int SC_ROWS = 32;          // rows of X per stage (MFMA k extent 2 -> 16 steps)
+constexpr int SC_LD = 128;           // LDS slab row stride (floats); reads are lane-consecutive
+constexpr int SC_SLAB = SC_ROWS * SC_LD;
+constexpr int SC_FLUSH = 8;          // stages per f32 chain (256 rows)
+
+// ---------------------------------------------------------------- column sums
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ld,
+                                                             int D, int64_t rows_per_block,
+                                                             double* __restrict__ partial) {
+    __shared__ double red[256 * 4];
+    const int tid = threadIdx.x;
+    const int cgs = (D + 3) / 4;
+    const int cpp = cgs < 256 ? cgs : 256;
+    const int rpar = 256 / cpp;
+    const int my_cg = tid % cpp, my_r = tid / cpp;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
+    for (int cg0 = 0; cg0 < cgs; cg0 += cpp) {
+        const int cg = cg0 + my_cg;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        if (cg < cgs && my_r < rpar) {
+            for (int64_t row = r0 + my_r; row < r1; row += rpar) {
+                const f32x4 v = load_k4(X + row * ld, cg * 4, D);
+                s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+            }
+        }
+        red[tid * 4 + 0] = s0; red[tid * 4 + 1] = s1; red[tid * 4 + 2] = s2; red[tid * 4 + 3] = s3;
+        __syncthreads();
+        if (my_r == 0 && cg < cgs) {
+            for (int rr = 1; rr < rpar; ++rr) {
+                const int o = (rr * cpp + my_cg) * 4;
+                s0 += red[o]; s1 += red[o + 1]; s2 += red[o + 2]; s3 += red[o + 3];
+            }
+            double* out = partial + (int64_t)blockIdx.x * D + cg * 4;
+            out[0] = s0;
+            if (cg * 4 + 1 < D) out[1] = s1;
+            if (cg * 4 + 2 < D) out[2] = s2;
+            if (cg * 4 + 3 < D) out[3] = s3;
+        }
+        __syncthreads();
+    }
+}
+
+// out[d] = (sum_b partial[b][d]) * scale
+__global__ void colsum_reduce_kernel(const double* __restrict__ partial, int nblocks, int D, double scale,
+                                     double* __restrict__ out) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    double s = 0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * D + d];
+    out[d] = s * scale;
+}
+
+// ------------------------------------------------------------ centred scatter
+__device__ __forceinline__ void tri_decode(int t, int T, int& tp, int& tq) {   // t-th pair with tp <= tq
+    tp = 0;
+    int rem = t;
+    while (rem >= T - tp) { rem -= T - tp; ++tp; }
+    tq = tp + rem;
+}
+
+__global__ void __launch_bounds__(ENGINE_THREADS, 1)
+scatter_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ld, int D, const double* __restrict__ mean,
+                       int64_t rows_per_slab, int ntri, double* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * SC_SLAB];    // [2 stages][A slab, B slab]
+    const LaneInfo L;
+    const int T = (D + TB - 1) / TB;
+    const int tri = blockIdx.x % ntri;
+    const int slab = blockIdx.x / ntri;
+    int tp, tq;
+    tri_decode(tri, T, tp, tq);
+    const int64_t r0 = (int64_t)slab * rows_per_slab;
+    const int64_t r1 = (r0 + rows_per_slab < N) ? r0 + rows_per_slab : N;
+    const int nstages = (int)((r1 - r0 + SC_ROWS - 1) / SC_ROWS);
+
+    // staging role: 4 rows (tid/32 + 8q) x one float4 column group (tid%32) per operand
+    const int srow = L.tid >> 5, sc4 = (L.tid & 31) * 4;
+    const int colA = tp * TB + sc4, colB = tq * TB + sc4;
+    f32x4 muA, muB;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        muA[e] = (colA + e < D) ? (float)mean[colA + e] : 0.f;
+        muB[e] = (colB + e < D) ? (float)mean[colB + e] : 0.f;
+    }
+    f32x4 ra[4], rb[4];
+    auto centred = [&](const float* row, int col, const f32x4& mu) {
+        f32x4 v = load_k4(row, col, D);
+        if (row != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (col + e < D) ? v[e] - mu[e] : 0.f;
+        }
+        return v;
+    };
+    auto issue = [&](int st) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t row = r0 + (int64_t)st * SC_ROWS + q * 8 + srow;
+            const float* p = row < r1 ? X + row * ld : nullptr;
+            ra[q] = centred(p, colA, muA);
+            rb[q] = centred(p, colB, muB);
+        }
+    };
+    auto commit = [&](int st) {
+        float* s = lds + (st & 1) * 2 * SC_SLAB + srow * SC_LD + sc4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<f32x4*>(s + q * 8 * SC_LD) = ra[q];
+            *reinterpret_cast<f32x4*>(s + SC_SLAB + q * 8 * SC_LD) = rb[q];
+        }
+    };
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    double acc64[2][2][16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc64[a][b][i] = 0.0;
+
+    if (nstages > 0) {
+        issue(0);
+        commit(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nstages; ++st) {
+        const bool more = st + 1 < nstages;
+        if (more) issue(st + 1);
+        const float* sA = lds + (st & 1) * 2 * SC_SLAB + L.wm * 64 + L.r;
+        const float* sB = sA - L.wm * 64 + SC_SLAB + L.wn * 64;
+#pragma unroll
+        for (int ks = 0; ks < SC_ROWS / 2; ++ks) {
+            const int o = (ks * 2 + L.h) * SC_LD;
+            const float a0 = sA[o], a1 = sA[o + 32];
+            const float b0 = sB[o], b1 = sB[o + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if ((st % SC_FLUSH) == SC_FLUSH - 1 || !more) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc64[a][b][i] += (double)acc[a][b][i];
+            zero_acc(acc);
+        }
+        if (more) commit(st + 1);
+        __syncthreads();
+    }
+    // partial tile, row-major 128x128 f64: row = output row p (MFMA m), col = q (MFMA n = lane&31)
+    double* out = partial + ((int64_t)slab * ntri + tri) * (TB * TB);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int p = L.wm * 64 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * L.h;
+                const int q = L.wn * 64 + nt * 32 + L.r;
+                out[p * TB + q] = acc64[mt][nt][i];
+            }
+}
+
+// out[p][q] = scale * sum_slab partial[slab][tri(p,q)][...]; lower tiles mirror the upper ones
+__global__ void scatter_reduce_kernel(const double* __restrict__ partial, int nslabs, int ntri, int D, double scale,
+                                      double* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = blockIdx.y;
+    if (q >= D) return;
+    const int T = (D + TB - 1) / TB;
+    int a = p, b = q;
+    if (a / TB > b / TB) { a = q; b = p; }
+    const int tp = a / TB, tq = b / TB;
+    const int tri = tp * T - tp * (tp - 1) / 2 + (tq - tp);
+    const double* src = partial + (int64_t)tri * (TB * TB) + (a % TB) * TB + (b % TB);
+    double s = 0;
+    for (int sl = 0; sl < nslabs; ++sl) s += src[(int64_t)sl * ntri * (TB * TB)];
+    out[(int64_t)p * D + q] = s * scale;
+}
+
+__global__ void zero_f64_kernel(double* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+
+// ------------------------------------------------------------------ Chan merge
+__global__ void merge_cov_kernel(int64_t n1, const double* __restrict__ mean1, const double* cov1, int64_t n2,
+                                 const double* __restrict__ mean2, const double* __restrict__ cov2, int D,
+                                 double* out_cov) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= D) return;
+    const double n = (double)(n1 + n2);
+    const double w1 = (double)(n1 - 1) / (n - 1);
+    const double w2 = (double)(n2 - 1) / (n - 1);
+    const double wd = ((double)n1 * (double)n2 / n) / (n - 1);
+    const double di = mean1[i] - mean2[i], dj = mean1[j] - mean2[j];
+    const int64_t o = (int64_t)i * D + j;
+    // same association as the reference: (w1*cov1 + w2*cov2) + wd*outer
+    out_cov[o] = (w1 * cov1[o] + w2 * cov2[o]) + wd * (di * dj);
+}
+
+__global__ void merge_mean_kernel(int64_t n1, const double* mean1, int64_t n2, const double* __restrict__ mean2, int D,
+                                  double* out_mean) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    out_mean[i] = ((double)n1 * mean1[i] + (double)n2 * mean2[i]) / (double)(n1 + n2);
+}
+
+// ------------------------------------------------------------------ host side
+struct StatsPlan {
+    int cs_blocks;
+    int64_t cs_rows;
+    int ntri, nslabs;
+    int64_t slab_rows;
+};
+
+static StatsPlan plan_stats(int64_t N, int D) {
+    StatsPlan p;
+    int64_t b = ceil_div(N, 64);
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    p.cs_rows = ceil_div(N, b);
+    p.cs_blocks = (int)ceil_div(N, p.cs_rows);
+    const int T = (int)ceil_div(D, TB);
+    p.ntri = T * (T + 1) / 2;
+    int64_t s = ceil_div(768, p.ntri);                       // ~3 workgroups per CU
+    const int64_t max_s = ceil_div(N, SC_ROWS * SC_FLUSH);   // at least one full f32 chain per slab
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    p.slab_rows = ceil_div(ceil_div(N, s), SC_ROWS) * SC_ROWS;
+    p.nslabs = (int)ceil_div(N, p.slab_rows);
+    return p;
+}
+
+static size_t stats_ws(int64_t N, int D, const StatsPlan& p) {
+    Carver c(nullptr, 0);
+    c.take<double>((size_t)p.cs_blocks * D);
+    c.take<double>((size_t)p.nslabs * p.ntri * TB * TB);
+    c.take<double>(D);
+    return c.off;
+}
+
+static int check_x(const float* X, int64_t N, int D, int64_t ld) {
+    AM_REQUIRE(X != nullptr, AM_ERR_BAD_ARG, "X is null");
+    AM_REQUIRE(N >= 1 && D >= 1, AM_ERR_BAD_SHAPE, "X has shape %lld x %d", (long long)N, D);
+    AM_REQUIRE(aligned16(X) && ld % 4 == 0 && ld >= D, AM_ERR_BAD_ARG,
+               "X must be 16-byte aligned with ld %% 4 == 0 and ld >= D (ld=%lld, D=%d)", (long long)ld, D);
+    return AM_OK;
+}
+
+static int run_colsum(const float* X, int64_t N, int D, int64_t ld, double scale, double* out, double* partial,
+                      const StatsPlan& p, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.cs_blocks), dim3(256), 0, st, X, N, ld, D, p.cs_rows, partial);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)ceil_div(D, 128)), dim3(128), 0, st, partial, p.cs_blocks, D,
+                       scale, out);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+static int run_scatter(const float* X, int64_t N, int D, int64_t ld, const double* mean, double scale, double* out,
+                       double* partial, const StatsPlan& p, hipStream_t st) {
+    hipLaunchKernelGGL(scatter_partial_kernel, dim3((unsigned)(p.ntri * p.nslabs)), dim3(ENGINE_THREADS), 0, st, X, N, ld,
+                       D, mean, p.slab_rows, p.ntri, partial);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scatter_reduce_kernel, dim3((unsigned)ceil_div(D, 128), (unsigned)D), dim3(128), 0, st, partial,
+                       p.nslabs, p.ntri, D, scale, out);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+}  // namespace am
+
+using namespace am;
+
+extern "C" size_t am_stats_workspace_bytes(int64_t N, int D) {
+    if (N < 1 || D < 1) return 0;
+    return stats_ws(N, D, plan_stats(N, D));
+}
+
+extern "C" int am_colsum_f32(const float* X, int64_t N, int D, int64_t ld, double* colsum, void* ws, size_t ws_bytes,
+                             am_stream_t stream) {
+    int rc;
+    if ((rc = check_x(X, N, D, ld)) != AM_OK) return rc;
+    AM_REQUIRE(colsum != nullptr, AM_ERR_BAD_ARG, "colsum is null");
+    const StatsPlan p = plan_stats(N, D);
+    Carver c(ws, ws_bytes);
+    double* cs_part = c.take<double>((size_t)p.cs_blocks * D);
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    return run_colsum(X, N, D, ld, 1.0, colsum, cs_part, p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int am_scatter_f32(const float* X, int64_t N, int D, int64_t ld, const double* mean, double* scatter,
+                              void* ws, size_t ws_bytes, am_stream_t stream) {
+    int rc;
+    if ((rc = check_x(X, N, D, ld)) != AM_OK) return rc;
+    AM_REQUIRE(mean && scatter, AM_ERR_BAD_ARG, "mean/scatter is null");
+    const StatsPlan p = plan_stats(N, D);
+    Carver c(ws, ws_bytes);
+    c.take<double>((size_t)p.cs_blocks * D);
+    double* sc_part = c.take<double>((size_t)p.nslabs * p.ntri * TB * TB);
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    return run_scatter(X, N, D, ld, mean, 1.0, scatter, sc_part, p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int am_stats_f32(const float* X, int64_t N, int D, int64_t ld, double* mean, double* cov, void* ws,
+                            size_t ws_bytes, am_stream_t stream) {
+    int rc;
+    if ((rc = check_x(X, N, D, ld)) != AM_OK) return rc;
+    AM_REQUIRE(mean && cov, AM_ERR_BAD_ARG, "mean/cov is null");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const StatsPlan p = plan_stats(N, D);
+    Carver c(ws, ws_bytes);
+    double* cs_part = c.take<double>((size_t)p.cs_blocks * D);
+    double* sc_part = c.take<double>((size_t)p.nslabs * p.ntri * TB * TB);
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    if ((rc = run_colsum(X, N, D, ld, 1.0 / (double)N, mean, cs_part, p, st)) != AM_OK) return rc;
+    if (N == 1) {                                          // data.py:40-42
+        hipLaunchKernelGGL(zero_f64_kernel, dim3((unsigned)ceil_div((int64_t)D * D, 256)), dim3(256), 0, st, cov,
+                           (int64_t)D * D);
+        AM_LAUNCH_CHECK();
+        return AM_OK;
+    }
+    return run_scatter(X, N, D, ld, mean, 1.0 / (double)(N - 1), cov, sc_part, p, st);
+}
+
+extern "C" int am_stats_merge_f64(int64_t n1, const double* mean1, const double* cov1, int64_t n2, const double* mean2,
+                                  const double* cov2, int D, double* out_mean, double* out_cov, am_stream_t stream) {
+    AM_REQUIRE(mean1 && cov1 && mean2 && cov2 && out_mean && out_cov, AM_ERR_BAD_ARG, "null pointer");
+    AM_REQUIRE(D >= 1 && n1 >= 1 && n2 >= 1, AM_ERR_BAD_SHAPE, "n1=%lld n2=%lld D=%d", (long long)n1, (long long)n2, D);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(merge_cov_kernel, dim3((unsigned)ceil_div(D, 128), (unsigned)D), dim3(128), 0, st, n1, mean1, cov1,
+                       n2, mean2, cov2, D, out_cov);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(merge_mean_kernel, dim3((unsigned)ceil_div(D, 128)), dim3(128), 0, st, n1, mean1, n2, mean2, D,
+                       out_mean);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}

@@ -1,0 +1,203 @@
+"""Thin torch<->C-ABI glue: device tensors in, device tensors out.
+
+PyTorch is used only as the device-memory allocator and stream owner; every
+computation below is a call into libaudio_metrics_hip.so on torch's current
+HIP stream.  There is no CPU path: CPU tensors are rejected.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _require_cuda(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.HipLibraryError(
+            f"{name} must be a tensor resident on the MI355X (got {type(t).__name__} on "
+            f"{getattr(t, 'device', 'host')}); this package has no CPU fallback")
+
+
+def as_matrix(e, name="embeddings"):
+    """(N, D) f32 device matrix with unit column stride, 16-B aligned rows
+    (row stride % 4 == 0).  Copies (zero-padding the row stride) only if needed."""
+    _require_cuda(e, name)
+    if e.dim() != 2:
+        raise ValueError(f"{name} must be 2-D, got shape {tuple(e.shape)}")
+    if e.dtype != torch.float32:
+        e = e.to(torch.float32)
+    n, d = e.shape
+    ok = e.stride(1) == 1 and e.stride(0) % 4 == 0 and e.stride(0) >= d and e.data_ptr() % 16 == 0
+    if n > 0 and not ok:
+        ld = (d + 3) // 4 * 4
+        buf = torch.zeros((n, ld), dtype=torch.float32, device=e.device)
+        buf[:, :d] = e
+        e = buf[:, :d]
+    return e
+
+
+def _ld(e):
+    """Leading dimension handed to the C ABI (a 1-row view may carry any stride)."""
+    if e.shape[0] > 1:
+        return e.stride(0)
+    return (e.shape[1] + 3) // 4 * 4
+
+
+def _f64(t, name):
+    _require_cuda(t, name)
+    if t.dtype != torch.float64 or not t.is_contiguous():
+        t = t.to(torch.float64).contiguous()
+    return t
+
+
+# ------------------------------------------------------------------ statistics
+def stats(e):
+    """mean f64[D], unbiased covariance f64[D, D] of the rows of e (data.py:37-58)."""
+    lib = _lib.load()
+    e = as_matrix(e)
+    n, d = e.shape
+    mean = torch.empty(d, dtype=torch.float64, device=e.device)
+    cov = torch.empty((d, d), dtype=torch.float64, device=e.device)
+    nb = lib.am_stats_workspace_bytes(n, d)
+    ws = _workspace(nb, e.device)
+    _lib.check(lib.am_stats_f32(_ptr(e), n, d, _ld(e), _ptr(mean), _ptr(cov), _ptr(ws), nb, _stream()), "am_stats_f32")
+    return mean, cov
+
+
+def colsum(e):
+    lib = _lib.load()
+    e = as_matrix(e)
+    n, d = e.shape
+    out = torch.empty(d, dtype=torch.float64, device=e.device)
+    nb = lib.am_stats_workspace_bytes(n, d)
+    ws = _workspace(nb, e.device)
+    _lib.check(lib.am_colsum_f32(_ptr(e), n, d, _ld(e), _ptr(out), _ptr(ws), nb, _stream()), "am_colsum_f32")
+    return out
+
+
+def scatter(e, mean):
+    """sum_n (x_n - mean)(x_n - mean)^T, not divided (multi-GPU building block)."""
+    lib = _lib.load()
+    e = as_matrix(e)
+    mean = _f64(mean, "mean")
+    n, d = e.shape
+    out = torch.empty((d, d), dtype=torch.float64, device=e.device)
+    nb = lib.am_stats_workspace_bytes(n, d)
+    ws = _workspace(nb, e.device)
+    _lib.check(lib.am_scatter_f32(_ptr(e), n, d, _ld(e), _ptr(mean), _ptr(out), _ptr(ws), nb, _stream()),
+               "am_scatter_f32")
+    return out
+
+
+def stats_merge(n1, mean1, cov1, n2, mean2, cov2, inplace=False):
+    """Chan merge (data.py:77-94).  inplace=True overwrites (mean1, cov1)."""
+    lib = _lib.load()
+    mean1, cov1, mean2, cov2 = (_f64(t, "stats") for t in (mean1, cov1, mean2, cov2))
+    d = mean1.numel()
+    om = mean1 if inplace else torch.empty_like(mean1)
+    oc = cov1 if inplace else torch.empty_like(cov1)
+    _lib.check(lib.am_stats_merge_f64(int(n1), _ptr(mean1), _ptr(cov1), int(n2), _ptr(mean2), _ptr(cov2), d,
+                                      _ptr(om), _ptr(oc), _stream()), "am_stats_merge_f64")
+    return om, oc
+
+
+# ------------------------------------------------------------------ Frechet
+def frechet(mu_x, cov_x, mu_y, cov_y, max_iter=64, tol=1e-13):
+    lib = _lib.load()
+    mu_x, cov_x, mu_y, cov_y = (_f64(t, "stats") for t in (mu_x, cov_x, mu_y, cov_y))
+    d = mu_x.numel()
+    if cov_x.shape != (d, d) or cov_y.shape != (d, d) or mu_y.numel() != d:
+        raise ValueError(f"inconsistent shapes: mu {tuple(mu_x.shape)}/{tuple(mu_y.shape)}, "
+                         f"cov {tuple(cov_x.shape)}/{tuple(cov_y.shape)}")
+    out = (ctypes.c_double * 4)()
+    nb = lib.am_frechet_workspace_bytes(d)
+    ws = _workspace(nb, mu_x.device)
+    _lib.check(lib.am_frechet_f64(_ptr(mu_x), _ptr(cov_x), _ptr(mu_y), _ptr(cov_y), d, int(max_iter), float(tol),
+                                  ctypes.cast(out, ctypes.c_void_p), _ptr(ws), nb, _stream()), "am_frechet_f64")
+    return dict(fd=out[0], tr_sqrt=out[1], iters=int(out[2]), resid=out[3])
+
+
+def apa_scalar(d_y_x, d_y_xp, d_x_xp):
+    return _lib.load().am_apa_f64(float(d_y_x), float(d_y_xp), float(d_x_xp))
+
+
+# ------------------------------------------------------------------ kernel distance
+def kd_poly(x, y, idx1, idx2, gamma, coef0, degree):
+    """Per-subset unbiased MMD^2 (f64[S] device tensor).  idx1/idx2: int64 [S, m]."""
+    lib = _lib.load()
+    x, y = as_matrix(x, "features_1"), as_matrix(y, "features_2")
+    _require_cuda(idx1, "idx1")
+    _require_cuda(idx2, "idx2")
+    idx1 = idx1.to(torch.int64).contiguous()
+    idx2 = idx2.to(torch.int64).contiguous()
+    s, m = idx1.shape
+    out = torch.empty(s, dtype=torch.float64, device=x.device)
+    nb = lib.am_kd_workspace_bytes(s, m)
+    ws = _workspace(nb, x.device)
+    _lib.check(lib.am_kd_poly_f32(_ptr(x), x.shape[0], _ld(x), _ptr(y), y.shape[0], _ld(y), x.shape[1],
+                                  _ptr(idx1), _ptr(idx2), s, m, float(gamma), float(coef0), int(degree),
+                                  _ptr(out), _ptr(ws), nb, _stream()), "am_kd_poly_f32")
+    return out
+
+
+# ------------------------------------------------------------------ PRDC
+def knn_radii(x, k, columns=None):
+    """(k+1)-th smallest distance from each row of x to the rows of `columns`
+    (default: x itself) - prdc.py:4-14."""
+    lib = _lib.load()
+    x = as_matrix(x)
+    y = x if columns is None else as_matrix(columns, "columns")
+    n, d = x.shape
+    if y.shape[1] != d:
+        raise ValueError("feature dimensions differ")
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    nb = lib.am_knn_workspace_bytes(n, y.shape[0], int(k))
+    ws = _workspace(nb, x.device)
+    _lib.check(lib.am_knn_radii_f32(_ptr(x), n, _ld(x), _ptr(y), y.shape[0], _ld(y), d, int(k), _ptr(out),
+                                    _ptr(ws), nb, _stream()), "am_knn_radii_f32")
+    return out
+
+
+def prdc_counts(ref, cand, r_ref, r_cand):
+    """col_count i32[Nc], row_any u8[Nr], row_min f32[Nr] (prdc.py:34-48)."""
+    lib = _lib.load()
+    ref, cand = as_matrix(ref, "reference"), as_matrix(cand, "candidate")
+    _require_cuda(r_ref, "r_ref")
+    _require_cuda(r_cand, "r_cand")
+    r_ref = r_ref.to(torch.float32).contiguous()
+    r_cand = r_cand.to(torch.float32).contiguous()
+    nr, d = ref.shape
+    nc = cand.shape[0]
+    if r_ref.numel() != nr or r_cand.numel() != nc or cand.shape[1] != d:
+        raise ValueError("radius / embedding shapes do not match")
+    col = torch.empty(nc, dtype=torch.int32, device=ref.device)
+    rany = torch.empty(nr, dtype=torch.uint8, device=ref.device)
+    rmin = torch.empty(nr, dtype=torch.float32, device=ref.device)
+    nb = lib.am_prdc_workspace_bytes(nr, nc)
+    ws = _workspace(nb, ref.device)
+    _lib.check(lib.am_prdc_counts_f32(_ptr(ref), nr, _ld(ref), _ptr(cand), nc, _ld(cand), d, _ptr(r_ref),
+                                      _ptr(r_cand), _ptr(col), _ptr(rany), _ptr(rmin), _ptr(ws), nb, _stream()),
+               "am_prdc_counts_f32")
+    return col, rany, rmin
+
+
+def prdc_reduce(col, rany, rmin, r_ref):
+    """Four integer totals as a device int64[4]:
+    (#cols with count>0, #rows with any, sum of counts, #rows with row_min < r_ref)."""
+    lib = _lib.load()
+    out = torch.empty(4, dtype=torch.int64, device=col.device)
+    _lib.check(lib.am_prdc_reduce(_ptr(col), col.numel(), _ptr(rany), _ptr(rmin), _ptr(r_ref), rany.numel(),
+                                  _ptr(out), _stream()), "am_prdc_reduce")
+    return out

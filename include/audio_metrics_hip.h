@@ -1,0 +1,150 @@
+/*
+ * audio_metrics_hip.h - C ABI of the MI355X (gfx950) distribution-distance library.
+ *
+ * This is the drop-in boundary for the hot path of SonyCSLParis/audio-metrics
+ * (reference v1.0.4): everything that happens between "N x D embedding matrix"
+ * and "metric value".  The reference has no FFI for this path - its boundary
+ * is the Python call surface of data.py and metrics/{fad,kd,prdc,apa}.py - so every entry point
+ * below cites the reference function (file:line, relative to the reference
+ * checkout) whose arithmetic it replaces.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C types only; no torch / HIP types in signatures (am_stream_t is a
+ *    hipStream_t passed as void*; NULL = the default stream);
+ *  - every data pointer is a DEVICE pointer owned by the caller unless the
+ *    parameter is documented as "host"; matrices are row-major with an explicit
+ *    leading dimension `ld` (elements), base pointers 16-byte aligned and
+ *    ld % 4 == 0 for float matrices;
+ *  - the library allocates nothing: scratch comes from a caller-provided
+ *    workspace whose size is returned by the matching workspace-size query;
+ *  - all work is enqueued on `stream`; functions return without synchronising
+ *    unless documented otherwise; return value 0 = AM_OK, negative = am_status;
+ *  - no exceptions cross the ABI; am_last_error() gives a thread-local message.
+ */
+#ifndef AUDIO_METRICS_HIP_H
+#define AUDIO_METRICS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* am_stream_t;
+
+typedef enum am_status {
+    AM_OK = 0,
+    AM_ERR_BAD_ARG = -1,          /* null pointer, misaligned base, ld % 4 != 0 ...           */
+    AM_ERR_BAD_SHAPE = -2,        /* empty input, D < 1, k + 1 > N (torch.kthvalue would raise) */
+    AM_ERR_UNSUPPORTED_K = -3,    /* nearest_k > AM_MAX_K                                      */
+    AM_ERR_WORKSPACE = -4,        /* workspace missing or too small                            */
+    AM_ERR_NO_CONVERGENCE = -5,   /* Newton-Schulz produced a non-finite trace                 */
+    AM_ERR_HIP = -6               /* a HIP runtime call failed (see am_last_error)             */
+} am_status;
+
+#define AM_MAX_K 31               /* largest nearest_k of am_knn_radii_f32 (k+1 <= 32 slots)   */
+
+const char* am_version(void);
+const char* am_status_string(int status);
+const char* am_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * A1/A2  per-set sufficient statistics        reference: data.py:37-47, 49-58
+ *   mean[D]  = column means of X (f64 accumulation of the f32 inputs)
+ *   cov[D*D] = unbiased covariance  sum (x-mean)(x-mean)^T / (N-1)   (f64 out;
+ *              products on the f32 matrix cores in short chains, f64 across)
+ *   N == 1 -> cov = 0 (data.py:40-42).  N == 0 -> AM_ERR_BAD_SHAPE.
+ * am_colsum_f32 / am_scatter_f32 are the two halves (column sums; centred
+ * scatter matrix, NOT divided) that a multi-GPU caller all-reduces in between.
+ * ------------------------------------------------------------------------- */
+size_t am_stats_workspace_bytes(int64_t N, int D);
+int am_stats_f32(const float* X, int64_t N, int D, int64_t ld,
+                 double* mean, double* cov,
+                 void* ws, size_t ws_bytes, am_stream_t stream);
+int am_colsum_f32(const float* X, int64_t N, int D, int64_t ld,
+                  double* colsum, void* ws, size_t ws_bytes, am_stream_t stream);
+int am_scatter_f32(const float* X, int64_t N, int D, int64_t ld, const double* mean,
+                   double* scatter, void* ws, size_t ws_bytes, am_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * A3  Chan / pairwise merge of two (n, mean, cov) triples in f64
+ *                                             reference: data.py:77-94
+ *   out may alias the first operand (in-place update, as _update_stats does).
+ * ------------------------------------------------------------------------- */
+int am_stats_merge_f64(int64_t n1, const double* mean1, const double* cov1,
+                       int64_t n2, const double* mean2, const double* cov2,
+                       int D, double* out_mean, double* out_cov, am_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * A5  Frechet distance                         reference: fad.py:16-31
+ *   fd = |mu_x-mu_y|^2 + tr(cov_x) + tr(cov_y) - 2 tr sqrt(cov_x cov_y)
+ *   tr sqrt by a coupled Newton-Schulz iteration in f64 on the f64 matrix
+ *   cores (the reference uses LAPACK eigvals); stops when |I - ZY|_F <
+ *   tol*sqrt(D), when the trace stops growing (rank-deficient inputs) or at
+ *   max_iter.  SYNCHRONISES `stream`.  out_host (HOST pointer, 4 doubles):
+ *   { fd, tr_sqrt, iterations, final residual }.
+ * ------------------------------------------------------------------------- */
+size_t am_frechet_workspace_bytes(int D);
+int am_frechet_f64(const double* mu_x, const double* cov_x,
+                   const double* mu_y, const double* cov_y, int D,
+                   int max_iter, double tol, double* out_host,
+                   void* ws, size_t ws_bytes, am_stream_t stream);
+
+/* A11 APA scalar combination (host arithmetic)  reference: apa.py:22-32 */
+double am_apa_f64(double d_y_x, double d_y_xp, double d_x_xp);
+
+/* ---------------------------------------------------------------------------
+ * A6-A8  kernel distance, polynomial kernel     reference: kd.py:38-83,112-124,178-187
+ *   For each subset s < S: rows idx1[s*m .. s*m+m) of X (features_1) and
+ *   idx2[...] of Y (features_2) -> K = (x.y * gamma + coef0)^degree on the three
+ *   m x m Gram blocks, unbiased MMD^2:
+ *   out_mmd[s] = (sum offdiag Kxx + sum offdiag Kyy)/(m(m-1)) - 2 sum Kxy / m^2.
+ *   Dot products in f32 on the matrix cores, kernel values and sums in f64.
+ *   The index table is drawn by the caller (numpy PCG64, kd.py:176,185-186).
+ * ------------------------------------------------------------------------- */
+size_t am_kd_workspace_bytes(int S, int m);
+int am_kd_poly_f32(const float* X, int64_t N1, int64_t ldx,
+                   const float* Y, int64_t N2, int64_t ldy, int D,
+                   const int64_t* idx1, const int64_t* idx2, int S, int m,
+                   double gamma, double coef0, int degree,
+                   double* out_mmd, void* ws, size_t ws_bytes, am_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * A9  k-NN radii                                reference: prdc.py:4-14, data.py:60-66
+ *   out_r[i] = (k+1)-th smallest Euclidean distance from row i of X to the M
+ *   rows of Y (Y == X for the reference's self-distance use; a multi-GPU
+ *   caller passes its row shard as X and the gathered set as Y).
+ *   Distances follow torch.cdist's matmul form  sqrt(max(|x|^2+|y|^2-2x.y, 0))
+ *   in f32; no N x M matrix is materialised.  1 <= k <= AM_MAX_K, k+1 <= M.
+ * ------------------------------------------------------------------------- */
+size_t am_knn_workspace_bytes(int64_t N, int64_t M, int k);
+int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx,
+                     const float* Y, int64_t M, int64_t ldy, int D, int k,
+                     float* out_r, void* ws, size_t ws_bytes, am_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * A10  hypersphere membership counts            reference: prdc.py:34-48
+ *   With d(i,j) the distance between reference row i and candidate row j:
+ *   out_col_count[j] = #{ i : d(i,j) < r_ref[i] }      (precision, density)
+ *   out_row_any[i]   = any_j d(i,j) < r_cand[j]        (recall)
+ *   out_row_min[i]   = min_j d(i,j)                    (coverage)
+ *   Outputs are OVERWRITTEN.  am_prdc_reduce turns them into the four integer
+ *   totals { #cols with count>0, #rows with any, sum of counts, #rows with
+ *   row_min < r_ref } (device int64[4]); the caller divides in f64.
+ * ------------------------------------------------------------------------- */
+size_t am_prdc_workspace_bytes(int64_t Nr, int64_t Nc);
+int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr,
+                       const float* C, int64_t Nc, int64_t ldc, int D,
+                       const float* r_ref, const float* r_cand,
+                       int32_t* out_col_count, uint8_t* out_row_any, float* out_row_min,
+                       void* ws, size_t ws_bytes, am_stream_t stream);
+int am_prdc_reduce(const int32_t* col_count, int64_t Nc,
+                   const uint8_t* row_any, const float* row_min, const float* r_ref, int64_t Nr,
+                   int64_t* out4, am_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIO_METRICS_HIP_H */
