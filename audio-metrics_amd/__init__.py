@@ -6,4 +6,8 @@ top-level ``audio_metrics_amd/`` shim points Python at it).
 from . import _lib, hip_ops                        # noqa: F401
 from ._build import build_library, LIB_PATH        # noqa: F401
 
+from .data import AudioMetricsData, ensure_tensor, ensure_ndarray            # noqa: F401
+from .metrics import (frechet_distance, kernel_distance, kid_features_to_metric,   # noqa: F401
+                      prdc, nearest_neighbour_distances, apa, apa_compute_d_x_xp)
+
 __version__ = "0.1.0"

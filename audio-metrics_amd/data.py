@@ -1,0 +1,167 @@
+"""Device-resident sufficient statistics container.
+
+Host-side mirror of the reference's ``AudioMetricsData``
+(src/audio_metrics/data.py:18-112): same attributes, same method names and
+argument meaning, same quirks - but every tensor lives in MI355X HBM and every
+computation is a call into the HIP library:
+
+  add / recompute_stats  -> am_stats_f32          (data.py:37-58)
+  _update_stats          -> am_stats_merge_f64    (data.py:77-94)
+  get_radii              -> am_knn_radii_f32      (data.py:60-66, prdc.py:4-14)
+  _update_embeddings     -> amortised-doubling HBM buffer instead of the
+                            reference's per-batch torch.cat (data.py:68-72)
+"""
+import numpy as np
+import torch
+
+from . import hip_ops as ops
+
+
+def default_device():
+    if not torch.cuda.is_available():
+        from ._lib import HipLibraryError
+        raise HipLibraryError("no MI355X visible (torch.cuda.is_available() is False); "
+                              "audio_metrics_amd has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def ensure_tensor(x, device=None):
+    """data.py:6-9."""
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(x)
+    return x.to(device, non_blocking=True) if device else x
+
+
+def ensure_ndarray(x):
+    """data.py:12-15."""
+    if isinstance(x, torch.Tensor):
+        x = x.cpu().numpy()
+    return x
+
+
+def _ld_for(d):
+    return (d + 3) // 4 * 4
+
+
+class AudioMetricsData:
+    def __init__(self, store_embeddings=True, device=None):
+        self.mean = None
+        self.n = None
+        self.cov = None
+        self.store_embeddings = store_embeddings
+        self.embeddings = None            # [n, D] f32 view of self._buf
+        self.radii = {}
+        self.dtype = torch.float64
+        self._device = torch.device(device) if device is not None else None
+        self._buf = None                  # [capacity, ld] f32, rows 16-B aligned
+
+    # ------------------------------------------------------------ plumbing
+    @property
+    def device(self):
+        if self._device is None:
+            self._device = default_device()
+        return self._device
+
+    def _to_device_matrix(self, embeddings):
+        e = ensure_tensor(embeddings)
+        if e.dim() != 2:
+            raise ValueError(f"embeddings must have shape [n, d], got {tuple(e.shape)}")
+        if not e.is_cuda:
+            e = e.to(self.device, non_blocking=True)
+        elif self._device is None:
+            self._device = e.device
+        return ops.as_matrix(e)           # f32 (f64 embedder outputs are narrowed to the path's f32)
+
+    # ------------------------------------------------------------ reference API
+    def serialize(self):
+        """Plain dict in the reference's layout (data.py:28-29) with HOST tensors,
+        so that ``torch.save`` / ``torch.load(weights_only=True)`` round-trip and
+        reference-written state files stay loadable."""
+        cpu = lambda t: t.detach().cpu() if isinstance(t, torch.Tensor) else t   # noqa: E731
+        return dict(
+            mean=cpu(self.mean), n=self.n, cov=cpu(self.cov), store_embeddings=self.store_embeddings,
+            embeddings=None if self.embeddings is None else self.embeddings.detach().cpu().contiguous(),
+            radii={k: cpu(v) for k, v in self.radii.items()}, dtype=self.dtype)
+
+    @classmethod
+    def deserialize(cls, state, device=None):
+        self = cls(store_embeddings=state.get("store_embeddings", True), device=device)
+        self.n = state.get("n")
+        dev = self.device
+        if state.get("mean") is not None:
+            self.mean = ensure_tensor(state["mean"]).to(dev, torch.float64)
+            self.cov = ensure_tensor(state["cov"]).to(dev, torch.float64)
+        if state.get("embeddings") is not None:
+            self._append(self._to_device_matrix(state["embeddings"]))
+        self.radii = {k: ensure_tensor(v).to(dev) for k, v in (state.get("radii") or {}).items()}
+        self.dtype = state.get("dtype", torch.float64)
+        return self
+
+    def add(self, embeddings):
+        e = self._to_device_matrix(embeddings)
+        n = e.shape[0]
+        if n == 0:
+            raise ValueError("cannot add an empty batch of embeddings")
+        mean, cov = ops.stats(e)          # n == 1 -> zero covariance (data.py:40-42)
+        self._update_stats(mean, cov, n)
+        if self.store_embeddings:
+            self._update_embeddings(e)
+
+    def recompute_stats(self):
+        if self.embeddings is not None:
+            self.n = len(self.embeddings)
+            self.mean, self.cov = ops.stats(self.embeddings)
+            if self.n == 1:
+                # reference quirk kept on purpose: a (1, 1) zero matrix, not (D, D) (data.py:56)
+                self.cov = torch.zeros((1, 1), dtype=self.dtype, device=self.device)
+
+    def get_radii(self, k_neighbor):
+        key = f"radii_{k_neighbor}"
+        radii = self.radii.get(key)
+        if radii is None and self.embeddings is not None:
+            radii = ops.knn_radii(self.embeddings, k_neighbor)
+            self.radii[key] = radii       # never invalidated on append - same as the reference
+        return radii
+
+    def _update_embeddings(self, embeddings):
+        self._append(self._to_device_matrix(embeddings))
+
+    def _append(self, e):
+        n_new, d = e.shape
+        n_old = 0 if self.embeddings is None else self.embeddings.shape[0]
+        if self._buf is None or self._buf.shape[0] < n_old + n_new:
+            cap = max(n_old + n_new, 2 * (0 if self._buf is None else self._buf.shape[0]), 1024)
+            buf = torch.empty((cap, _ld_for(d)), dtype=torch.float32, device=e.device)
+            if n_old:
+                buf[:n_old, :d] = self.embeddings
+            self._buf = buf
+        self._buf[n_old:n_old + n_new, :d] = e
+        self.embeddings = self._buf[:n_old + n_new, :d]
+
+    def __len__(self):
+        return self.n or 0
+
+    def _update_stats(self, mean, cov, n):
+        if self.n is None:
+            self.mean, self.cov, self.n = mean, cov, n
+            return
+        self.mean, self.cov = ops.stats_merge(self.n, self.mean, self.cov, n, mean, cov, inplace=True)
+        self.n = self.n + n
+
+    def __iadd__(self, other):
+        assert isinstance(other, AudioMetricsData)
+        if other.n is None:
+            return self
+        if self.n is None:
+            self.store_embeddings = other.store_embeddings
+        assert self.store_embeddings == other.store_embeddings
+        self._update_stats(other.mean.clone(), other.cov.clone(), other.n)
+        if self.store_embeddings:
+            self._update_embeddings(other.embeddings)
+        return self
+
+    def __add__(self, other):
+        new = AudioMetricsData(device=self._device)
+        new += self
+        new += other
+        return new

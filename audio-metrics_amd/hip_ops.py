@@ -23,6 +23,45 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+class KernelTimer:
+    """Optional per-entry-point timing with HIP events recorded on the stream the
+    kernels are launched on (torch's current stream).  Used by bench.py:
+        with KernelTimer() as t: ...;  t.summary() -> {name: (calls, total_ms)}"""
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.records:
+            c, t = out.get(name, (0, 0.0))
+            out[name] = (c + 1, t + a.elapsed_time(b))
+        return out
+
+
+def _call(lib, name, *args):
+    timer = KernelTimer.active
+    if timer is not None:
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        status = getattr(lib, name)(*args)
+        b.record()
+        timer.records.append((name, a, b))
+    else:
+        status = getattr(lib, name)(*args)
+    _lib.check(status, name)
+
+
 def _require_cuda(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.HipLibraryError(
@@ -72,7 +111,7 @@ def stats(e):
     cov = torch.empty((d, d), dtype=torch.float64, device=e.device)
     nb = lib.am_stats_workspace_bytes(n, d)
     ws = _workspace(nb, e.device)
-    _lib.check(lib.am_stats_f32(_ptr(e), n, d, _ld(e), _ptr(mean), _ptr(cov), _ptr(ws), nb, _stream()), "am_stats_f32")
+    _call(lib, "am_stats_f32", _ptr(e), n, d, _ld(e), _ptr(mean), _ptr(cov), _ptr(ws), nb, _stream())
     return mean, cov
 
 
@@ -83,7 +122,7 @@ def colsum(e):
     out = torch.empty(d, dtype=torch.float64, device=e.device)
     nb = lib.am_stats_workspace_bytes(n, d)
     ws = _workspace(nb, e.device)
-    _lib.check(lib.am_colsum_f32(_ptr(e), n, d, _ld(e), _ptr(out), _ptr(ws), nb, _stream()), "am_colsum_f32")
+    _call(lib, "am_colsum_f32", _ptr(e), n, d, _ld(e), _ptr(out), _ptr(ws), nb, _stream())
     return out
 
 
@@ -96,8 +135,7 @@ def scatter(e, mean):
     out = torch.empty((d, d), dtype=torch.float64, device=e.device)
     nb = lib.am_stats_workspace_bytes(n, d)
     ws = _workspace(nb, e.device)
-    _lib.check(lib.am_scatter_f32(_ptr(e), n, d, _ld(e), _ptr(mean), _ptr(out), _ptr(ws), nb, _stream()),
-               "am_scatter_f32")
+    _call(lib, "am_scatter_f32", _ptr(e), n, d, _ld(e), _ptr(mean), _ptr(out), _ptr(ws), nb, _stream())
     return out
 
 
@@ -108,8 +146,8 @@ def stats_merge(n1, mean1, cov1, n2, mean2, cov2, inplace=False):
     d = mean1.numel()
     om = mean1 if inplace else torch.empty_like(mean1)
     oc = cov1 if inplace else torch.empty_like(cov1)
-    _lib.check(lib.am_stats_merge_f64(int(n1), _ptr(mean1), _ptr(cov1), int(n2), _ptr(mean2), _ptr(cov2), d,
-                                      _ptr(om), _ptr(oc), _stream()), "am_stats_merge_f64")
+    _call(lib, "am_stats_merge_f64", int(n1), _ptr(mean1), _ptr(cov1), int(n2), _ptr(mean2), _ptr(cov2), d,
+                                      _ptr(om), _ptr(oc), _stream())
     return om, oc
 
 
@@ -124,8 +162,8 @@ def frechet(mu_x, cov_x, mu_y, cov_y, max_iter=64, tol=1e-13):
     out = (ctypes.c_double * 4)()
     nb = lib.am_frechet_workspace_bytes(d)
     ws = _workspace(nb, mu_x.device)
-    _lib.check(lib.am_frechet_f64(_ptr(mu_x), _ptr(cov_x), _ptr(mu_y), _ptr(cov_y), d, int(max_iter), float(tol),
-                                  ctypes.cast(out, ctypes.c_void_p), _ptr(ws), nb, _stream()), "am_frechet_f64")
+    _call(lib, "am_frechet_f64", _ptr(mu_x), _ptr(cov_x), _ptr(mu_y), _ptr(cov_y), d, int(max_iter), float(tol),
+                                  ctypes.cast(out, ctypes.c_void_p), _ptr(ws), nb, _stream())
     return dict(fd=out[0], tr_sqrt=out[1], iters=int(out[2]), resid=out[3])
 
 
@@ -146,9 +184,9 @@ def kd_poly(x, y, idx1, idx2, gamma, coef0, degree):
     out = torch.empty(s, dtype=torch.float64, device=x.device)
     nb = lib.am_kd_workspace_bytes(s, m)
     ws = _workspace(nb, x.device)
-    _lib.check(lib.am_kd_poly_f32(_ptr(x), x.shape[0], _ld(x), _ptr(y), y.shape[0], _ld(y), x.shape[1],
+    _call(lib, "am_kd_poly_f32", _ptr(x), x.shape[0], _ld(x), _ptr(y), y.shape[0], _ld(y), x.shape[1],
                                   _ptr(idx1), _ptr(idx2), s, m, float(gamma), float(coef0), int(degree),
-                                  _ptr(out), _ptr(ws), nb, _stream()), "am_kd_poly_f32")
+                                  _ptr(out), _ptr(ws), nb, _stream())
     return out
 
 
@@ -165,8 +203,8 @@ def knn_radii(x, k, columns=None):
     out = torch.empty(n, dtype=torch.float32, device=x.device)
     nb = lib.am_knn_workspace_bytes(n, y.shape[0], int(k))
     ws = _workspace(nb, x.device)
-    _lib.check(lib.am_knn_radii_f32(_ptr(x), n, _ld(x), _ptr(y), y.shape[0], _ld(y), d, int(k), _ptr(out),
-                                    _ptr(ws), nb, _stream()), "am_knn_radii_f32")
+    _call(lib, "am_knn_radii_f32", _ptr(x), n, _ld(x), _ptr(y), y.shape[0], _ld(y), d, int(k), _ptr(out),
+                                    _ptr(ws), nb, _stream())
     return out
 
 
@@ -187,9 +225,8 @@ def prdc_counts(ref, cand, r_ref, r_cand):
     rmin = torch.empty(nr, dtype=torch.float32, device=ref.device)
     nb = lib.am_prdc_workspace_bytes(nr, nc)
     ws = _workspace(nb, ref.device)
-    _lib.check(lib.am_prdc_counts_f32(_ptr(ref), nr, _ld(ref), _ptr(cand), nc, _ld(cand), d, _ptr(r_ref),
-                                      _ptr(r_cand), _ptr(col), _ptr(rany), _ptr(rmin), _ptr(ws), nb, _stream()),
-               "am_prdc_counts_f32")
+    _call(lib, "am_prdc_counts_f32", _ptr(ref), nr, _ld(ref), _ptr(cand), nc, _ld(cand), d, _ptr(r_ref),
+                                      _ptr(r_cand), _ptr(col), _ptr(rany), _ptr(rmin), _ptr(ws), nb, _stream())
     return col, rany, rmin
 
 
@@ -198,6 +235,6 @@ def prdc_reduce(col, rany, rmin, r_ref):
     (#cols with count>0, #rows with any, sum of counts, #rows with row_min < r_ref)."""
     lib = _lib.load()
     out = torch.empty(4, dtype=torch.int64, device=col.device)
-    _lib.check(lib.am_prdc_reduce(_ptr(col), col.numel(), _ptr(rany), _ptr(rmin), _ptr(r_ref), rany.numel(),
-                                  _ptr(out), _stream()), "am_prdc_reduce")
+    _call(lib, "am_prdc_reduce", _ptr(col), col.numel(), _ptr(rany), _ptr(rmin), _ptr(r_ref), rany.numel(),
+                                  _ptr(out), _stream())
     return out

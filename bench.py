@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: evaluate() embeddings/sec for FAD + KD + PRDC on two sets of
+100k CLAP-512 (f32) embeddings already resident in HBM (BASELINE.json metric,
+configs[2]), on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one COLD evaluation: both sets' statistics, the Frechet distance, the
+100 x 1000 kernel-distance subsets, both sets' k-NN radii and the membership
+counts are all recomputed (nothing is cached between steps).  With N > 1 the rows
+of both sets are sharded over the ranks (strong scaling: the problem is fixed) and
+the stats / gathered embeddings / radii / counts go through RCCL collectives.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "evaluate() embeddings/sec (FAD+KD+PRDC), 2×100k CLAP-512 sets, 1/2/4/8 GPUs"
+F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def cpu_baseline(ref, cand, k, sample_rows=10000):
+    """The CPU oracle (a port of the reference's torch/numpy calls, oracle/) timed on
+    this host.  stats + FAD + KD run at the full size; PRDC materialises N x N
+    matrices in the reference (164 GB at 100k), so it is timed on a row subsample
+    and scaled by (N / sample)^2."""
+    import oracle
+    torch.set_num_threads(os.cpu_count() or 1)
+    ref, cand = ref.cpu(), cand.cpu()
+    n = len(ref)
+    t0 = time.perf_counter()
+    a = oracle.OracleData(False).add(cand)
+    b = oracle.OracleData(False).add(ref)
+    t_stats = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.frechet_distance(a, b)
+    t_fad = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.kid_from_features(cand, ref)
+    t_kd = time.perf_counter() - t0
+    m = min(sample_rows, n)
+    t0 = time.perf_counter()
+    oracle.prdc_blocked(ref[:m], cand[:m], k, block=2048)
+    t_prdc_s = time.perf_counter() - t0
+    t_prdc = t_prdc_s * (n / m) ** 2
+    total = t_stats + t_fad + t_kd + t_prdc
+    return {
+        "value": 2 * n / total, "unit": "embeddings/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": (f"oracle/ (torch-CPU port of the reference): stats {t_stats:.2f}s + FAD {t_fad:.2f}s + KD {t_kd:.2f}s "
+                   f"at full 2x{n}x{ref.shape[1]}; PRDC(k={k}) timed on 2x{m} rows ({t_prdc_s:.2f}s) and scaled by "
+                   f"(N/{m})^2 to {t_prdc:.0f}s because the reference's N x N matrices do not fit host RAM at 100k"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=100000, help="rows per set (default: the BASELINE config)")
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--nearest-k", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import audio_metrics_amd as am
+    from audio_metrics_amd import hip_ops as ops
+    from audio_metrics_amd.distributed import evaluate_sharded, shard_bounds
+    am._lib.load()                                       # no HIP library -> fail here, loudly
+
+    n, d, k = args.rows, args.dim, args.nearest_k
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0)                                   # same seed on every rank: identical full sets
+    ref = torch.randn(n, d, generator=gen, device=dev)
+    cand = torch.randn(n, d, generator=gen, device=dev) * 1.05 + 0.05
+    lo, hi = shard_bounds(n, world, rank)
+    ref_l, cand_l = ref[lo:hi], cand[lo:hi]              # this rank's row shard (as its embedder would produce)
+
+    def step():
+        return evaluate_sharded(ref_l, cand_l, metrics=("fad", "kd", "prdc"), nearest_k=k)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        result = step()
+    fence()
+    with ops.KernelTimer() as timer:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            result = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    kern = timer.summary()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        calls, ms = kern["am_knn_radii_f32"]
+        knn_ms = ms / calls
+        ccalls, cms = kern["am_prdc_counts_f32"]
+        rows_local = hi - lo
+        flop_per_launch = 2.0 * rows_local * n * d            # algorithmic: one dot product per (row, column)
+        achieved = flop_per_launch / (knn_ms * 1e-3) / 1e12
+        out = {
+            "metric": METRIC,
+            "value": args.steps * 2 * n / elapsed,
+            "unit": "embeddings/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"FAD+KD+PRDC(k={k}) cold evaluate() of 2x{n} CLAP-{d} f32 embedding sets resident in HBM "
+                                   "(BASELINE.json configs[2])",
+                       "n_ref": n, "n_cand": n, "dim": d, "nearest_k": k, "kd_subsets": 100, "kd_subset_size": 1000,
+                       "sharding": f"rows/{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "knn_partial_kernel (am_knn_radii_f32)", "launch_ms": knn_ms,
+                         "flop_per_launch": flop_per_launch},
+            "kernels_ms_per_call": {name: tot / c for name, (c, tot) in sorted(kern.items())},
+            "kernels_calls_per_step": {name: c / args.steps for name, (c, tot) in sorted(kern.items())},
+            "cross_kernel_tflops": 2.0 * rows_local * n * d / (cms / ccalls * 1e-3) / 1e12,
+            "result": result,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ref, cand, k)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+"""world_size-2 gloo test of the row-sharded evaluate (sharding, all-gathers of
+unequal shards, all-reduces), with the oracle standing in for the HIP kernels."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import inputs as gi
+import oracle
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_ref, n_cand, d, k, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_ops
+    from audio_metrics_amd.distributed import evaluate_sharded, shard_bounds
+    ref, cand = gi.pair("shifted", 91, n_ref, n_cand, d)
+    rl, rh = shard_bounds(n_ref, world, rank)
+    cl, ch = shard_bounds(n_cand, world, rank)
+    res = evaluate_sharded(torch.as_tensor(ref[rl:rh]), torch.as_tensor(cand[cl:ch]), nearest_k=k, ops=cpu_ops,
+                           kid_subsets=6, kid_subset_size=200)
+    out_q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_ref,n_cand", [(700, 700), (701, 655)])
+def test_sharded_evaluate_matches_single_process(n_ref, n_cand):
+    d, k, world = 24, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_ref, n_cand, d, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, cand = gi.pair("shifted", 91, n_ref, n_cand, d)
+    a = oracle.OracleData(True).add(torch.as_tensor(cand))
+    b = oracle.OracleData(True).add(torch.as_tensor(ref))
+    want = {"fad": oracle.frechet_distance(a, b)}
+    want.update(oracle.kid_from_features(cand, ref, subsets=6, subset_size=200))
+    want.update(oracle.prdc(b, a, k))
+    assert results[0] == results[1]                     # every rank reports the same values
+    for key, w in want.items():
+        assert abs(results[0][key] - w) <= max(2e-5 * abs(w), 5e-7), (key, results[0][key], w)
+
+
+def test_shard_bounds_cover_rows():
+    from audio_metrics_amd.distributed import shard_bounds
+    for n in (1, 7, 100000, 1000003):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))

@@ -1,0 +1,247 @@
+"""Parity of the HIP path (through the Python mirror -> ctypes -> C ABI) against
+the oracle, the reference's golden vectors and the plain-C model of the device
+arithmetic.  Tolerances (BASELINE.json north_star): 1e-4 relative on f32 inputs
+for FAD / KD / PRDC / APA; PRDC radii, thresholds and membership counts are
+additionally BIT-EXACT against oracle/exact_c."""
+import numpy as np
+import pytest
+import torch
+
+import inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+KD_ABS_FLOOR = 5e-7        # f32 noise floor of the reference's own KD
+EPS32 = 2.0 ** -24
+
+
+@pytest.fixture(scope="module")
+def am():
+    import audio_metrics_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    audio_metrics_amd._lib.load()          # fail loudly if the HIP library is missing
+    return audio_metrics_amd
+
+
+def dev(x):
+    return torch.as_tensor(x).to("cuda:0")
+
+
+def amd_of(am, x, store=True, splits=None):
+    d = am.AudioMetricsData(store)
+    t = dev(x)
+    if splits is None:
+        d.add(t)
+    else:
+        s = 0
+        for b in splits:
+            d.add(t[s:s + b])
+            s += b
+    return d
+
+
+# ----------------------------------------------------------------- PRDC
+@pytest.mark.parametrize("name", list(gi.PRDC_CASES))
+def test_prdc_bit_exact_and_golden(am, golden, name):
+    from oracle import exact
+    g = golden("prdc")
+    kind, seed, nr, nc, d, k = gi.PRDC_CASES[name]
+    ref, cand = gi.pair(kind, seed, nr, nc, d)
+    a, b = amd_of(am, ref), amd_of(am, cand)
+    res = am.prdc(a, b, k)
+    _, aux = exact.prdc(ref, cand, k)
+    ops = am.hip_ops
+    col, rany, rmin = ops.prdc_counts(a.embeddings, b.embeddings, a.get_radii(k), b.get_radii(k))
+    # bit-exact against the C model of the device arithmetic
+    assert np.array_equal(a.get_radii(k).cpu().numpy().view(np.uint32), aux["r_ref"].view(np.uint32))
+    assert np.array_equal(b.get_radii(k).cpu().numpy().view(np.uint32), aux["r_cand"].view(np.uint32))
+    assert np.array_equal(col.cpu().numpy(), aux["col_count"])
+    assert np.array_equal(rany.cpu().numpy(), aux["row_any"])
+    assert np.array_equal(rmin.cpu().numpy().view(np.uint32), aux["row_min"].view(np.uint32))
+    # against the reference's own outputs
+    np.testing.assert_allclose(a.get_radii(k).cpu().numpy(), g[f"{name}/r_ref"], rtol=3e-5, atol=1e-6)
+    flips = int(np.abs(col.cpu().numpy().astype(np.int64) - g[f"{name}/col_count"]).sum())
+    assert flips <= max(1, 1e-4 * int(g[f"{name}/col_count"].sum()))
+    for key in ("precision", "recall", "density", "coverage"):
+        want = float(g[f"{name}/{key}"])
+        assert abs(res[key] - want) <= max(REL * abs(want), 1.0 / min(nr, nc)), (key, res[key], want)
+    assert list(res) == ["precision", "recall", "density", "coverage"]
+
+
+@pytest.mark.parametrize("k", [1, 7, 16, 31])
+def test_knn_other_k_bit_exact(am, k):
+    from oracle import exact
+    x = gi.randn(61, 700, 40)
+    r = am.nearest_neighbour_distances(dev(x), k).cpu().numpy()
+    assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, k).view(np.uint32))
+
+
+def test_knn_rows_vs_other_columns(am):
+    """row shard against a larger column set (the multi-GPU calling pattern)."""
+    from oracle import exact
+    x, y = gi.randn(62, 333, 72), gi.randn(63, 901, 72)
+    r = am.hip_ops.knn_radii(dev(x), 4, columns=dev(y)).cpu().numpy()
+    assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, 4, columns=y).view(np.uint32))
+
+
+def test_knn_k_out_of_range(am):
+    x = dev(gi.randn(1, 5, 8))
+    with pytest.raises(am._lib.HipLibraryError):
+        am.nearest_neighbour_distances(x, 5)          # k + 1 > N: torch.kthvalue raises in the reference
+    with pytest.raises(am._lib.HipLibraryError):
+        am.nearest_neighbour_distances(dev(gi.randn(1, 64, 8)), 32)   # > AM_MAX_K
+    with pytest.raises(am._lib.HipLibraryError):
+        am.hip_ops.stats(torch.zeros(4, 4))            # host tensor: no CPU fallback
+
+
+def test_prdc_self_consistency_full_size(am):
+    """2 x 100k x 512 (BASELINE config 3 shape), size-independent property: for
+    identical sets every row has exactly k columns strictly inside its radius
+    (itself + k-1 neighbours), so precision = recall = coverage = density = 1."""
+    torch.manual_seed(0)
+    x = torch.randn(100000, 512, device="cuda:0")
+    a = am.AudioMetricsData(True)
+    a.add(x)
+    res = am.prdc(a, a, 5)
+    assert res == dict(precision=1.0, recall=1.0, density=1.0, coverage=1.0)
+
+
+# ----------------------------------------------------------------- stats
+@pytest.mark.parametrize("name", list(gi.STATS_CASES))
+def test_stats_vs_golden(am, golden, name):
+    g = golden("stats")
+    seed, d, splits = gi.STATS_CASES[name]
+    x = gi.randn(seed, sum(splits), d, 1.3, 0.2)
+    a = amd_of(am, x, True, splits)
+    assert a.n == int(g[f"{name}/n"]) and len(a) == a.n
+    np.testing.assert_allclose(a.mean.cpu().numpy(), g[f"{name}/mean"], rtol=1e-6, atol=1e-6)
+    c = a.cov.cpu().numpy()
+    if d <= 128:
+        np.testing.assert_allclose(c, g[f"{name}/cov"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(np.trace(c), float(g[f"{name}/cov_trace"]), rtol=1e-6)
+    np.testing.assert_allclose(c[::37, ::41], g[f"{name}/cov_sample"], rtol=1e-5, atol=2e-6)
+    assert np.array_equal(c, c.T)
+    a.recompute_stats()
+    np.testing.assert_allclose(a.mean.cpu().numpy(), g[f"{name}/re_mean"], rtol=1e-6, atol=1e-6)
+    assert tuple(a.cov.shape) == tuple(g[f"{name}/re_cov_shape"])       # incl. the (1, 1) quirk for n == 1
+    assert a.embeddings.shape == (sum(splits), d)
+    np.testing.assert_array_equal(a.embeddings.cpu().numpy(), x)
+
+
+def test_incremental_equals_oneshot(am):
+    """Device analogue of the reference's tests/test_data.py:6-31 (1e-6)."""
+    x = gi.randn(7, 1101, 8)
+    a = amd_of(am, x, True, [1, 100, 1000])
+    b = amd_of(am, x, True, [1101])
+    np.testing.assert_allclose(a.mean.cpu().numpy(), b.mean.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(a.cov.cpu().numpy(), b.cov.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    c = amd_of(am, x[:500], True) + amd_of(am, x[500:], True)
+    np.testing.assert_allclose(c.cov.cpu().numpy(), b.cov.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    assert c.embeddings.shape == (1101, 8)
+
+
+def test_stats_full_size_vs_f64(am):
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((100000, 512)) * 1.05 + 0.05).astype(np.float32)
+    mean, cov = am.hip_ops.stats(dev(x))
+    x64 = x.astype(np.float64)
+    np.testing.assert_allclose(mean.cpu().numpy(), x64.mean(0), rtol=0, atol=1e-12)
+    xc = x64 - x64.mean(0)
+    want = xc.T @ xc / (len(x) - 1)
+    got = cov.cpu().numpy()
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-7
+    assert abs(np.trace(got) - np.trace(want)) / np.trace(want) < 1e-7
+
+
+def test_strided_and_odd_width_inputs(am):
+    x = gi.randn(8, 300, 21)                                        # D % 4 != 0
+    big = dev(np.concatenate([x, x], axis=1))[:, :21]               # non-contiguous view, odd row stride
+    m1, c1 = am.hip_ops.stats(big)
+    x64 = x.astype(np.float64)
+    np.testing.assert_allclose(m1.cpu().numpy(), x64.mean(0), atol=1e-12)
+    np.testing.assert_allclose(c1.cpu().numpy(), np.cov(x64.T), rtol=1e-5, atol=1e-6)
+
+
+# ----------------------------------------------------------------- FAD / APA
+def fad_tolerance(fad, cov_x, cov_y, n_min):
+    """1e-4 relative, plus - for rank-deficient covariances only - the reference's own
+    noise floor: its f32 torch.cov leaves spurious eigenvalues of either sign up to
+    ~eps32*lambda_max in each null direction and fad.py:30 adds sqrt of the positive ones."""
+    d = cov_x.shape[0]
+    nullity = max(0, d - (n_min - 1))
+    lam = float(np.linalg.norm(cov_x @ cov_y, 2))
+    return REL * abs(fad) + 2.0 * nullity * np.sqrt(EPS32 * lam)
+
+
+@pytest.mark.parametrize("name", list(gi.FAD_CASES))
+def test_fad_vs_golden(am, golden, name):
+    g = golden("fad")
+    kind, seed, nr, nc, d = gi.FAD_CASES[name]
+    ref, cand = gi.pair(kind, seed, nr, nc, d)
+    a, b = amd_of(am, cand, False), amd_of(am, ref, False)
+    fad = am.frechet_distance(a, b)
+    want = float(g[f"{name}/fad"])
+    tol = fad_tolerance(want, a.cov.cpu().numpy(), b.cov.cpu().numpy(), min(nr, nc))
+    assert abs(fad - want) <= tol, (fad, want, tol)
+    assert abs(am.frechet_distance(b, a) - float(g[f"{name}/fad_swapped"])) <= tol
+    assert isinstance(fad, float)
+
+
+def test_fad_properties(am):
+    x, y = gi.pair("randn", 71, 5000, 5000, 128)
+    a, b = amd_of(am, x, False), amd_of(am, y, False)
+    scale = float(a.cov.trace() + b.cov.trace())
+    assert abs(am.frechet_distance(a, a)) <= 1e-10 * scale           # identical Gaussians
+    f1 = am.frechet_distance(a, b)
+    a3, b3 = amd_of(am, 3 * x, False), amd_of(am, 3 * y, False)
+    assert abs(am.frechet_distance(a3, b3) - 9 * f1) <= 1e-5 * 9 * f1    # FD(sX, sY) = s^2 FD(X, Y)
+    assert am.metrics.fad.last_info["iters"] <= 20
+
+
+def test_apa_vs_golden(am, golden):
+    g = golden("apa")
+    for t, want in zip(g["table_in"], g["table_out"]):
+        assert am.metrics.apa._apa(*t) == want
+    d = 64
+    ref, anti = gi.randn(51, 1500, d), gi.randn(52, 1500, d, 1.2, 0.3)
+    b, c = amd_of(am, ref, False), amd_of(am, anti, False)
+    for i in range(4):
+        sc, sh = g[f"three_set_{i}/params"]
+        a = amd_of(am, gi.randn(53 + i, 1200, d, sc, sh), False)
+        want = float(g[f"three_set_{i}/apa"])
+        assert abs(am.apa(a, b, c) - want) <= REL * max(abs(want), 1e-3)
+        assert abs(am.apa(a, b, c, am.apa_compute_d_x_xp(b, c)) - want) <= REL * max(abs(want), 1e-3)
+
+
+# ----------------------------------------------------------------- KD
+@pytest.mark.parametrize("name", list(gi.KD_CASES))
+def test_kd_vs_golden(am, golden, name):
+    g = golden("kd")
+    kind, seed, n1, n2, d = gi.KD_CASES[name]
+    f2, f1 = gi.pair(kind, seed, n2, n1, d)
+    a, b = amd_of(am, f1), amd_of(am, f2)
+    res = am.kernel_distance(a, b)
+    for key, gk in (("kernel_distance_mean", "mean"), ("kernel_distance_std", "std")):
+        want = float(g[f"{name}/{gk}"])
+        assert abs(res[key] - want) <= max(REL * abs(want), KD_ABS_FLOOR), (key, res[key], want)
+    # per-subset values against the reference's own mmds[100]
+    import oracle
+    i1, i2 = oracle.draw_subsets(n1, n2)
+    mm = am.hip_ops.kd_poly(a.embeddings, b.embeddings, dev(i1), dev(i2), 1.0 / d, 1.0, 3).cpu().numpy()
+    assert np.all(np.abs(mm - g[f"{name}/mmds"]) <= np.maximum(REL * np.abs(g[f"{name}/mmds"]), KD_ABS_FLOOR))
+
+
+def test_kd_argument_order_and_kwargs(am):
+    f2, f1 = gi.pair("randn", 32, 3000, 3000, 64)
+    import oracle
+    ab = am.kid_features_to_metric(dev(f1), dev(f2))
+    ba = am.kid_features_to_metric(dev(f2), dev(f1))
+    assert ab != ba                                                  # the two rng draws swap
+    o = oracle.kid_from_features(f1, f2, subsets=7, subset_size=500, degree=2, gamma=0.01, coef0=0.5, seed=99)
+    r = am.kid_features_to_metric(dev(f1), dev(f2), kid_subsets=7, kid_subset_size=500, kid_degree=2,
+                                  kid_gamma=0.01, kid_coef0=0.5, rng_seed=99)
+    for key in o:
+        assert abs(o[key] - r[key]) <= max(REL * abs(o[key]), KD_ABS_FLOOR)
+    with pytest.raises(NotImplementedError):
+        am.kid_features_to_metric(dev(f1), dev(f2), kernel_type="laplace")
