@@ -9,6 +9,7 @@
 //     sqrt_rn(d2) < R   <=>   d2 < T(R),  T(R) = min { t : sqrt_rn(t) >= R }.
 #include "am_common.h"
 #include "tile_engine.h"
+#include <stdlib.h>
 
 namespace am {
 
@@ -113,18 +114,19 @@ struct KnnEpilogue {
             for (int g4 = 0; g4 < 4; ++g4) yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                float d2[16];
+                // max(.,0) commutes with min, so the tile minimum is clamped once
                 float tmin = INFINITY;
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    d2[reg] = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
-                    tmin = fminf(tmin, d2[reg]);
-                }
+                for (int reg = 0; reg < 16; ++reg)
+                    tmin = fminf(tmin, fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]));
+                tmin = fmaxf(tmin, 0.f);
                 // common case after warm-up: no lane of the wave improves its list with this 32x32 tile
                 if (__any(tmin < best[nt][KCAP - 1])) {
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg)
-                        if (__any(d2[reg] < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], d2[reg]);
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float d2 = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
+                        if (__any(d2 < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], d2);
+                    }
                 }
             }
         }
@@ -132,7 +134,7 @@ struct KnnEpilogue {
 };
 
 // partial[(chunk * n_rows + row) * KCAP + s] = s-th smallest d2 of `row` inside column chunk `chunk`
-template <int KCAP>
+template <int KCAP, int V, bool KTAIL>
 __global__ void __launch_bounds__(ENGINE_THREADS, 2)
 knn_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ldx, const float* __restrict__ xnorm,
                    const float* __restrict__ Y, int64_t M, int64_t ldy, const float* __restrict__ ynorm,
@@ -154,10 +156,16 @@ knn_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ldx, const fl
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = INFINITY;
     }
-    const DenseRows qsrc{Y, ldy, M, w.qtile0};
-    const DenseRows psrc_base{X, ldx, N, w.prow0 / TB};
-    auto psrc = [&](int, int row) { return psrc_base(0, row); };
-    tile_pipeline(qsrc, psrc, w.ntiles, D, lds, L, epi);
+    if constexpr (V & EV_EARLY) {
+        dense_pipeline_early<V, KTAIL>(Y, M, ldy, w.qtile0, X, N, ldx, w.prow0, w.ntiles, D, lds, L, epi);
+    } else if constexpr (V & EV_RSRC) {
+        dense_pipeline<V>(Y, M, ldy, w.qtile0, X, N, ldx, w.prow0, w.ntiles, D, lds, L, epi);
+    } else {
+        const DenseRows qsrc{Y, ldy, M, w.qtile0};
+        const DenseRows psrc_base{X, ldx, N, w.prow0 / TB};
+        auto psrc = [&](int, int row) { return psrc_base(0, row); };
+        tile_pipeline(qsrc, psrc, w.ntiles, D, lds, L, epi);
+    }
 
     // merge the 4 lists that cover each P row (2 half-waves x 2 Q-half waves) through LDS
     float* mg = lds;                                   // [128][4][KCAP], staging slabs are free now
@@ -271,6 +279,7 @@ struct CrossEpilogue {
     }
 };
 
+template <int V, bool KTAIL>
 __global__ void __launch_bounds__(ENGINE_THREADS, 2)
 prdc_cross_kernel(const float* __restrict__ R, int64_t Nr, int64_t ldr, const float* __restrict__ rnorm,
                   const float* __restrict__ rthr,
@@ -298,10 +307,16 @@ prdc_cross_kernel(const float* __restrict__ R, int64_t Nr, int64_t ldr, const fl
         epi.rmin[nt] = INFINITY;
         epi.margin[nt] = INFINITY;
     }
-    const DenseRows qsrc{C, ldc, Nc, w.qtile0};
-    const DenseRows psrc_base{R, ldr, Nr, w.prow0 / TB};
-    auto psrc = [&](int, int row) { return psrc_base(0, row); };
-    tile_pipeline(qsrc, psrc, w.ntiles, D, lds, L, epi);
+    if constexpr (V & EV_EARLY) {
+        dense_pipeline_early<V, KTAIL>(C, Nc, ldc, w.qtile0, R, Nr, ldr, w.prow0, w.ntiles, D, lds, L, epi);
+    } else if constexpr (V & EV_RSRC) {
+        dense_pipeline<V>(C, Nc, ldc, w.qtile0, R, Nr, ldr, w.prow0, w.ntiles, D, lds, L, epi);
+    } else {
+        const DenseRows qsrc{C, ldc, Nc, w.qtile0};
+        const DenseRows psrc_base{R, ldr, Nr, w.prow0 / TB};
+        auto psrc = [&](int, int row) { return psrc_base(0, row); };
+        tile_pipeline(qsrc, psrc, w.ntiles, D, lds, L, epi);
+    }
 
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -361,10 +376,22 @@ __global__ void __launch_bounds__(256) prdc_reduce_kernel(const int32_t* __restr
 }
 
 // ------------------------------------------------------------------ host side
+// Development knobs (A/B experiments on the GPU box); unset in production use.
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+constexpr int EV_DEFAULT = EV_RSRC | EV_FRAGDB | EV_EARLY;
+static int engine_variant() {
+    static const int v = env_int("AM_ENGINE_VARIANT", EV_DEFAULT);
+    return v;
+}
+
 static int choose_chunks(int64_t p_rows, int64_t q_rows) {
     const int64_t row_blocks = ceil_div(p_rows, TB);
     const int64_t q_tiles = ceil_div(q_rows, TB);
-    int64_t want = ceil_div(2048, row_blocks);           // aim for >= 2048 workgroups (256 CUs x 2 x 4 rounds)
+    static const int target = env_int("AM_WG_TARGET", 8192);
+    int64_t want = ceil_div(target, row_blocks);         // aim for >= 8192 workgroups: 16 rounds of 256 CUs x 2 keeps the tail ~2%
     if (want < 8) want = 8;                              // one chunk per XCD at least
     want = ceil_div(want, 8) * 8;
     if (want > q_tiles) want = q_tiles;
@@ -390,19 +417,46 @@ static int launch_norms(const float* X, int64_t N, int64_t ld, int D, float* out
     return AM_OK;
 }
 
-template <int KCAP>
-static int launch_knn(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
-                      const float* yn, int D, int k1, int nchunks, float* partial, float* out_r, hipStream_t st) {
+template <int KCAP, int V, bool KTAIL>
+static int launch_knn_vt(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
+                         const float* yn, int D, int nchunks, float* partial, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_partial_kernel<KCAP>),
+        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_partial_kernel<KCAP, V, KTAIL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIRWISE_LDS_BYTES));
         attr_done = true;
     }
     const int64_t blocks = ceil_div(N, TB) * nchunks;
-    hipLaunchKernelGGL(knn_partial_kernel<KCAP>, dim3((unsigned)blocks), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES, st,
-                       X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial);
+    hipLaunchKernelGGL((knn_partial_kernel<KCAP, V, KTAIL>), dim3((unsigned)blocks), dim3(ENGINE_THREADS),
+                       PAIRWISE_LDS_BYTES, st, X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial);
     AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+template <int KCAP, int V>
+static int launch_knn_v(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
+                        const float* yn, int D, int nchunks, float* partial, hipStream_t st) {
+    // the inner-dimension tail (D % 32 != 0) is a separate instantiation so the common kernel carries no tail code
+    if constexpr ((V & EV_EARLY) != 0) {
+        if ((D % BK) != 0) return launch_knn_vt<KCAP, V, true>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial, st);
+    }
+    return launch_knn_vt<KCAP, V, false>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial, st);
+}
+
+template <int KCAP>
+static int launch_knn(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
+                      const float* yn, int D, int k1, int nchunks, float* partial, float* out_r, hipStream_t st) {
+    int rc;
+    if constexpr (KCAP == 6) {                       // older schedules stay selectable for A/B runs (k <= 5 kernel only)
+        switch (engine_variant()) {
+            case 0: rc = launch_knn_v<KCAP, 0>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial, st); break;
+            case 3: rc = launch_knn_v<KCAP, 3>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial, st); break;
+            default: rc = launch_knn_v<KCAP, EV_DEFAULT>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial, st); break;
+        }
+    } else {
+        rc = launch_knn_v<KCAP, EV_DEFAULT>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial, st);
+    }
+    if (rc != AM_OK) return rc;
     hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st,
                        partial, N, nchunks, k1, out_r);
     AM_LAUNCH_CHECK();
@@ -487,17 +541,20 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
     AM_LAUNCH_CHECK();
     AM_HIP_TRY(hipMemsetAsync(rany, 0, (size_t)Nr * sizeof(unsigned), st));
     AM_HIP_TRY(hipMemsetAsync(out_col_count, 0, (size_t)Nc * sizeof(int32_t), st));
-    static bool attr_done = false;
-    if (!attr_done) {
-        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&prdc_cross_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIRWISE_LDS_BYTES));
-        attr_done = true;
-    }
     const int nchunks = choose_chunks(Nr, Nc);
     const int64_t blocks = ceil_div(Nr, TB) * nchunks;
-    hipLaunchKernelGGL(prdc_cross_kernel, dim3((unsigned)blocks), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES, st,
-                       R, Nr, ldr, rn, rt, C, Nc, ldc, cn, ct, D, nchunks, out_col_count, rmin, rany);
-    AM_LAUNCH_CHECK();
+    auto launch = [&](auto kernel) -> int {
+        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)PAIRWISE_LDS_BYTES));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES, st, R, Nr, ldr, rn, rt,
+                           C, Nc, ldc, cn, ct, D, nchunks, out_col_count, rmin, rany);
+        AM_LAUNCH_CHECK();
+        return AM_OK;
+    };
+    if (engine_variant() == 0) rc = launch(&prdc_cross_kernel<0, false>);
+    else if ((D % BK) != 0) rc = launch(&prdc_cross_kernel<EV_DEFAULT, true>);
+    else rc = launch(&prdc_cross_kernel<EV_DEFAULT, false>);
+    if (rc != AM_OK) return rc;
     hipLaunchKernelGGL(prdc_finish_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, rmin, rany, Nr,
                        out_row_min, out_row_any);
     AM_LAUNCH_CHECK();

@@ -31,6 +31,7 @@
 // drains inside a workgroup.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace am {
 
@@ -101,6 +102,316 @@ __device__ __forceinline__ void compute_stage(const float* __restrict__ sQ, cons
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qb[s], pb[s], acc[1][1], 0, 0, 0);
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Buffer-resource staging (engine variant bit 0).  A dense 128-row operand tile
+// is addressed through a raw buffer descriptor whose base is the tile's first
+// row and whose num_records is the byte extent of its VALID rows: rows past the
+// end of the matrix read as zero in hardware, so the staging loads need neither
+// branches nor 64-bit per-lane address arithmetic - each thread keeps four
+// constant 32-bit offsets (its rows inside the tile) and the stage advances a
+// scalar offset.
+struct TileRsrc {
+    __amdgpu_buffer_rsrc_t rsrc;
+};
+
+__device__ __forceinline__ TileRsrc make_tile_rsrc(const float* base, int64_t ld, int64_t n_rows, int64_t row0) {
+    int64_t valid = n_rows - row0;
+    valid = valid < 0 ? 0 : (valid > TB ? TB : valid);
+    const float* p = base + (valid > 0 ? row0 : 0) * ld;
+    // wave-uniform by construction (kernel arguments and blockIdx only); readfirstlane makes that provable
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(p) & 0xffffffffu));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(p) >> 32));
+    const unsigned bytes = __builtin_amdgcn_readfirstlane((unsigned)(valid * ld * 4));
+    void* q = reinterpret_cast<void*>((static_cast<uintptr_t>(hi) << 32) | lo);
+    TileRsrc r;
+    r.rsrc = __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)bytes, 0x00020000);
+    return r;
+}
+
+__device__ __forceinline__ f32x4 rsrc_load(const TileRsrc& r, unsigned voff, unsigned soff) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, (int)voff, (int)soff, 0);
+    f32x4 f;
+    f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
+    return f;
+}
+
+// engine variant bits
+constexpr int EV_RSRC = 1;       // buffer-resource staging loads (dense operands only)
+constexpr int EV_FRAGDB = 2;     // double-buffered LDS fragments across the 8-wide k chunks
+constexpr int EV_PRIO = 4;       // s_setprio rising through the stage: the wave further along wins the MFMA pipe
+constexpr int EV_ABL_NOEPI = 8;  // ablation only (wrong results): skip the tile epilogue
+constexpr int EV_ABL_NOLOAD = 16; // ablation only (wrong results): stage the first slab only
+
+__device__ __forceinline__ void set_prio_level(int c) {   // s_setprio takes an immediate
+    switch (c) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
+// 64 MFMAs of one BK=32 slab with the fragments of chunk c+1 read while chunk c multiplies.
+template <int V>
+__device__ __forceinline__ void compute_stage_v(const float* __restrict__ sQ, const float* __restrict__ sP,
+                                                const LaneInfo& L, f32x16 (&acc)[2][2]) {
+    if constexpr ((V & EV_FRAGDB) == 0) {
+        if constexpr (V & EV_PRIO) __builtin_amdgcn_s_setprio(1);
+        compute_stage(sQ, sP, L, acc);
+        if constexpr (V & EV_PRIO) __builtin_amdgcn_s_setprio(0);
+    } else {
+        const float* q = sQ + (L.wm * 64 + L.r) * LDK + L.h * 4;
+        const float* p = sP + (L.wn * 64 + L.r) * LDK + L.h * 4;
+        f32x4 qa[2], qb[2], pa[2], pb[2];
+        qa[0] = *reinterpret_cast<const f32x4*>(q);
+        qb[0] = *reinterpret_cast<const f32x4*>(q + 32 * LDK);
+        pa[0] = *reinterpret_cast<const f32x4*>(p);
+        pb[0] = *reinterpret_cast<const f32x4*>(p + 32 * LDK);
+#pragma unroll
+        for (int c = 0; c < BK / 8; ++c) {
+            const int cur = c & 1, nxt = cur ^ 1;
+            if (c + 1 < BK / 8) {
+                qa[nxt] = *reinterpret_cast<const f32x4*>(q + (c + 1) * 8);
+                qb[nxt] = *reinterpret_cast<const f32x4*>(q + 32 * LDK + (c + 1) * 8);
+                pa[nxt] = *reinterpret_cast<const f32x4*>(p + (c + 1) * 8);
+                pb[nxt] = *reinterpret_cast<const f32x4*>(p + 32 * LDK + (c + 1) * 8);
+            }
+            if constexpr (V & EV_PRIO) set_prio_level(c);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[cur][s], pa[cur][s], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[cur][s], pb[cur][s], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qb[cur][s], pa[cur][s], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qb[cur][s], pb[cur][s], acc[1][1], 0, 0, 0);
+            }
+        }
+        if constexpr (V & EV_PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// Dense-operand pipeline: Q tiles qtile0 .. qtile0+ntiles-1 of the row-major matrix (Q, nq, ldq) against the
+// fixed 128-row P block starting at prow0 of (P, np, ldp).  Same stage order, LDS image and arithmetic as
+// tile_pipeline; only the way the slabs are fetched differs.
+template <int V, class Epi>
+__device__ __forceinline__ void dense_pipeline(const float* __restrict__ Q, int64_t nq, int64_t ldq, int64_t qtile0,
+                                               const float* __restrict__ P, int64_t np, int64_t ldp, int64_t prow0,
+                                               int ntiles, int D, float* __restrict__ lds, const LaneInfo& L, Epi& epi) {
+    const int nk = (D + BK - 1) / BK;
+    const int G = ntiles * nk;
+    const int srow = L.tid >> 3;
+    const int scol = (L.tid & 7) * 4;
+    const bool ktail = (D % BK) != 0;
+    f32x4 rq[4], rp[4];
+    f32x16 acc[2][2];
+    zero_acc(acc);
+
+    const TileRsrc prs = make_tile_rsrc(P, ldp, np, prow0);
+    unsigned voq[4], vop[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        voq[q] = (unsigned)(((int64_t)(q * 32 + srow) * ldq + scol) * 4);
+        vop[q] = (unsigned)(((int64_t)(q * 32 + srow) * ldp + scol) * 4);
+    }
+    TileRsrc qrs = make_tile_rsrc(Q, ldq, nq, qtile0 * TB);
+
+    auto issue = [&](int kt) {
+        const unsigned so = (unsigned)(kt * BK * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rq[q] = rsrc_load(qrs, voq[q], so);
+            rp[q] = rsrc_load(prs, vop[q], so);
+        }
+    };
+    auto commit = [&](int g, int kt) {
+        if (ktail && kt == nk - 1) {               // wave-uniform: zero the inner-dimension tail of the last slab
+            const int k = kt * BK + scol;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (k + e >= D) { rq[q][e] = 0.f; rp[q][e] = 0.f; }
+                }
+        }
+        float* s = lds + (g & 1) * STAGE_FLOATS + srow * LDK + scol;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<f32x4*>(s + q * 32 * LDK) = rq[q];
+            *reinterpret_cast<f32x4*>(s + TILE_FLOATS + q * 32 * LDK) = rp[q];
+        }
+    };
+
+    issue(0);
+    epi.aux_issue(0);
+    commit(0, 0);
+    epi.aux_commit(0);
+    __syncthreads();
+
+    int t = 0, kt = 0;
+    for (int g = 0; g < G; ++g) {
+        const bool more = (g + 1 < G);
+        const bool last_k = (kt == nk - 1);
+        const int nt_ = last_k ? t + 1 : t;
+        const int nkt = last_k ? 0 : kt + 1;
+        if (more) {
+            if (last_k) qrs = make_tile_rsrc(Q, ldq, nq, (qtile0 + nt_) * TB);
+            if constexpr ((V & EV_ABL_NOLOAD) == 0) issue(nkt);
+            if (last_k) epi.aux_issue(nt_);
+        }
+        const float* s = lds + (g & 1) * STAGE_FLOATS;
+        compute_stage_v<V>(s, s + TILE_FLOATS, L, acc);
+        if (last_k) {
+            if constexpr ((V & EV_ABL_NOEPI) == 0) {
+                epi.finish(t, acc);
+            } else {
+                if (acc[0][0][0] == 123.456f && acc[1][1][7] == 3.f) epi.finish(t, acc);   // keep the MFMAs live
+            }
+            zero_acc(acc);
+        }
+        if (more) {
+            if constexpr ((V & EV_ABL_NOLOAD) == 0) commit(g + 1, nkt);
+            if (last_k) epi.aux_commit(nt_);
+        }
+        __syncthreads();
+        t = nt_;
+        kt = nkt;
+    }
+}
+
+constexpr int EV_EARLY = 32;     // loads issued two stages ahead, LDS writes placed inside the MFMA stream
+
+struct FragSet {
+    f32x4 qa, qb, pa, pb;
+};
+
+__device__ __forceinline__ FragSet read_frags(const float* __restrict__ q, const float* __restrict__ p, int c) {
+    FragSet f;
+    f.qa = *reinterpret_cast<const f32x4*>(q + c * 8);
+    f.qb = *reinterpret_cast<const f32x4*>(q + 32 * LDK + c * 8);
+    f.pa = *reinterpret_cast<const f32x4*>(p + c * 8);
+    f.pb = *reinterpret_cast<const f32x4*>(p + 32 * LDK + c * 8);
+    return f;
+}
+
+__device__ __forceinline__ void mfma_chunk(const FragSet& f, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.qa[s], f.pa[s], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.qa[s], f.pb[s], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.qb[s], f.pa[s], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.qb[s], f.pb[s], acc[1][1], 0, 0, 0);
+    }
+}
+
+// Dense-operand pipeline, "early commit" schedule.  Stage g multiplies LDS buffer g&1 while
+//   - the slab of stage g+2 is fetched into one of two register sets (issued at the top of stage g), and
+//   - the slab of stage g+1 (fetched during stage g-1, long since landed) is written to buffer (g+1)&1
+//     between the second and third 8-wide k chunk, i.e. in the shadow of the MFMA pipe,
+// so that only the barrier itself separates two stages.  Same LDS image, stage order and arithmetic as
+// dense_pipeline / tile_pipeline (bit-identical results).
+template <int V, bool KTAIL, class Epi>
+__device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q, int64_t nq, int64_t ldq, int64_t qtile0,
+                                                     const float* __restrict__ P, int64_t np, int64_t ldp, int64_t prow0,
+                                                     int ntiles, int D, float* __restrict__ lds, const LaneInfo& L,
+                                                     Epi& epi) {
+    const int nk = (D + BK - 1) / BK;
+    const int G = ntiles * nk;
+    const int srow = L.tid >> 3;
+    const int scol = (L.tid & 7) * 4;
+    f32x16 acc[2][2];
+    zero_acc(acc);
+
+    const TileRsrc prs = make_tile_rsrc(P, ldp, np, prow0);
+    unsigned voq[4], vop[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        voq[q] = (unsigned)(((int64_t)(q * 32 + srow) * ldq + scol) * 4);
+        vop[q] = (unsigned)(((int64_t)(q * 32 + srow) * ldp + scol) * 4);
+    }
+    // (tile, k-slab) of the stage being fetched; runs two stages ahead of the compute stage
+    int ft = 0, fkt = 0;
+    TileRsrc qrs = make_tile_rsrc(Q, ldq, nq, qtile0 * TB);
+    auto fetch_advance = [&]() {
+        if (++fkt == nk) {
+            fkt = 0;
+            ++ft;
+            // past this workgroup's last tile: row0 = nq -> zero valid rows -> every load returns 0
+            qrs = make_tile_rsrc(Q, ldq, nq, ft < ntiles ? (qtile0 + ft) * TB : nq);
+        }
+    };
+    auto issue = [&](f32x4 (&r)[8]) {
+        const unsigned so = (unsigned)(fkt * BK * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            r[q] = rsrc_load(qrs, voq[q], so);
+            r[4 + q] = rsrc_load(prs, vop[q], so);
+        }
+        fetch_advance();
+    };
+    auto commit = [&](f32x4 (&r)[8], int g, int kt) {
+        if constexpr (KTAIL) {                     // D % 32 != 0: zero the inner-dimension tail (branch-free select)
+            const int k = kt * BK + scol;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[q][e] = (k + e < D) ? r[q][e] : 0.f;
+        }
+        float* s = lds + (g & 1) * STAGE_FLOATS + srow * LDK + scol;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<f32x4*>(s + q * 32 * LDK) = r[q];
+            *reinterpret_cast<f32x4*>(s + TILE_FLOATS + q * 32 * LDK) = r[4 + q];
+        }
+    };
+
+    f32x4 ra[8], rb[8];
+    issue(ra);                                     // stage 0
+    issue(rb);                                     // stage 1 (an empty descriptor if there is none)
+    epi.aux_issue(0);
+    commit(ra, 0, 0);
+    epi.aux_commit(0);
+    __syncthreads();
+
+    int t = 0, kt = 0;
+    // One compute stage; RI receives the fetch of stage g+2, RC holds the landed slab of stage g+1.
+    // Fetch and commit are UNCONDITIONAL, so the stage is straight-line code and the compiler can wait for
+    // the older register set with a counted vmcnt while the newer fetch is in flight.  Past the last stage
+    // the fetch hits an empty buffer descriptor (hardware returns zeros, no memory traffic) and the commit
+    // writes those zeros into the LDS buffer nobody reads any more.
+    auto stage = [&](int g, f32x4 (&ri)[8], f32x4 (&rc)[8]) {
+        const bool last_k = (kt == nk - 1);
+        const int nt_ = last_k ? t + 1 : t;
+        const int nkt = last_k ? 0 : kt + 1;
+        issue(ri);
+        if (last_k) epi.aux_issue(nt_);
+        const float* sq = lds + (g & 1) * STAGE_FLOATS + (L.wm * 64 + L.r) * LDK + L.h * 4;
+        const float* sp = lds + (g & 1) * STAGE_FLOATS + TILE_FLOATS + (L.wn * 64 + L.r) * LDK + L.h * 4;
+        FragSet f0 = read_frags(sq, sp, 0);
+        FragSet f1 = read_frags(sq, sp, 1);
+        mfma_chunk(f0, acc);
+        f0 = read_frags(sq, sp, 2);
+        mfma_chunk(f1, acc);
+        commit(rc, g + 1, nkt);                    // LDS writes of the next slab, behind queued MFMAs
+        f1 = read_frags(sq, sp, 3);
+        mfma_chunk(f0, acc);
+        mfma_chunk(f1, acc);
+        if (last_k) {
+            epi.finish(t, acc);
+            zero_acc(acc);
+            epi.aux_commit(nt_);
+        }
+        __syncthreads();
+        t = nt_;
+        kt = nkt;
+    };
+    int g = 0;
+    for (; g + 1 < G; g += 2) {
+        stage(g, ra, rb);
+        stage(g + 1, rb, ra);
+    }
+    if (g < G) stage(g, ra, rb);
 }
 
 // Runs `ntiles` consecutive 128x128 tiles.  Src(t, row) returns the global row

@@ -1,4 +1,4 @@
-from .fad import frechet_distance                                   # noqa: F401
-from .kd import kernel_distance, kid_features_to_metric              # noqa: F401
-from .prdc import prdc, nearest_neighbour_distances                  # noqa: F401
-from .apa import apa, apa_compute_d_x_xp, _apa                       # noqa: F401
+"""Metric functions of the hot path, one module per reference module
+(src/audio_metrics/metrics/{fad,kd,prdc,apa}.py).  Submodules are kept importable by
+name (``metrics.apa`` is the module, as in the reference), so nothing is re-exported here."""
+from . import apa, fad, kd, prdc   # noqa: F401

@@ -30,13 +30,15 @@ METRIC = "evaluate() embeddings/sec (FAD+KD+PRDC), 2×100k CLAP-512 sets, 1/2/4/
 F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
-def cpu_baseline(ref, cand, k, sample_rows=10000):
+def cpu_baseline(ref, cand, k, sample_rows=8000):
     """The CPU oracle (a port of the reference's torch/numpy calls, oracle/) timed on
     this host.  stats + FAD + KD run at the full size; PRDC materialises N x N
     matrices in the reference (164 GB at 100k), so it is timed on a row subsample
     and scaled by (N / sample)^2."""
     import oracle
-    torch.set_num_threads(os.cpu_count() or 1)
+    # LAPACK geev (the reference's eigvals) and small-block cdist degrade badly with hundreds of
+    # threads (measured on the 256-core GPU host: eigvals 477 s); cap at 32 and report the count used.
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     ref, cand = ref.cpu(), cand.cpu()
     n = len(ref)
     t0 = time.perf_counter()

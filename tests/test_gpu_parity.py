@@ -98,13 +98,16 @@ def test_knn_k_out_of_range(am):
 def test_prdc_self_consistency_full_size(am):
     """2 x 100k x 512 (BASELINE config 3 shape), size-independent property: for
     identical sets every row has exactly k columns strictly inside its radius
-    (itself + k-1 neighbours), so precision = recall = coverage = density = 1."""
+    (itself + k-1 neighbours) unless its k-th and (k-1)-th neighbours tie in f32, so
+    precision = recall = coverage = 1 and the count total is N*k minus a few ties."""
     torch.manual_seed(0)
     x = torch.randn(100000, 512, device="cuda:0")
     a = am.AudioMetricsData(True)
     a.add(x)
     res = am.prdc(a, a, 5)
-    assert res == dict(precision=1.0, recall=1.0, density=1.0, coverage=1.0)
+    assert (res["precision"], res["recall"], res["coverage"]) == (1.0, 1.0, 1.0)
+    total = round(res["density"] * 5 * 100000)
+    assert 500000 - 50 <= total <= 500000, total
 
 
 # ----------------------------------------------------------------- stats
