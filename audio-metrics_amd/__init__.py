@@ -13,4 +13,7 @@ from .metrics.kd import kernel_distance, kid_features_to_metric               # 
 from .metrics.prdc import prdc, nearest_neighbour_distances                   # noqa: F401
 from .metrics.apa import apa, apa_compute_d_x_xp                              # noqa: F401
 
+from .embed import ItemCategory, embedding_pipeline                            # noqa: F401
+from .audio_metrics import AudioMetrics                                        # noqa: F401
+
 __version__ = "0.1.0"

@@ -81,3 +81,54 @@ PRDC_CASES = {
     "ragged_300_500_24_k3": ("shifted", 45, 300, 500, 24, 3),
     "tiny_12_9_8_k2": ("shifted", 46, 12, 9, 8, 2),
 }
+
+
+# ---- end-to-end (A12/A13) case: synthetic (context, stem) pairs + a host-side numpy embedder
+E2E = dict(sr=16000, win_dur=1.0, n_ref=60, n_cand=50, seconds=3, dim=24, seed=77, random_seed=1234)
+
+
+def e2e_pairs(seed, n_items, seconds, sr, stem_gain=1.0):
+    """n_items arrays of shape (seconds*sr, 2): column 0 = context, column 1 = stem."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(seconds * sr) / sr
+    out = []
+    for _ in range(n_items):
+        f0, f1 = rng.uniform(80, 400), rng.uniform(200, 1200)
+        ctx = np.sin(2 * np.pi * f0 * t) * rng.uniform(0.2, 0.9) + 0.05 * rng.standard_normal(len(t))
+        stem = np.sign(np.sin(2 * np.pi * f1 * t)) * rng.uniform(0.1, 0.6) * stem_gain + 0.05 * rng.standard_normal(len(t))
+        out.append(np.stack([ctx, stem], axis=1).astype(np.float32))
+    return out
+
+
+class NumpyEmbedder:
+    """Embedder protocol (sr / get_device / forward) computed entirely with numpy on the host,
+    so the reference run and this build see bit-identical embeddings."""
+
+    def __init__(self, dim=24, sr=16000, frame=400, seed=5):
+        rng = np.random.default_rng(seed)
+        self._sr, self.frame = sr, frame
+        self.w = (rng.standard_normal((frame, dim)) / np.sqrt(frame)).astype(np.float64)
+
+    @property
+    def sr(self):
+        return self._sr
+
+    def get_device(self):
+        import torch
+        return torch.device("cpu")
+
+    def forward(self, data, sr=None):
+        import torch
+        audio = np.asarray(data["audio"], dtype=np.float64)
+        if audio.ndim == 1:
+            audio = audio[None]
+        n = audio.shape[1] // self.frame * self.frame
+        frames = audio[:, :n].reshape(len(audio), -1, self.frame)
+        h = np.tanh(3.0 * frames @ self.w)
+        emb = np.concatenate([h.mean(1)[:, : self.w.shape[1] // 2], h.std(1)[:, self.w.shape[1] // 2:]], axis=1)
+        return {"embedding": torch.as_tensor(emb.astype(np.float32))}
+
+
+def e2e_mix(audio, sr):
+    """custom mix function (protocol f(audio[n,2], sr) -> audio[n])"""
+    return 0.6 * audio[:, 0] + 0.4 * audio[:, 1]

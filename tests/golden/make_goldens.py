@@ -152,8 +152,66 @@ def gen_apa():
     np.savez_compressed(os.path.join(HERE, "apa.npz"), **out)
 
 
+def gen_e2e():
+    """Full API (A12/A13) through the reference's own AudioMetrics, with ENVIRONMENT shims only
+    (SURVEY appendix A recipe 2): stub modules for packages absent here, one pretend GPU, no model
+    cloning, and an in-order stand-in for the thread-pool pump so the row order is reproducible."""
+    import random
+    for name in ("soxr", "pyloudnorm", "pyloudnorm.util", "pyloudnorm.normalize", "numpy_audio_limiter",
+                 "opt_einsum", "numba", "appdirs"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["numba"].jit = lambda *a, **k: (lambda f: f)
+    sys.modules["pyloudnorm"].Meter = object
+    sys.modules["pyloudnorm"].util = sys.modules["pyloudnorm.util"]
+    sys.modules["pyloudnorm"].normalize = sys.modules["pyloudnorm.normalize"]
+    sys.modules["appdirs"].user_cache_dir = lambda *a, **k: "/tmp"
+    del sys.modules["audio_metrics"]
+    for k in [k for k in sys.modules if k.startswith("audio_metrics.")]:
+        del sys.modules[k]
+    sys.path.insert(0, "/root/reference/src")
+    import audio_metrics
+    import audio_metrics.embed as r_embed
+    import audio_metrics.util.gpu_parallel as r_gp
+    torch.cuda.device_count = lambda: 1
+    r_gp.clone_model = lambda model, device: model
+
+    def in_order(iterator, target, discard_input=True, **kw):
+        for item in iterator:
+            res = target(item)
+            if discard_input:
+                yield res
+            else:
+                item.update(res)
+                yield item
+    r_embed.cpu_parallel = in_order
+
+    c = gi.E2E
+    out = {"versions": VERSIONS}
+    for tag, metrics in (("all", ["fad", "kd", "prdc", "apa"]), ("stems", ["fad", "kd", "prdc"]), ("apa", ["apa"])):
+        random.seed(c["random_seed"])
+        am = audio_metrics.AudioMetrics(metrics=metrics, embedder=gi.NumpyEmbedder(c["dim"], c["sr"]),
+                                        mix_function=gi.e2e_mix, win_dur=c["win_dur"])
+        ref = gi.e2e_pairs(c["seed"], c["n_ref"], c["seconds"], c["sr"])
+        cand = gi.e2e_pairs(c["seed"] + 1, c["n_cand"], c["seconds"], c["sr"], stem_gain=1.3)
+        if tag == "stems":
+            ref, cand = [x[:, 1] for x in ref], [x[:, 1] for x in cand]
+        am.add_reference(ref)
+        res = am.evaluate(cand)
+        for k, v in res.items():
+            out[f"{tag}/{k}"] = v
+        out[f"{tag}/keys"] = np.array(list(res.keys()))
+        for attr in ("stem_reference", "mix_reference", "mix_anti_reference"):
+            d = getattr(am, attr)
+            if d is not None and d.n is not None:
+                out[f"{tag}/{attr}/n"] = d.n
+                out[f"{tag}/{attr}/mean"] = d.mean.numpy()
+                out[f"{tag}/{attr}/cov"] = d.cov.numpy()
+        print("e2e", tag, res)
+    np.savez_compressed(os.path.join(HERE, "e2e.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["stats", "fad", "kd", "prdc", "apa"]
+    which = sys.argv[1:] or ["stats", "fad", "kd", "prdc", "apa", "e2e"]
     for w in which:
         globals()[f"gen_{w}"]()
     print("done", VERSIONS)

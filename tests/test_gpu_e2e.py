@@ -1,0 +1,124 @@
+"""End-to-end parity of the front end (A12/A13): AudioMetrics.add_reference / evaluate
+against goldens produced by the reference's own AudioMetrics (same synthetic audio, same
+host-side numpy embedder and mix function, same random.seed)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import inputs as gi
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def am():
+    import audio_metrics_amd
+    audio_metrics_amd._lib.load()
+    return audio_metrics_amd
+
+
+def make(am, metrics, **kw):
+    c = gi.E2E
+    return am.AudioMetrics(metrics=metrics, embedder=gi.NumpyEmbedder(c["dim"], c["sr"]), mix_function=gi.e2e_mix,
+                           win_dur=c["win_dur"], **kw)
+
+
+def data(stems_only=False):
+    c = gi.E2E
+    ref = gi.e2e_pairs(c["seed"], c["n_ref"], c["seconds"], c["sr"])
+    cand = gi.e2e_pairs(c["seed"] + 1, c["n_cand"], c["seconds"], c["sr"], stem_gain=1.3)
+    if stems_only:
+        ref, cand = [x[:, 1] for x in ref], [x[:, 1] for x in cand]
+    return ref, cand
+
+
+def tol(key, want):
+    if key.startswith("kernel_distance"):
+        return max(REL * abs(want), 5e-7)
+    if key in ("precision", "recall", "coverage", "density"):
+        return max(REL * abs(want), 1.0 / 150)          # one membership flip among 150 candidate windows
+    return REL * abs(want)
+
+
+@pytest.mark.parametrize("tag,metrics", [("all", ["fad", "kd", "prdc", "apa"]), ("stems", ["fad", "kd", "prdc"]),
+                                         ("apa", ["apa"])])
+def test_evaluate_matches_reference(am, golden, tag, metrics):
+    g = golden("e2e")
+    random.seed(gi.E2E["random_seed"])
+    m = make(am, metrics)
+    ref, cand = data(stems_only=(tag == "stems"))
+    m.add_reference(ref)
+    res = m.evaluate(cand)
+    assert list(res) == [str(k) for k in g[f"{tag}/keys"]]
+    for key, v in res.items():
+        want = float(g[f"{tag}/{key}"])
+        assert abs(v - want) <= tol(key, want), (key, v, want)
+        assert isinstance(v, float)
+    for attr in ("stem_reference", "mix_reference", "mix_anti_reference"):
+        if f"{tag}/{attr}/n" in g.files:
+            d = getattr(m, attr)
+            assert d.n == int(g[f"{tag}/{attr}/n"])
+            np.testing.assert_allclose(d.mean.cpu().numpy(), g[f"{tag}/{attr}/mean"], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(d.cov.cpu().numpy(), g[f"{tag}/{attr}/cov"], rtol=1e-4, atol=1e-8)
+    # a second evaluate() reuses the cached reference side (radii, d_x_xp) and gives the same values
+    res2 = m(cand)
+    for key in res:
+        assert abs(res2[key] - res[key]) <= 1e-9 * max(1.0, abs(res[key]))
+
+
+def test_input_containers(am):
+    """ndarray (B, n, 2), generator of (n, 2) arrays and torch tensor are all accepted (embed.py:110-147)."""
+    ref, cand = data()
+    outs = []
+    for conv in (lambda x: np.stack(x), lambda x: (a for a in x), lambda x: torch.as_tensor(np.stack(x))):
+        random.seed(3)
+        m = make(am, ["fad", "apa"])
+        m.add_reference(conv(ref))
+        outs.append(m.evaluate(conv(cand)))
+    for o in outs[1:]:
+        assert o.keys() == outs[0].keys()
+        for k in o:
+            assert abs(o[k] - outs[0][k]) <= 1e-9 * max(1.0, abs(outs[0][k]))
+
+
+def test_errors(am):
+    ref, cand = data(stems_only=True)
+    m = make(am, ["fad", "apa"])
+    with pytest.raises(ValueError):
+        m.add_reference(ref)                       # APA requested but items are 1-D (embed.py:54-56)
+    m = make(am, ["fad"])
+    with pytest.raises(ValueError):
+        m.evaluate(cand)                           # empty reference (audio_metrics.py:300-313)
+    m.add_reference([x[:100] for x in ref])        # shorter than win_dur -> still empty
+    with pytest.raises(ValueError):
+        m.evaluate(cand)
+    with pytest.raises(ValueError):
+        am.AudioMetrics(metrics=["fad"], embedder="no_such_embedder")
+    with pytest.raises(ValueError):
+        am.AudioMetrics(metrics=["fad"], embedder=gi.NumpyEmbedder(), mix_function="no_such_mix")
+
+
+def test_save_load_state_roundtrip(am, tmp_path):
+    """Device analogue of the reference's tests/test_audio_metrics.py:175-197 (rel=abs=1e-6)."""
+    ref, cand = data()
+    random.seed(11)
+    m1 = make(am, ["fad", "kd", "prdc", "apa"])
+    m1.add_reference(ref)
+    r1 = m1.evaluate(cand)
+    fp = tmp_path / "state.pt"
+    m1.save_state(fp)
+    state = torch.load(fp, weights_only=True)      # loadable with weights_only=True, reference layout
+    assert set(state["stem_reference"]) == {"mean", "n", "cov", "store_embeddings", "embeddings", "radii", "dtype"}
+    assert not state["stem_reference"]["mean"].is_cuda
+    m2 = make(am, ["fad", "kd", "prdc", "apa"])
+    m2.load_state(fp)
+    r2 = m2.evaluate(cand)
+    assert r1.keys() == r2.keys()
+    for k in r1:
+        assert r2[k] == pytest.approx(r1[k], rel=1e-6, abs=1e-6)
+    m2.reset_reference()
+    with pytest.raises(ValueError):
+        m2.evaluate(cand)
