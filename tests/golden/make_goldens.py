@@ -185,6 +185,18 @@ def gen_e2e():
                 yield item
     r_embed.cpu_parallel = in_order
 
+    def in_order_gpu(iterator, model, discard_input=True, **kw):
+        # the reference's pump yields batches in completion order (cf.as_completed), which is not
+        # reproducible; batch order decides the stored row order and hence KD (kd.py:185-186)
+        for item in iterator:
+            res = model.forward(item)
+            if discard_input:
+                yield res
+            else:
+                item.update(res)
+                yield item
+    r_embed.gpu_parallel = in_order_gpu
+
     c = gi.E2E
     out = {"versions": VERSIONS}
     for tag, metrics in (("all", ["fad", "kd", "prdc", "apa"]), ("stems", ["fad", "kd", "prdc"]), ("apa", ["apa"])):
