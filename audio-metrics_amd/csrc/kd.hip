@@ -32,7 +32,7 @@ struct KdEpilogue {
     double sum;
     const LaneInfo& L;
     __device__ __forceinline__ KdEpilogue(const LaneInfo& l) : L(l) {}
-    __device__ __forceinline__ void aux_issue(int) {}
+    __device__ __forceinline__ void aux_issue(int, int64_t) {}
     __device__ __forceinline__ void aux_commit(int) {}
     __device__ __forceinline__ double kval(float dot) const {
         const double base = (double)dot * gamma + coef0;
@@ -42,7 +42,7 @@ struct KdEpilogue {
     }
     // Sums ALL 128x128 entries of the tile; padded (zero) rows give exactly kval(0) each, which the
     // caller subtracts analytically.  Diagonal entries of Kxx / Kyy are removed here (valid ones only).
-    __device__ __forceinline__ void finish(int, f32x16 (&acc)[2][2]) {
+    __device__ __forceinline__ void finish(int, int64_t, f32x16 (&acc)[2][2]) {
         double s = 0.0;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)

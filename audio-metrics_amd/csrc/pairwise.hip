@@ -10,8 +10,12 @@
 #include "am_common.h"
 #include "tile_engine.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 
 namespace am {
+
+constexpr int EV_DEFAULT = EV_RSRC | EV_FRAGDB | EV_EARLY;   // the production schedule of the tile engine
 
 // ------------------------------------------------------------------ row norms
 // |x|^2 in f32 with a fixed order (mirrored by oracle/exact_c): lane l of the
@@ -84,6 +88,16 @@ __device__ __forceinline__ WorkItem work_item(int64_t q_tiles, int nchunks) {
     return w;
 }
 
+// the generic (gather) pipeline numbers tiles locally; shift them to absolute Q tile indices
+template <class Epi>
+struct OffsetEpilogue {
+    Epi& e;
+    int64_t q0;
+    __device__ __forceinline__ void aux_issue(int t, int64_t qt) { e.aux_issue(t, q0 + qt); }
+    __device__ __forceinline__ void aux_commit(int t) { e.aux_commit(t); }
+    __device__ __forceinline__ void finish(int t, int64_t qt, f32x16 (&acc)[2][2]) { e.finish(t, q0 + qt, acc); }
+};
+
 // ------------------------------------------------------------ k-NN epilogue
 template <int KCAP>
 struct KnnEpilogue {
@@ -96,16 +110,16 @@ struct KnnEpilogue {
     const LaneInfo& L;
 
     __device__ __forceinline__ KnnEpilogue(const LaneInfo& l) : L(l) {}
-    __device__ __forceinline__ void aux_issue(int t) {
+    __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
         if (L.tid < TB) {
-            const int64_t j = (qtile0 + t) * TB + L.tid;
+            const int64_t j = qtile * TB + L.tid;
             aux_reg = j < nq ? qnorm[j] : INFINITY;
         }
     }
     __device__ __forceinline__ void aux_commit(int t) {
         if (L.tid < TB) aux[(t & 1) * TB + L.tid] = aux_reg;
     }
-    __device__ __forceinline__ void finish(int t, f32x16 (&acc)[2][2]) {
+    __device__ __forceinline__ void finish(int t, int64_t, f32x16 (&acc)[2][2]) {
         const float* a = aux + (t & 1) * TB + L.wm * 64 + L.h * 4;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -138,10 +152,11 @@ template <int KCAP, int V, bool KTAIL>
 __global__ void __launch_bounds__(ENGINE_THREADS, 2)
 knn_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ldx, const float* __restrict__ xnorm,
                    const float* __restrict__ Y, int64_t M, int64_t ldy, const float* __restrict__ ynorm,
-                   int D, int nchunks, float* __restrict__ partial) {
+                   int D, int nchunks, int qstride, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
-    const int64_t q_tiles = (M + TB - 1) / TB;
+    // qstride > 1: only every qstride-th column tile is visited (cheap upper bounds for the symmetric kernel)
+    const int64_t q_tiles = ((M + TB - 1) / TB + qstride - 1) / qstride;
     const WorkItem w = work_item(q_tiles, nchunks);
 
     KnnEpilogue<KCAP> epi(L);
@@ -157,14 +172,15 @@ knn_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ldx, const fl
         for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = INFINITY;
     }
     if constexpr (V & EV_EARLY) {
-        dense_pipeline_early<V, KTAIL>(Y, M, ldy, w.qtile0, X, N, ldx, w.prow0, w.ntiles, D, lds, L, epi);
+        dense_pipeline_early<V, KTAIL>(Y, M, ldy, LinearTiles{w.qtile0, qstride}, X, N, ldx, w.prow0, w.ntiles, D, lds, L, epi);
     } else if constexpr (V & EV_RSRC) {
         dense_pipeline<V>(Y, M, ldy, w.qtile0, X, N, ldx, w.prow0, w.ntiles, D, lds, L, epi);
     } else {
         const DenseRows qsrc{Y, ldy, M, w.qtile0};
         const DenseRows psrc_base{X, ldx, N, w.prow0 / TB};
         auto psrc = [&](int, int row) { return psrc_base(0, row); };
-        tile_pipeline(qsrc, psrc, w.ntiles, D, lds, L, epi);
+        OffsetEpilogue<decltype(epi)> oe{epi, w.qtile0};
+        tile_pipeline(qsrc, psrc, w.ntiles, D, lds, L, oe);
     }
 
     // merge the 4 lists that cover each P row (2 half-waves x 2 Q-half waves) through LDS
@@ -194,7 +210,7 @@ knn_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ldx, const fl
 
 // radius[i] = sqrt_rn( (k+1)-th smallest d2 over all chunks )
 template <int KCAP>
-__global__ void knn_merge_kernel(const float* __restrict__ partial, int64_t N, int nchunks, int k1,
+__global__ void knn_merge_kernel(const float* __restrict__ partial, int64_t N, int nchunks, int k1, int squared,
                                  float* __restrict__ radii) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -209,7 +225,273 @@ __global__ void knn_merge_kernel(const float* __restrict__ partial, int64_t N, i
 #pragma unroll
     for (int s = 1; s < KCAP; ++s)
         if (s == k1 - 1) r2 = m[s];
+    radii[i] = squared ? r2 : sqrt_rn(r2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Symmetric k-NN (Y == X).  d2(i,j) == d2(j,i) bit for bit (products commute, same inner order), so only
+// the tile pairs (pb, qt) with qt in the CYCLIC HALF-RANGE pb, pb+1, ..., pb+T/2 (mod T) are multiplied.
+// Each tile serves two directions:
+//   * rows of the P block: per-lane sorted lists, exactly as in the general kernel;
+//   * rows of the Q block (the mirrored entries): a value can only matter if it is <= an UPPER BOUND
+//     thr[j] of that row's final (k+1)-th smallest d2 (<=, not <: a bound can be exactly tight, and then the
+//     entry that defines it may sit in the mirrored half).  Bounds come from a 1/32 column-sample pre-pass of
+//     the general kernel and are tightened (atomicMin) by every workgroup that finishes a row block.
+//     The few survivors are appended to a per-row candidate buffer; rows whose buffer overflows are
+//     recomputed exactly by knn_fixup_kernel.  The final value is the (k+1)-th smallest of a multiset that
+//     provably contains every entry below it, so it equals the general kernel's result bit for bit.
+template <int KCAP>
+struct KnnSymEpilogue {
+    const float* qnorm;
+    const float* thr;
+    int64_t n, pblock;
+    float* aux;                 // LDS [2][2][128] : |x_j|^2 and thr[j] of the tile
+    float* cand;
+    int* cnt;
+    int cap;
+    uint2* wgq;                 // this workgroup's append region in global memory: (row, d2 bits)
+    int* qn;                    // LDS slot counter of that region
+    int qcap;
+    float xn[2];
+    float flt[2];               // bound of this lane's own rows at workgroup start: larger values cannot matter
+    bool rowok[2];
+    float best[2][KCAP];
+    float aux_n, aux_t;
+    const LaneInfo& L;
+
+    __device__ __forceinline__ KnnSymEpilogue(const LaneInfo& l) : L(l) {}
+    // A surviving mirrored entry.  The slot comes from an LDS atomic (no global round trip) and the store
+    // is fire-and-forget; knn_sym_scatter_kernel later files the entries under their rows.  Only when the
+    // region is full does the entry go to the row's candidate buffer directly (returning global atomic).
+    __device__ __forceinline__ void push(int64_t j, float d2) {
+        const int slot = atomicAdd(qn, 1);
+        if (slot < qcap) {
+            wgq[slot] = make_uint2((unsigned)j, __float_as_uint(d2));
+        } else {
+            const int s2 = atomicAdd(cnt + j, 1);
+            if (s2 < cap) cand[j * cap + s2] = d2;
+        }
+    }
+    __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
+        if (L.tid < TB) {
+            const int64_t j = qtile * TB + L.tid;
+            aux_n = j < n ? qnorm[j] : INFINITY;
+            aux_t = j < n ? __hip_atomic_load(thr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1.f;   // -1: never hit
+        }
+    }
+    __device__ __forceinline__ void aux_commit(int t) {
+        if (L.tid < TB) {
+            aux[(t & 1) * 2 * TB + L.tid] = aux_n;
+            aux[(t & 1) * 2 * TB + TB + L.tid] = aux_t;
+        }
+    }
+    __device__ __forceinline__ void finish(int t, int64_t qtile, f32x16 (&acc)[2][2]) {
+        const float* a = aux + (t & 1) * 2 * TB + L.wm * 64 + L.h * 4;
+        const bool mirror = (qtile != pblock);            // the diagonal tile already holds both directions
+        const int64_t jbase = qtile * TB + L.wm * 64 + L.h * 4;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 yn[4], tq[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
+                tq[g4] = *reinterpret_cast<const f32x4*>(a + TB + mt * 32 + g4 * 8);
+            }
+            float tmax = 0.f;                             // loosest bound among this lane's 16 Q rows
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) tmax = fmaxf(tmax, tq[reg >> 2][reg & 3]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float tmin = INFINITY;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    tmin = fminf(tmin, fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]));
+                tmin = fmaxf(tmin, 0.f);
+                // <= : an entry EQUAL to the bound may be the (k+1)-th smallest itself
+                if (__any(tmin < best[nt][KCAP - 1] && tmin <= flt[nt])) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float d2 = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
+                        const float v = d2 <= flt[nt] ? d2 : INFINITY;
+                        if (__any(v < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], v);
+                    }
+                }
+                // <= again: if a bound is exactly tight, the entry that defines it may live in the mirrored half
+                if (mirror && __any(rowok[nt] && tmin <= tmax)) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float d2 = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
+                        if (rowok[nt] && d2 <= tq[reg >> 2][reg & 3])
+                            push(jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3), d2);
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <int KCAP, bool KTAIL>
+__global__ void __launch_bounds__(ENGINE_THREADS, 2)
+knn_sym_kernel(const float* __restrict__ X, int64_t N, int64_t ld, const float* __restrict__ xnorm, float* thr, int D,
+               int nchunks, int k1, float* __restrict__ partial, float* __restrict__ cand, int* __restrict__ cnt, int cap,
+               uint2* __restrict__ wgq, int qcap, int* __restrict__ wgq_count) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LaneInfo L;
+    const int64_t T = (N + TB - 1) / TB;
+    // CHUNK-MAJOR order: all row blocks do their first slice of offsets before any does its second, so every
+    // row publishes a bound over 1/nchunks of its half-range early and later slices see few mirrored survivors
+    const int chunk = (int)(blockIdx.x / T);
+    const int64_t pb = blockIdx.x % T;
+    // offsets 0 .. T/2; for even T the antipodal offset T/2 is taken by the lower-numbered block only
+    int64_t noff = T / 2 + 1;
+    if ((T % 2) == 0 && pb >= T / 2) noff = T / 2;
+    const int64_t o0 = noff * chunk / nchunks;
+    const int ntiles = (int)(noff * (chunk + 1) / nchunks - o0);
+
+    KnnSymEpilogue<KCAP> epi(L);
+    epi.qnorm = xnorm;
+    epi.thr = thr;
+    epi.n = N;
+    epi.pblock = pb;
+    epi.aux = lds + ENGINE_LDS_FLOATS;
+    epi.cand = cand;
+    epi.cnt = cnt;
+    epi.cap = cap;
+    epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
+    epi.qn = reinterpret_cast<int*>(lds + ENGINE_LDS_FLOATS + 4 * TB);
+    epi.qcap = qcap;
+    if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int64_t i = pb * TB + L.wn * 64 + nt * 32 + L.r;
+        epi.rowok[nt] = i < N;
+        epi.xn[nt] = i < N ? xnorm[i] : 0.f;
+        epi.flt[nt] = i < N ? __hip_atomic_load(thr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = INFINITY;
+    }
+    if (ntiles > 0) {
+        int64_t start = pb + o0;
+        if (start >= T) start -= T;
+        dense_pipeline_early<EV_DEFAULT, KTAIL>(X, N, ld, CyclicTiles{start, T}, X, N, ld, pb * TB, ntiles, D, lds, L, epi);
+    }
+    __syncthreads();                                  // ntiles == 0: still orders the counter reset
+    float* mg = lds;                                   // [128][4][KCAP]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float* dst = mg + ((L.wn * 64 + nt * 32 + L.r) * 4 + (L.wm * 2 + L.h)) * KCAP;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
+    }
+    __syncthreads();
+    if (L.tid == 0) wgq_count[blockIdx.x] = min(*epi.qn, qcap);
+    if (L.tid < TB) {
+        const int64_t i = pb * TB + L.tid;
+        if (i < N) {
+            const float* src = mg + L.tid * 4 * KCAP;
+            float m[KCAP];
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) m[s] = src[s];
+            for (int s = KCAP; s < 4 * KCAP; ++s) list_insert<KCAP>(m, src[s]);
+            float* out = partial + ((int64_t)chunk * N + i) * KCAP;
+            float kth = m[0];
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) {
+                out[s] = m[s];
+                if (s == k1 - 1) kth = m[s];
+            }
+            // a (k+1)-th smallest over a subset of the columns bounds the final one from above: publish it
+            atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(kth));
+        }
+    }
+}
+
+// files the per-workgroup append regions under their rows (massively parallel, latency hidden)
+__global__ void __launch_bounds__(256) knn_sym_scatter_kernel(const uint2* __restrict__ wgq, int qcap,
+                                                              const int* __restrict__ wgq_count, float* __restrict__ cand,
+                                                              int* __restrict__ cnt, int cap) {
+    const int n = wgq_count[blockIdx.x];
+    const uint2* q = wgq + (int64_t)blockIdx.x * qcap;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const uint2 v = q[e];
+        const int slot = atomicAdd(cnt + v.x, 1);
+        if (slot < cap) cand[(int64_t)v.x * cap + slot] = __uint_as_float(v.y);
+    }
+}
+
+template <int KCAP>
+__global__ void knn_sym_merge_kernel(const float* __restrict__ partial, int64_t N, int nchunks, int k1,
+                                     const float* __restrict__ cand, const int* __restrict__ cnt, int cap,
+                                     float* __restrict__ radii, int* __restrict__ ov_list, int* __restrict__ ov_count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int c = cnt[i];
+    if (c > cap) {                                     // candidate buffer overflowed: exact recomputation later
+        ov_list[atomicAdd(ov_count, 1)] = (int)i;
+        return;
+    }
+    float m[KCAP];
+#pragma unroll
+    for (int s = 0; s < KCAP; ++s) m[s] = partial[i * KCAP + s];
+    for (int ch = 1; ch < nchunks; ++ch) {
+        const float* src = partial + ((int64_t)ch * N + i) * KCAP;
+        for (int s = 0; s < KCAP; ++s) list_insert<KCAP>(m, src[s]);
+    }
+    const float* cs = cand + i * (int64_t)cap;
+    for (int s = 0; s < c; ++s) list_insert<KCAP>(m, cs[s]);
+    float r2 = m[0];
+#pragma unroll
+    for (int s = 1; s < KCAP; ++s)
+        if (s == k1 - 1) r2 = m[s];
     radii[i] = sqrt_rn(r2);
+}
+
+// Exact recomputation of single rows (candidate-buffer overflow): one workgroup per row, every thread
+// walks columns j = tid, tid+256, ... with the engine's fmaf order, keeps a sorted list, lists merged in LDS.
+template <int KCAP>
+__global__ void __launch_bounds__(256) knn_fixup_kernel(const float* __restrict__ X, int64_t N, int64_t ld,
+                                                        const float* __restrict__ xnorm, int D, int k1,
+                                                        const int* __restrict__ ov_list, const int* __restrict__ ov_count,
+                                                        float* __restrict__ radii) {
+    extern __shared__ __attribute__((aligned(16))) float xrow[];      // D padded to a multiple of 32
+    __shared__ float lists[256 * KCAP];
+    const int n_ov = *ov_count;
+    const int dp = (D + 31) / 32 * 32;
+    for (int ov = blockIdx.x; ov < n_ov; ov += gridDim.x) {
+        const int64_t i = ov_list[ov];
+        for (int k = threadIdx.x; k < dp; k += 256) xrow[k] = k < D ? X[i * ld + k] : 0.f;
+        __syncthreads();
+        float m[KCAP];
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) m[s] = INFINITY;
+        const float xi = xnorm[i];
+        for (int64_t j = threadIdx.x; j < N; j += 256) {
+            const float* y = X + j * ld;
+            float acc = 0.f;
+            for (int c = 0; c < dp; c += 8) {
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const int ka = c + s2, kb = c + 4 + s2;
+                    acc = fmaf(ka < D ? y[ka] : 0.f, xrow[ka], acc);
+                    acc = fmaf(kb < D ? y[kb] : 0.f, xrow[kb], acc);
+                }
+            }
+            const float d2 = fmaxf(fmaf(-2.f, acc, xi + xnorm[j]), 0.f);
+            if (d2 < m[KCAP - 1]) list_insert<KCAP>(m, d2);
+        }
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) lists[threadIdx.x * KCAP + s] = m[s];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int s = KCAP; s < 256 * KCAP; ++s) list_insert<KCAP>(m, lists[s]);
+            float r2 = m[0];
+#pragma unroll
+            for (int s = 1; s < KCAP; ++s)
+                if (s == k1 - 1) r2 = m[s];
+            radii[i] = sqrt_rn(r2);
+        }
+        __syncthreads();
+    }
 }
 
 // --------------------------------------------------------- PRDC counts epilogue
@@ -224,9 +506,9 @@ struct CrossEpilogue {
     const LaneInfo& L;
 
     __device__ __forceinline__ CrossEpilogue(const LaneInfo& l) : L(l) {}
-    __device__ __forceinline__ void aux_issue(int t) {
+    __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
         if (L.tid < TB) {
-            const int64_t j = (qtile0 + t) * TB + L.tid;
+            const int64_t j = qtile * TB + L.tid;
             aux_n = j < nq ? qnorm[j] : INFINITY;
             aux_t = j < nq ? qthr[j] : 0.f;
         }
@@ -237,9 +519,9 @@ struct CrossEpilogue {
             aux[(t & 1) * 2 * TB + TB + L.tid] = aux_t;
         }
     }
-    __device__ __forceinline__ void finish(int t, f32x16 (&acc)[2][2]) {
+    __device__ __forceinline__ void finish(int t, int64_t qtile, f32x16 (&acc)[2][2]) {
         const float* a = aux + (t & 1) * 2 * TB + L.wm * 64 + L.h * 4;
-        const int64_t jbase = (qtile0 + t) * TB + L.wm * 64;
+        const int64_t jbase = qtile * TB + L.wm * 64;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             f32x4 yn[4], tc[4];
@@ -308,14 +590,15 @@ prdc_cross_kernel(const float* __restrict__ R, int64_t Nr, int64_t ldr, const fl
         epi.margin[nt] = INFINITY;
     }
     if constexpr (V & EV_EARLY) {
-        dense_pipeline_early<V, KTAIL>(C, Nc, ldc, w.qtile0, R, Nr, ldr, w.prow0, w.ntiles, D, lds, L, epi);
+        dense_pipeline_early<V, KTAIL>(C, Nc, ldc, LinearTiles{w.qtile0}, R, Nr, ldr, w.prow0, w.ntiles, D, lds, L, epi);
     } else if constexpr (V & EV_RSRC) {
         dense_pipeline<V>(C, Nc, ldc, w.qtile0, R, Nr, ldr, w.prow0, w.ntiles, D, lds, L, epi);
     } else {
         const DenseRows qsrc{C, ldc, Nc, w.qtile0};
         const DenseRows psrc_base{R, ldr, Nr, w.prow0 / TB};
         auto psrc = [&](int, int row) { return psrc_base(0, row); };
-        tile_pipeline(qsrc, psrc, w.ntiles, D, lds, L, epi);
+        OffsetEpilogue<decltype(epi)> oe{epi, w.qtile0};
+        tile_pipeline(qsrc, psrc, w.ntiles, D, lds, L, oe);
     }
 
 #pragma unroll
@@ -381,7 +664,6 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-constexpr int EV_DEFAULT = EV_RSRC | EV_FRAGDB | EV_EARLY;
 static int engine_variant() {
     static const int v = env_int("AM_ENGINE_VARIANT", EV_DEFAULT);
     return v;
@@ -419,7 +701,7 @@ static int launch_norms(const float* X, int64_t N, int64_t ld, int D, float* out
 
 template <int KCAP, int V, bool KTAIL>
 static int launch_knn_vt(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
-                         const float* yn, int D, int nchunks, float* partial, hipStream_t st) {
+                         const float* yn, int D, int nchunks, int qstride, float* partial, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
         AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_partial_kernel<KCAP, V, KTAIL>),
@@ -428,37 +710,66 @@ static int launch_knn_vt(const float* X, int64_t N, int64_t ldx, const float* xn
     }
     const int64_t blocks = ceil_div(N, TB) * nchunks;
     hipLaunchKernelGGL((knn_partial_kernel<KCAP, V, KTAIL>), dim3((unsigned)blocks), dim3(ENGINE_THREADS),
-                       PAIRWISE_LDS_BYTES, st, X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial);
+                       PAIRWISE_LDS_BYTES, st, X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial);
     AM_LAUNCH_CHECK();
     return AM_OK;
 }
 
 template <int KCAP, int V>
 static int launch_knn_v(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
-                        const float* yn, int D, int nchunks, float* partial, hipStream_t st) {
+                        const float* yn, int D, int nchunks, int qstride, float* partial, hipStream_t st) {
     // the inner-dimension tail (D % 32 != 0) is a separate instantiation so the common kernel carries no tail code
     if constexpr ((V & EV_EARLY) != 0) {
-        if ((D % BK) != 0) return launch_knn_vt<KCAP, V, true>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial, st);
+        if ((D % BK) != 0)
+            return launch_knn_vt<KCAP, V, true>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st);
     }
-    return launch_knn_vt<KCAP, V, false>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial, st);
+    return launch_knn_vt<KCAP, V, false>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st);
 }
 
 template <int KCAP>
 static int launch_knn(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
-                      const float* yn, int D, int k1, int nchunks, float* partial, float* out_r, hipStream_t st) {
+                      const float* yn, int D, int k1, int nchunks, int qstride, bool squared, float* partial,
+                      float* out_r, hipStream_t st) {
     int rc;
     if constexpr (KCAP == 6) {                       // older schedules stay selectable for A/B runs (k <= 5 kernel only)
-        switch (engine_variant()) {
-            case 0: rc = launch_knn_v<KCAP, 0>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial, st); break;
-            case 3: rc = launch_knn_v<KCAP, 3>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial, st); break;
-            default: rc = launch_knn_v<KCAP, EV_DEFAULT>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial, st); break;
+        switch (qstride == 1 ? engine_variant() : EV_DEFAULT) {
+            case 0: rc = launch_knn_v<KCAP, 0>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, 1, partial, st); break;
+            case 3: rc = launch_knn_v<KCAP, 3>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, 1, partial, st); break;
+            default: rc = launch_knn_v<KCAP, EV_DEFAULT>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st); break;
         }
     } else {
-        rc = launch_knn_v<KCAP, EV_DEFAULT>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, partial, st);
+        rc = launch_knn_v<KCAP, EV_DEFAULT>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st);
     }
     if (rc != AM_OK) return rc;
     hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st,
-                       partial, N, nchunks, k1, out_r);
+                       partial, N, nchunks, k1, squared ? 1 : 0, out_r);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+// ---- symmetric path -------------------------------------------------------------------------------
+template <int KCAP>
+static int launch_knn_sym(const float* X, int64_t N, int64_t ld, const float* xn, float* thr, int D, int k1, int nchunks,
+                          float* partial, float* cand, int* cnt, int cap, uint2* wgq, int qcap, int* wgq_count,
+                          int* ov_list, int* ov_count, float* out_r, hipStream_t st) {
+    const unsigned nwg = (unsigned)(ceil_div(N, TB) * nchunks);
+    auto launch = [&](auto kernel) -> int {
+        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)PAIRWISE_LDS_BYTES + 16));
+        hipLaunchKernelGGL(kernel, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st,
+                           X, N, ld, xn, thr, D, nchunks, k1, partial, cand, cnt, cap, wgq, qcap, wgq_count);
+        AM_LAUNCH_CHECK();
+        return AM_OK;
+    };
+    int rc = ((D % BK) != 0) ? launch(&knn_sym_kernel<KCAP, true>) : launch(&knn_sym_kernel<KCAP, false>);
+    if (rc != AM_OK) return rc;
+    hipLaunchKernelGGL(knn_sym_scatter_kernel, dim3(nwg), dim3(256), 0, st, wgq, qcap, wgq_count, cand, cnt, cap);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_sym_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, partial, N, nchunks, k1,
+                       cand, cnt, cap, out_r, ov_list, ov_count);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
+                       xn, D, k1, ov_list, ov_count, out_r);
     AM_LAUNCH_CHECK();
     return AM_OK;
 }
@@ -467,14 +778,124 @@ static int launch_knn(const float* X, int64_t N, int64_t ldx, const float* xn, c
 
 using namespace am;
 
+// ---- k-NN planning (shared by the workspace query and the launcher) ---------------------------------
+struct KnnPlan {
+    bool sym;
+    int kcap, nchunks;          // main pass
+    int pre_chunks, pre_stride; // sampling pre-pass (symmetric path)
+    int cap;                    // candidate slots per row (symmetric path)
+    int qcap;                   // entries of each workgroup's append region (symmetric path)
+};
+
+static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
+    static const int sym_min = env_int("AM_KNN_SYM_MIN_ROWS", 8192);
+    static const int sym_min_dim = env_int("AM_KNN_SYM_MIN_DIM", 128);
+    static const int cap_env = env_int("AM_KNN_SYM_CAP", 0);
+    static const int stride = env_int("AM_KNN_SYM_STRIDE", 32);
+    KnnPlan p;
+    p.kcap = kcap_for(k + 1);
+    // the mirrored-candidate machinery costs per PAIR, the saved MFMA work scales with D: worth it for
+    // wide embeddings and enough rows (measured crossover, tools/ab_knn.py)
+    p.sym = self && N >= sym_min && D >= sym_min_dim && N >= 2 * TB;
+    // survivors per row are ~ (k+1) * (1 + stride/2 ... ) with a heavy tail: 64 slots per list entry
+    p.cap = cap_env > 0 ? cap_env : std::max(256, 64 * (k + 1));
+    p.pre_stride = stride;
+    p.pre_chunks = 1;
+    p.qcap = 0;
+    if (!p.sym) {
+        p.nchunks = choose_chunks(N, M);
+        return p;
+    }
+    const int64_t T = ceil_div(N, TB);
+    const int64_t sample_tiles = ceil_div(T, stride);
+    p.pre_chunks = (int)std::min<int64_t>(sample_tiles, std::max<int64_t>(1, ceil_div(2048, T)));
+    // half as many column tiles per row block as the general kernel: aim for the same workgroup count
+    static const int target = env_int("AM_WG_TARGET", 8192);
+    int64_t want = ceil_div(target, T);
+    want = std::max<int64_t>(want, 4);
+    // a workgroup publishes the (k+1)-th smallest of ITS slice as the row's new bound; slices much shorter
+    // than the pre-pass sample (N/stride columns) would publish nothing useful -> at most 16 slices
+    static const int max_slices = env_int("AM_KNN_SYM_MAX_SLICES", 16);
+    want = std::min<int64_t>(want, std::min<int64_t>(T / 2, max_slices));
+    p.nchunks = (int)std::max<int64_t>(want, 1);
+    // expected survivors per workgroup in the first slice (bounds from the sample only):
+    //   pairs = 128 * ntiles * 128, hit rate = (k+1) / (N / stride); keep 4x head-room
+    const double ntiles = (double)(T / 2 + 1) / p.nchunks + 1.0;
+    const double expect = 128.0 * 128.0 * ntiles * (double)(k + 1) * stride / (double)N;
+    static const int qcap_env = env_int("AM_KNN_SYM_QCAP", 0);
+    p.qcap = qcap_env > 0 ? qcap_env : (int)std::min(8192.0, std::max(256.0, 4.0 * expect));
+    return p;
+}
+
+struct KnnBuffers {
+    float *xn, *yn, *thr, *partial, *cand;
+    int *cnt, *ov_list, *ov_count, *wgq_count;
+    uint2* wgq;
+};
+
+static size_t carve_knn(Carver& c, int64_t N, int64_t M, const KnnPlan& p, KnnBuffers& b) {
+    b.xn = c.take<float>(N);
+    b.yn = c.take<float>(M);
+    const size_t lists = (size_t)std::max(p.nchunks, p.pre_chunks) * N * p.kcap;
+    b.partial = c.take<float>(lists);
+    if (p.sym) {
+        b.thr = c.take<float>(N);
+        b.cand = c.take<float>((size_t)N * p.cap);
+        b.cnt = c.take<int>(N + 1);               // [N] = overflow counter
+        b.ov_list = c.take<int>(N);
+        b.ov_count = b.cnt ? b.cnt + N : nullptr;
+        const size_t nwg = (size_t)ceil_div(N, TB) * p.nchunks;
+        b.wgq = c.take<uint2>(nwg * p.qcap);
+        b.wgq_count = c.take<int>(nwg);
+    } else {
+        b.thr = b.cand = nullptr;
+        b.cnt = b.ov_list = b.ov_count = b.wgq_count = nullptr;
+        b.wgq = nullptr;
+    }
+    return c.off;
+}
+
 extern "C" size_t am_knn_workspace_bytes(int64_t N, int64_t M, int k) {
     if (N < 1 || M < 1 || k < 1 || k > AM_MAX_K) return 0;
-    const int nchunks = choose_chunks(N, M);
+    // sized for the symmetric path whenever the shapes allow it (the caller may pass Y == X)
+    const KnnPlan p = plan_knn(N, M, 1 << 20, k, N == M);   // D unknown here: assume the wide case
     Carver c(nullptr, 0);
-    c.take<float>(N);
-    c.take<float>(M);
-    c.take<float>((size_t)nchunks * N * kcap_for(k + 1));
-    return c.off;
+    KnnBuffers b;
+    return carve_knn(c, N, M, p, b);
+}
+
+template <int KCAP>
+static int run_knn(const float* X, int64_t N, int64_t ldx, const float* Y, int64_t M, int64_t ldy, int D, int k1,
+                   const KnnPlan& p, const KnnBuffers& b, bool self, float* out_r, hipStream_t st) {
+    int rc;
+    if (!p.sym)
+        return launch_knn<KCAP>(X, N, ldx, b.xn, Y, M, ldy, self ? b.xn : b.yn, D, k1, p.nchunks, 1, false, b.partial, out_r,
+                                st);
+    // 1) upper bounds thr[i] >= final r2[i] from every pre_stride-th column tile (squared domain)
+    if ((rc = launch_knn<KCAP>(X, N, ldx, b.xn, X, N, ldx, b.xn, D, k1, p.pre_chunks, p.pre_stride, true, b.partial, b.thr,
+                               st)) != AM_OK)
+        return rc;
+    AM_HIP_TRY(hipMemsetAsync(b.cnt, 0, (size_t)(N + 1) * sizeof(int), st));
+    // 2) half of the tile pairs + mirrored candidates, 3) merge, 4) exact fix-up of overflowed rows
+    rc = launch_knn_sym<KCAP>(X, N, ldx, b.xn, b.thr, D, k1, p.nchunks, b.partial, b.cand, b.cnt, p.cap, b.wgq, p.qcap,
+                              b.wgq_count, b.ov_list, b.ov_count, out_r, st);
+    static const int debug = env_int("AM_KNN_DEBUG", 0);
+    if (rc == AM_OK && debug) {                      // development aid: candidate statistics (synchronises!)
+        std::vector<int> cnt(N + 1);
+        const size_t nwg = (size_t)ceil_div(N, TB) * p.nchunks;
+        std::vector<int> wq(nwg);
+        hipStreamSynchronize(st);
+        hipMemcpy(cnt.data(), b.cnt, (N + 1) * sizeof(int), hipMemcpyDeviceToHost);
+        hipMemcpy(wq.data(), b.wgq_count, nwg * sizeof(int), hipMemcpyDeviceToHost);
+        long long tot = 0, mx = 0, wtot = 0, wmx = 0, wfull = 0;
+        for (int64_t i = 0; i < N; ++i) { tot += cnt[i]; mx = std::max<long long>(mx, cnt[i]); }
+        for (size_t i = 0; i < nwg; ++i) { wtot += wq[i]; wmx = std::max<long long>(wmx, wq[i]); wfull += wq[i] >= p.qcap; }
+        fprintf(stderr, "[am knn sym] N=%lld k1=%d nchunks=%d stride=%d cap=%d qcap=%d | candidates/row mean %.1f max %lld | "
+                        "overflow rows %d | wg queue mean %.1f max %lld full %lld of %zu\n",
+                (long long)N, k1, p.nchunks, p.pre_stride, p.cap, p.qcap, (double)tot / N, mx, cnt[N], (double)wtot / nwg, wmx,
+                wfull, nwg);
+    }
+    return rc;
 }
 
 extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const float* Y, int64_t M, int64_t ldy,
@@ -488,22 +909,25 @@ extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const fl
     AM_REQUIRE((int64_t)k + 1 <= M, AM_ERR_BAD_SHAPE, "k + 1 = %d exceeds the %lld available rows (kthvalue out of range)",
                k + 1, (long long)M);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int nchunks = choose_chunks(N, M);
-    const int k1 = k + 1, kcap = kcap_for(k1);
-    Carver c(ws, ws_bytes);
-    float* xn = c.take<float>(N);
-    float* yn = c.take<float>(M);
-    float* partial = c.take<float>((size_t)nchunks * N * kcap);
-    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
-    if ((rc = launch_norms(X, N, ldx, D, xn, st)) != AM_OK) return rc;
     const bool self = (Y == X && M == N && ldy == ldx);
-    if (self) yn = xn;
-    else if ((rc = launch_norms(Y, M, ldy, D, yn, st)) != AM_OK) return rc;
-    switch (kcap) {
-        case 6:  return launch_knn<6>(X, N, ldx, xn, Y, M, ldy, yn, D, k1, nchunks, partial, out_r, st);
-        case 11: return launch_knn<11>(X, N, ldx, xn, Y, M, ldy, yn, D, k1, nchunks, partial, out_r, st);
-        case 16: return launch_knn<16>(X, N, ldx, xn, Y, M, ldy, yn, D, k1, nchunks, partial, out_r, st);
-        default: return launch_knn<32>(X, N, ldx, xn, Y, M, ldy, yn, D, k1, nchunks, partial, out_r, st);
+    KnnPlan p = plan_knn(N, M, D, k, self);
+    Carver c(ws, ws_bytes);
+    KnnBuffers b;
+    carve_knn(c, N, M, p, b);
+    if (!c.ok() && p.sym) {                        // a caller that sized the workspace for Y != X: general path
+        p = plan_knn(N, M, D, k, false);
+        c = Carver(ws, ws_bytes);
+        carve_knn(c, N, M, p, b);
+    }
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    if ((rc = launch_norms(X, N, ldx, D, b.xn, st)) != AM_OK) return rc;
+    if (!self && (rc = launch_norms(Y, M, ldy, D, b.yn, st)) != AM_OK) return rc;
+    const int k1 = k + 1;
+    switch (p.kcap) {
+        case 6:  return run_knn<6>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
+        case 11: return run_knn<11>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
+        case 16: return run_knn<16>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
+        default: return run_knn<32>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
     }
 }
 

@@ -244,7 +244,7 @@ __device__ __forceinline__ void dense_pipeline(const float* __restrict__ Q, int6
     };
 
     issue(0);
-    epi.aux_issue(0);
+    epi.aux_issue(0, qtile0);
     commit(0, 0);
     epi.aux_commit(0);
     __syncthreads();
@@ -258,15 +258,15 @@ __device__ __forceinline__ void dense_pipeline(const float* __restrict__ Q, int6
         if (more) {
             if (last_k) qrs = make_tile_rsrc(Q, ldq, nq, (qtile0 + nt_) * TB);
             if constexpr ((V & EV_ABL_NOLOAD) == 0) issue(nkt);
-            if (last_k) epi.aux_issue(nt_);
+            if (last_k) epi.aux_issue(nt_, qtile0 + nt_);
         }
         const float* s = lds + (g & 1) * STAGE_FLOATS;
         compute_stage_v<V>(s, s + TILE_FLOATS, L, acc);
         if (last_k) {
             if constexpr ((V & EV_ABL_NOEPI) == 0) {
-                epi.finish(t, acc);
+                epi.finish(t, qtile0 + t, acc);
             } else {
-                if (acc[0][0][0] == 123.456f && acc[1][1][7] == 3.f) epi.finish(t, acc);   // keep the MFMAs live
+                if (acc[0][0][0] == 123.456f && acc[1][1][7] == 3.f) epi.finish(t, qtile0 + t, acc);   // keep the MFMAs live
             }
             zero_acc(acc);
         }
@@ -311,8 +311,23 @@ __device__ __forceinline__ void mfma_chunk(const FragSet& f, f32x16 (&acc)[2][2]
 //     between the second and third 8-wide k chunk, i.e. in the shadow of the MFMA pipe,
 // so that only the barrier itself separates two stages.  Same LDS image, stage order and arithmetic as
 // dense_pipeline / tile_pipeline (bit-identical results).
-template <int V, bool KTAIL, class Epi>
-__device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q, int64_t nq, int64_t ldq, int64_t qtile0,
+// Column-tile sequences: local tile t of a workgroup -> 128-row tile index of Q.
+struct LinearTiles {              // (q0 + t) * stride : consecutive tiles, or every stride-th tile (sampling pre-pass)
+    int64_t q0;
+    int64_t stride = 1;
+    __device__ __forceinline__ int64_t operator()(int t) const { return (q0 + t) * stride; }
+};
+struct CyclicTiles {              // (start + t) mod T : the cyclic half-range used by the symmetric k-NN kernel
+    int64_t start, T;
+    __device__ __forceinline__ int64_t operator()(int t) const {
+        const int64_t q = start + t;
+        return q >= T ? q - T : q;
+    }
+};
+
+template <int V, bool KTAIL, class TileMap, class Epi>
+__device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q, int64_t nq, int64_t ldq,
+                                                     const TileMap& tmap,
                                                      const float* __restrict__ P, int64_t np, int64_t ldp, int64_t prow0,
                                                      int ntiles, int D, float* __restrict__ lds, const LaneInfo& L,
                                                      Epi& epi) {
@@ -332,13 +347,13 @@ __device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q
     }
     // (tile, k-slab) of the stage being fetched; runs two stages ahead of the compute stage
     int ft = 0, fkt = 0;
-    TileRsrc qrs = make_tile_rsrc(Q, ldq, nq, qtile0 * TB);
+    TileRsrc qrs = make_tile_rsrc(Q, ldq, nq, tmap(0) * TB);
     auto fetch_advance = [&]() {
         if (++fkt == nk) {
             fkt = 0;
             ++ft;
             // past this workgroup's last tile: row0 = nq -> zero valid rows -> every load returns 0
-            qrs = make_tile_rsrc(Q, ldq, nq, ft < ntiles ? (qtile0 + ft) * TB : nq);
+            qrs = make_tile_rsrc(Q, ldq, nq, ft < ntiles ? tmap(ft) * TB : nq);
         }
     };
     auto issue = [&](f32x4 (&r)[8]) {
@@ -369,7 +384,7 @@ __device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q
     f32x4 ra[8], rb[8];
     issue(ra);                                     // stage 0
     issue(rb);                                     // stage 1 (an empty descriptor if there is none)
-    epi.aux_issue(0);
+    epi.aux_issue(0, tmap(0));
     commit(ra, 0, 0);
     epi.aux_commit(0);
     __syncthreads();
@@ -385,7 +400,7 @@ __device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q
         const int nt_ = last_k ? t + 1 : t;
         const int nkt = last_k ? 0 : kt + 1;
         issue(ri);
-        if (last_k) epi.aux_issue(nt_);
+        if (last_k) epi.aux_issue(nt_, nt_ < ntiles ? tmap(nt_) : (nq + TB - 1) / TB);
         const float* sq = lds + (g & 1) * STAGE_FLOATS + (L.wm * 64 + L.r) * LDK + L.h * 4;
         const float* sp = lds + (g & 1) * STAGE_FLOATS + TILE_FLOATS + (L.wn * 64 + L.r) * LDK + L.h * 4;
         FragSet f0 = read_frags(sq, sp, 0);
@@ -398,7 +413,7 @@ __device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q
         mfma_chunk(f0, acc);
         mfma_chunk(f1, acc);
         if (last_k) {
-            epi.finish(t, acc);
+            epi.finish(t, tmap(t), acc);
             zero_acc(acc);
             epi.aux_commit(nt_);
         }
@@ -416,9 +431,9 @@ __device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q
 
 // Runs `ntiles` consecutive 128x128 tiles.  Src(t, row) returns the global row
 // pointer feeding local row `row` of tile t (nullptr = zero row).  Epi provides
-//   aux_issue(t)  : start any per-tile side loads (all threads call it)
-//   aux_commit(t) : write them to LDS (visible to finish(t) after a barrier)
-//   finish(t,acc) : consume the finished accumulators of tile t
+//   aux_issue(t, qtile) : start any per-tile side loads (all threads call it); qtile = Q tile index
+//   aux_commit(t)       : write them to LDS (visible to finish(t) after a barrier)
+//   finish(t,qtile,acc) : consume the finished accumulators of local tile t
 template <class QSrc, class PSrc, class Epi>
 __device__ __forceinline__ void tile_pipeline(const QSrc& qsrc, const PSrc& psrc, int ntiles, int D,
                                               float* __restrict__ lds, const LaneInfo& L, Epi& epi) {
@@ -448,7 +463,7 @@ __device__ __forceinline__ void tile_pipeline(const QSrc& qsrc, const PSrc& psrc
     };
 
     issue(0, 0);
-    epi.aux_issue(0);
+    epi.aux_issue(0, 0);
     commit(0);
     epi.aux_commit(0);
     __syncthreads();
@@ -461,12 +476,12 @@ __device__ __forceinline__ void tile_pipeline(const QSrc& qsrc, const PSrc& psrc
         const int nkt = last_k ? 0 : kt + 1;
         if (more) {
             issue(nt_, nkt);
-            if (last_k) epi.aux_issue(nt_);
+            if (last_k) epi.aux_issue(nt_, nt_);
         }
         const float* s = lds + (g & 1) * STAGE_FLOATS;
         compute_stage(s, s + TILE_FLOATS, L, acc);
         if (last_k) {
-            epi.finish(t, acc);
+            epi.finish(t, t, acc);
             zero_acc(acc);
         }
         if (more) {

@@ -248,3 +248,37 @@ def test_kd_argument_order_and_kwargs(am):
         assert abs(o[key] - r[key]) <= max(REL * abs(o[key]), KD_ABS_FLOOR)
     with pytest.raises(NotImplementedError):
         am.kid_features_to_metric(dev(f1), dev(f2), kernel_type="laplace")
+
+
+# ----------------------------------------------------------------- symmetric k-NN path
+def test_knn_symmetric_path_bit_exact(am):
+    """N >= 8192, D >= 128 self-distance radii take the symmetric kernel (half the tile pairs +
+    mirrored candidates); it must match the C model bit for bit, like the general kernel."""
+    from oracle import exact
+    x = gi.randn(81, 8500, 136)                      # D % 32 != 0 exercises the tail instantiation too
+    for k in (3, 10):
+        r = am.nearest_neighbour_distances(dev(x), k).cpu().numpy()
+        assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, k).view(np.uint32))
+    dup = np.concatenate([x[:4300], x[:4300]])       # every row has an exact duplicate: zero radii, exact ties
+    r = am.nearest_neighbour_distances(dev(dup), 1).cpu().numpy()
+    assert np.array_equal(r.view(np.uint32), exact.knn_radii(dup, 1).view(np.uint32))
+
+
+def test_knn_symmetric_fallbacks_agree():
+    """General kernel, symmetric kernel, symmetric kernel with a 2-slot candidate buffer (every row overflows
+    -> exact fix-up kernel) and with a 16-entry workgroup queue (direct per-row pushes) give identical bits.
+    The knobs are process-wide environment variables, hence subprocesses."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ, AB_ROWS="9000", AB_DIM="160", AB_K="5", AB_REPS="1")
+    outs = []
+    for extra in ({"AM_KNN_SYM_MIN_ROWS": "100000000"}, {}, {"AM_KNN_SYM_CAP": "2"}, {"AM_KNN_SYM_QCAP": "16"}):
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_knn.py")], env=dict(base, **extra),
+                             capture_output=True, text=True, timeout=600)
+        m = re.search(r"radii sha1 ([0-9a-f]+)", res.stdout)
+        assert m, res.stdout + res.stderr
+        outs.append(m.group(1))
+    assert len(set(outs)) == 1, outs
