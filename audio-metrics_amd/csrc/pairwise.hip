@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <vector>
+#include <cmath>
 
 namespace am {
 
@@ -252,6 +253,7 @@ struct KnnSymEpilogue {
     uint2* wgq;                 // this workgroup's append region in global memory: (row, d2 bits)
     int* qn;                    // LDS slot counter of that region
     int qcap;
+    int ablate;                 // timing experiments only (AM_KNN_SYM_ABL): 1 = no mirrored test, 2 = no lane-local lists
     float xn[2];
     float flt[2];               // bound of this lane's own rows at workgroup start: larger values cannot matter
     bool rowok[2];
@@ -287,7 +289,7 @@ struct KnnSymEpilogue {
     }
     __device__ __forceinline__ void finish(int t, int64_t qtile, f32x16 (&acc)[2][2]) {
         const float* a = aux + (t & 1) * 2 * TB + L.wm * 64 + L.h * 4;
-        const bool mirror = (qtile != pblock);            // the diagonal tile already holds both directions
+        const bool mirror = (qtile != pblock) && !(ablate & 1);   // the diagonal tile already holds both directions
         const int64_t jbase = qtile * TB + L.wm * 64 + L.h * 4;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -308,7 +310,7 @@ struct KnnSymEpilogue {
                     tmin = fminf(tmin, fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]));
                 tmin = fmaxf(tmin, 0.f);
                 // <= : an entry EQUAL to the bound may be the (k+1)-th smallest itself
-                if (__any(tmin < best[nt][KCAP - 1] && tmin <= flt[nt])) {
+                if (!(ablate & 2) && __any(tmin < best[nt][KCAP - 1] && tmin <= flt[nt])) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const float d2 = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
@@ -333,20 +335,39 @@ struct KnnSymEpilogue {
 template <int KCAP, bool KTAIL>
 __global__ void __launch_bounds__(ENGINE_THREADS, 2)
 knn_sym_kernel(const float* __restrict__ X, int64_t N, int64_t ld, const float* __restrict__ xnorm, float* thr, int D,
-               int nchunks, int k1, float* __restrict__ partial, float* __restrict__ cand, int* __restrict__ cnt, int cap,
-               uint2* __restrict__ wgq, int qcap, int* __restrict__ wgq_count) {
+               int win_tiles, int nwin, int per_win, int k1, float* __restrict__ partial, float* __restrict__ cand,
+               int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, int qcap, int* __restrict__ wgq_count, int ablate) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
     const int64_t T = (N + TB - 1) / TB;
-    // CHUNK-MAJOR order: all row blocks do their first slice of offsets before any does its second, so every
-    // row publishes a bound over 1/nchunks of its half-range early and later slices see few mirrored survivors
-    const int chunk = (int)(blockIdx.x / T);
-    const int64_t pb = blockIdx.x % T;
-    // offsets 0 .. T/2; for even T the antipodal offset T/2 is taken by the lower-numbered block only
+    // Work item = (column-tile WINDOW, row block) over the CYCLIC HALF-RANGE pairing: block pb owns the tile
+    // pairs (pb, q) with (q - pb) mod T in 0 .. T/2.  All workgroups in flight stream the same window of Q
+    // tiles (L2 / Infinity-Cache reuse) with different row blocks.  Windows are swept in DESCENDING order: the
+    // lane-local tiles of block pb lie in the windows from the one holding pb upwards (plus, for the upper
+    // half of the blocks, a wrapped piece at the bottom), so when the window holding pb is reached - the one
+    // in which other blocks generate the mirrored candidates for pb's rows - pb has already published a
+    // bound over most of its half-range.
+    const int W = nwin - 1 - (int)(blockIdx.x / per_win);
+    const int r = (int)(blockIdx.x % per_win);
+    const int64_t q0 = (int64_t)W * win_tiles;
+    const int64_t q1 = (q0 + win_tiles < T) ? q0 + win_tiles : T;
+    int64_t pb = (q1 - 1 - r) % T;
+    if (pb < 0) pb += T;
+    // offsets 0 .. T/2; for even T the antipodal offset belongs to the lower-numbered block only
     int64_t noff = T / 2 + 1;
     if ((T % 2) == 0 && pb >= T / 2) noff = T / 2;
-    const int64_t o0 = noff * chunk / nchunks;
-    const int ntiles = (int)(noff * (chunk + 1) / nchunks - o0);
+    // tiles q of the window with (q - pb) mod T < noff form one contiguous piece (window << T/2)
+    int64_t qa = pb > q0 ? pb : q0, qb = (pb + noff < q1) ? pb + noff : q1;          // q >= pb
+    if (qa >= qb) {                                                                   // wrapped: q < pb
+        qa = q0;
+        qb = (pb + noff - T < q1) ? pb + noff - T : q1;
+    }
+    const int ntiles = qb > qa ? (int)(qb - qa) : 0;
+    if (ntiles == 0) {                                 // nothing of this window belongs to this block
+        if (L.tid == 0) wgq_count[blockIdx.x] = 0;
+        return;
+    }
+    const int chunk = W;                               // partial-list slot
 
     KnnSymEpilogue<KCAP> epi(L);
     epi.qnorm = xnorm;
@@ -360,6 +381,7 @@ knn_sym_kernel(const float* __restrict__ X, int64_t N, int64_t ld, const float* 
     epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
     epi.qn = reinterpret_cast<int*>(lds + ENGINE_LDS_FLOATS + 4 * TB);
     epi.qcap = qcap;
+    epi.ablate = ablate;
     if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -370,12 +392,7 @@ knn_sym_kernel(const float* __restrict__ X, int64_t N, int64_t ld, const float* 
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = INFINITY;
     }
-    if (ntiles > 0) {
-        int64_t start = pb + o0;
-        if (start >= T) start -= T;
-        dense_pipeline_early<EV_DEFAULT, KTAIL>(X, N, ld, CyclicTiles{start, T}, X, N, ld, pb * TB, ntiles, D, lds, L, epi);
-    }
-    __syncthreads();                                  // ntiles == 0: still orders the counter reset
+    dense_pipeline_early<EV_DEFAULT, KTAIL>(X, N, ld, LinearTiles{qa}, X, N, ld, pb * TB, ntiles, D, lds, L, epi);
     float* mg = lds;                                   // [128][4][KCAP]
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -394,13 +411,22 @@ knn_sym_kernel(const float* __restrict__ X, int64_t N, int64_t ld, const float* 
             for (int s = 0; s < KCAP; ++s) m[s] = src[s];
             for (int s = KCAP; s < 4 * KCAP; ++s) list_insert<KCAP>(m, src[s]);
             float* out = partial + ((int64_t)chunk * N + i) * KCAP;
+            // write-through (sc1) stores: workgroups on OTHER XCDs read these lists below while this kernel is
+            // still running, and a plain store would sit dirty in this XCD's L2 (per-XCD L2s are not coherent)
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) __hip_atomic_store(out + s, m[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // Publish a new upper bound for the row: the (k+1)-th smallest over this window AND the lists the
+            // higher windows have already written (distinct columns, so their union is a set of true entries;
+            // a slot that is still +inf or stale only makes the bound looser, never wrong).
+            for (int w2 = W + 1; w2 < nwin; ++w2) {
+                const float* src2 = partial + ((int64_t)w2 * N + i) * KCAP;
+                for (int s = 0; s < KCAP; ++s)
+                    list_insert<KCAP>(m, __hip_atomic_load(src2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
             float kth = m[0];
 #pragma unroll
-            for (int s = 0; s < KCAP; ++s) {
-                out[s] = m[s];
+            for (int s = 1; s < KCAP; ++s)
                 if (s == k1 - 1) kth = m[s];
-            }
-            // a (k+1)-th smallest over a subset of the columns bounds the final one from above: publish it
             atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(kth));
         }
     }
@@ -446,8 +472,9 @@ __global__ void knn_sym_merge_kernel(const float* __restrict__ partial, int64_t 
     radii[i] = sqrt_rn(r2);
 }
 
-// Exact recomputation of single rows (candidate-buffer overflow): one workgroup per row, every thread
-// walks columns j = tid, tid+256, ... with the engine's fmaf order, keeps a sorted list, lists merged in LDS.
+// Exact recomputation of single rows (candidate-buffer overflow): one workgroup per row; every thread walks
+// columns j = tid, tid+256, ... with the engine's fmaf order (two columns at a time for ILP, float4 loads),
+// keeps a sorted list, and the 256 lists are merged pairwise through LDS.
 template <int KCAP>
 __global__ void __launch_bounds__(256) knn_fixup_kernel(const float* __restrict__ X, int64_t N, int64_t ld,
                                                         const float* __restrict__ xnorm, int D, int k1,
@@ -457,6 +484,23 @@ __global__ void __launch_bounds__(256) knn_fixup_kernel(const float* __restrict_
     __shared__ float lists[256 * KCAP];
     const int n_ov = *ov_count;
     const int dp = (D + 31) / 32 * 32;
+    auto dot = [&](const float* __restrict__ ya, const float* __restrict__ yb, float& da, float& db) {
+        float a = 0.f, b = 0.f;
+        for (int c = 0; c < dp; c += 8) {
+            const f32x4 a0 = load_k4(ya, c, D), a1 = load_k4(ya, c + 4, D);
+            const f32x4 b0 = load_k4(yb, c, D), b1 = load_k4(yb, c + 4, D);
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow + c), x1 = *reinterpret_cast<const f32x4*>(xrow + c + 4);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {                          // index order 8c+s, 8c+4+s
+                a = fmaf(a0[s2], x0[s2], a);
+                b = fmaf(b0[s2], x0[s2], b);
+                a = fmaf(a1[s2], x1[s2], a);
+                b = fmaf(b1[s2], x1[s2], b);
+            }
+        }
+        da = a;
+        db = b;
+    };
     for (int ov = blockIdx.x; ov < n_ov; ov += gridDim.x) {
         const int64_t i = ov_list[ov];
         for (int k = threadIdx.x; k < dp; k += 256) xrow[k] = k < D ? X[i * ld + k] : 0.f;
@@ -465,25 +509,30 @@ __global__ void __launch_bounds__(256) knn_fixup_kernel(const float* __restrict_
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) m[s] = INFINITY;
         const float xi = xnorm[i];
-        for (int64_t j = threadIdx.x; j < N; j += 256) {
-            const float* y = X + j * ld;
-            float acc = 0.f;
-            for (int c = 0; c < dp; c += 8) {
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    const int ka = c + s2, kb = c + 4 + s2;
-                    acc = fmaf(ka < D ? y[ka] : 0.f, xrow[ka], acc);
-                    acc = fmaf(kb < D ? y[kb] : 0.f, xrow[kb], acc);
-                }
+        for (int64_t j = threadIdx.x; j < N; j += 512) {
+            const int64_t j2 = j + 256;
+            float da, db;
+            dot(X + j * ld, j2 < N ? X + j2 * ld : nullptr, da, db);
+            const float d2a = fmaxf(fmaf(-2.f, da, xi + xnorm[j]), 0.f);
+            if (d2a < m[KCAP - 1]) list_insert<KCAP>(m, d2a);
+            if (j2 < N) {
+                const float d2b = fmaxf(fmaf(-2.f, db, xi + xnorm[j2]), 0.f);
+                if (d2b < m[KCAP - 1]) list_insert<KCAP>(m, d2b);
             }
-            const float d2 = fmaxf(fmaf(-2.f, acc, xi + xnorm[j]), 0.f);
-            if (d2 < m[KCAP - 1]) list_insert<KCAP>(m, d2);
         }
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) lists[threadIdx.x * KCAP + s] = m[s];
         __syncthreads();
+        for (int stride = 128; stride >= 1; stride >>= 1) {           // pairwise merge of the sorted lists
+            if ((int)threadIdx.x < stride) {
+                const float* other = lists + (threadIdx.x + stride) * KCAP;
+                for (int s = 0; s < KCAP; ++s) list_insert<KCAP>(m, other[s]);
+#pragma unroll
+                for (int s = 0; s < KCAP; ++s) lists[threadIdx.x * KCAP + s] = m[s];
+            }
+            __syncthreads();
+        }
         if (threadIdx.x == 0) {
-            for (int s = KCAP; s < 256 * KCAP; ++s) list_insert<KCAP>(m, lists[s]);
             float r2 = m[0];
 #pragma unroll
             for (int s = 1; s < KCAP; ++s)
@@ -749,15 +798,21 @@ static int launch_knn(const float* X, int64_t N, int64_t ldx, const float* xn, c
 
 // ---- symmetric path -------------------------------------------------------------------------------
 template <int KCAP>
-static int launch_knn_sym(const float* X, int64_t N, int64_t ld, const float* xn, float* thr, int D, int k1, int nchunks,
-                          float* partial, float* cand, int* cnt, int cap, uint2* wgq, int qcap, int* wgq_count,
-                          int* ov_list, int* ov_count, float* out_r, hipStream_t st) {
-    const unsigned nwg = (unsigned)(ceil_div(N, TB) * nchunks);
+static int launch_knn_sym(const float* X, int64_t N, int64_t ld, const float* xn, float* thr, int D, int k1, int win_tiles,
+                          int nwin, int per_win, float* partial, float* cand, int* cnt, int cap, uint2* wgq, int qcap,
+                          int* wgq_count, int* ov_list, int* ov_count, float* out_r, hipStream_t st) {
+    const unsigned nwg = (unsigned)nwin * (unsigned)per_win;
+    // slots of windows that do not touch a row stay +inf
+    const int64_t nlist = (int64_t)nwin * N * KCAP;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)ceil_div(nlist, 256)), dim3(256), 0, st,
+                       reinterpret_cast<unsigned*>(partial), nlist, 0x7f800000u);
+    AM_LAUNCH_CHECK();
     auto launch = [&](auto kernel) -> int {
         AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)PAIRWISE_LDS_BYTES + 16));
         hipLaunchKernelGGL(kernel, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st,
-                           X, N, ld, xn, thr, D, nchunks, k1, partial, cand, cnt, cap, wgq, qcap, wgq_count);
+                           X, N, ld, xn, thr, D, win_tiles, nwin, per_win, k1, partial, cand, cnt, cap, wgq, qcap, wgq_count,
+                           env_int("AM_KNN_SYM_ABL", 0));
         AM_LAUNCH_CHECK();
         return AM_OK;
     };
@@ -765,7 +820,7 @@ static int launch_knn_sym(const float* X, int64_t N, int64_t ld, const float* xn
     if (rc != AM_OK) return rc;
     hipLaunchKernelGGL(knn_sym_scatter_kernel, dim3(nwg), dim3(256), 0, st, wgq, qcap, wgq_count, cand, cnt, cap);
     AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_sym_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, partial, N, nchunks, k1,
+    hipLaunchKernelGGL(knn_sym_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, partial, N, nwin, k1,
                        cand, cnt, cap, out_r, ov_list, ov_count);
     AM_LAUNCH_CHECK();
     hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
@@ -785,13 +840,16 @@ struct KnnPlan {
     int pre_chunks, pre_stride; // sampling pre-pass (symmetric path)
     int cap;                    // candidate slots per row (symmetric path)
     int qcap;                   // entries of each workgroup's append region (symmetric path)
+    int win_tiles, nwin, per_win;   // symmetric path: column-tile windows and row blocks per window
+    int pre_windows;                // symmetric path: rows of this many top windows get a sampled bound
 };
 
 static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
     static const int sym_min = env_int("AM_KNN_SYM_MIN_ROWS", 8192);
     static const int sym_min_dim = env_int("AM_KNN_SYM_MIN_DIM", 128);
     static const int cap_env = env_int("AM_KNN_SYM_CAP", 0);
-    static const int stride = env_int("AM_KNN_SYM_STRIDE", 32);
+    static const int stride = env_int("AM_KNN_SYM_STRIDE", 16);
+    const int pre_windows = 0;
     KnnPlan p;
     p.kcap = kcap_for(k + 1);
     // the mirrored-candidate machinery costs per PAIR, the saved MFMA work scales with D: worth it for
@@ -802,26 +860,41 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
     p.pre_stride = stride;
     p.pre_chunks = 1;
     p.qcap = 0;
+    p.pre_windows = pre_windows;
     if (!p.sym) {
         p.nchunks = choose_chunks(N, M);
         return p;
     }
     const int64_t T = ceil_div(N, TB);
     const int64_t sample_tiles = ceil_div(T, stride);
-    p.pre_chunks = (int)std::min<int64_t>(sample_tiles, std::max<int64_t>(1, ceil_div(2048, T)));
-    // half as many column tiles per row block as the general kernel: aim for the same workgroup count
+    p.pre_chunks = (int)std::min<int64_t>(sample_tiles, 16);
+    // A row's half-range (T/2+1 tiles) is cut into ~`slices` windows; a workgroup publishes the (k+1)-th
+    // smallest of ITS window as the row's new bound, so windows much shorter than the pre-pass sample
+    // (N/stride columns) would publish nothing useful -> at most 16 slices.
     static const int target = env_int("AM_WG_TARGET", 8192);
-    int64_t want = ceil_div(target, T);
-    want = std::max<int64_t>(want, 4);
-    // a workgroup publishes the (k+1)-th smallest of ITS slice as the row's new bound; slices much shorter
-    // than the pre-pass sample (N/stride columns) would publish nothing useful -> at most 16 slices
     static const int max_slices = env_int("AM_KNN_SYM_MAX_SLICES", 16);
-    want = std::min<int64_t>(want, std::min<int64_t>(T / 2, max_slices));
-    p.nchunks = (int)std::max<int64_t>(want, 1);
-    // expected survivors per workgroup in the first slice (bounds from the sample only):
-    //   pairs = 128 * ntiles * 128, hit rate = (k+1) / (N / stride); keep 4x head-room
-    const double ntiles = (double)(T / 2 + 1) / p.nchunks + 1.0;
-    const double expect = 128.0 * 128.0 * ntiles * (double)(k + 1) * stride / (double)N;
+    int64_t slices = ceil_div(target, T);
+    slices = std::max<int64_t>(slices, 4);
+    slices = std::min<int64_t>(slices, std::min<int64_t>(T / 2, max_slices));
+    slices = std::max<int64_t>(slices, 1);
+    const int64_t half = T / 2 + 1;
+    p.win_tiles = (int)ceil_div(half, slices);
+    p.nwin = (int)ceil_div(T, p.win_tiles);
+    p.per_win = (int)std::min<int64_t>(T, half + p.win_tiles);   // row blocks that can own a tile of one window
+    // Which rows need a sampled bound?  A row relies on the bounds its own block published from the windows
+    // above it; those exist once the windows that are `in_flight` ahead have finished.  With ~512 resident
+    // workgroups (256 CUs x 2) about 512/per_win windows run concurrently: rows in the top in_flight+2 windows
+    // (and every row when a window cannot even fill a quarter of the GPU) get the sampled bound.  This is a
+    // PERFORMANCE heuristic only: a row that meets a mirrored test with no bound yet floods its candidate
+    // buffer, overflows, and is recomputed exactly by knn_fixup_kernel.
+    static const int pre_env = env_int("AM_KNN_SYM_PRE_WINDOWS", 0);
+    if (pre_env > 0) p.pre_windows = pre_env;
+    else if (p.per_win < 256) p.pre_windows = p.nwin;
+    else p.pre_windows = std::min<int>(p.nwin, (int)ceil_div(512, p.per_win) + 2);
+    p.nchunks = p.nwin;                               // partial-list slots
+    // expected survivors per workgroup when only the sample bound is known:
+    //   pairs = 128 * win_tiles * 128, hit rate = (k+1) / (N / stride); keep 4x head-room
+    const double expect = 128.0 * 128.0 * p.win_tiles * (double)(k + 1) * stride / (double)N;
     static const int qcap_env = env_int("AM_KNN_SYM_QCAP", 0);
     p.qcap = qcap_env > 0 ? qcap_env : (int)std::min(8192.0, std::max(256.0, 4.0 * expect));
     return p;
@@ -844,7 +917,7 @@ static size_t carve_knn(Carver& c, int64_t N, int64_t M, const KnnPlan& p, KnnBu
         b.cnt = c.take<int>(N + 1);               // [N] = overflow counter
         b.ov_list = c.take<int>(N);
         b.ov_count = b.cnt ? b.cnt + N : nullptr;
-        const size_t nwg = (size_t)ceil_div(N, TB) * p.nchunks;
+        const size_t nwg = (size_t)p.nwin * p.per_win;
         b.wgq = c.take<uint2>(nwg * p.qcap);
         b.wgq_count = c.take<int>(nwg);
     } else {
@@ -871,18 +944,26 @@ static int run_knn(const float* X, int64_t N, int64_t ldx, const float* Y, int64
     if (!p.sym)
         return launch_knn<KCAP>(X, N, ldx, b.xn, Y, M, ldy, self ? b.xn : b.yn, D, k1, p.nchunks, 1, false, b.partial, out_r,
                                 st);
-    // 1) upper bounds thr[i] >= final r2[i] from every pre_stride-th column tile (squared domain)
-    if ((rc = launch_knn<KCAP>(X, N, ldx, b.xn, X, N, ldx, b.xn, D, k1, p.pre_chunks, p.pre_stride, true, b.partial, b.thr,
-                               st)) != AM_OK)
+    // 1) upper bounds thr[i] >= final r2[i] (squared domain).  Rows below the top windows need none: by the
+    //    time their own window is reached they have published bounds over whole windows above them.  The rows
+    //    of the top pre_windows windows (whose half-ranges wrap around to the windows processed last) get the
+    //    (k+1)-th smallest over every pre_stride-th column tile from the general kernel.
+    const int64_t row_lo = std::max<int64_t>(0, (int64_t)(p.nwin - p.pre_windows) * p.win_tiles * TB);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st,
+                       reinterpret_cast<unsigned*>(b.thr), N, 0x7f800000u);
+    AM_LAUNCH_CHECK();
+    if (row_lo < N &&
+        (rc = launch_knn<KCAP>(X + row_lo * ldx, N - row_lo, ldx, b.xn + row_lo, X, N, ldx, b.xn, D, k1, p.pre_chunks,
+                               p.pre_stride, true, b.partial, b.thr + row_lo, st)) != AM_OK)
         return rc;
     AM_HIP_TRY(hipMemsetAsync(b.cnt, 0, (size_t)(N + 1) * sizeof(int), st));
     // 2) half of the tile pairs + mirrored candidates, 3) merge, 4) exact fix-up of overflowed rows
-    rc = launch_knn_sym<KCAP>(X, N, ldx, b.xn, b.thr, D, k1, p.nchunks, b.partial, b.cand, b.cnt, p.cap, b.wgq, p.qcap,
-                              b.wgq_count, b.ov_list, b.ov_count, out_r, st);
+    rc = launch_knn_sym<KCAP>(X, N, ldx, b.xn, b.thr, D, k1, p.win_tiles, p.nwin, p.per_win, b.partial, b.cand, b.cnt, p.cap,
+                              b.wgq, p.qcap, b.wgq_count, b.ov_list, b.ov_count, out_r, st);
     static const int debug = env_int("AM_KNN_DEBUG", 0);
     if (rc == AM_OK && debug) {                      // development aid: candidate statistics (synchronises!)
         std::vector<int> cnt(N + 1);
-        const size_t nwg = (size_t)ceil_div(N, TB) * p.nchunks;
+        const size_t nwg = (size_t)p.nwin * p.per_win;
         std::vector<int> wq(nwg);
         hipStreamSynchronize(st);
         hipMemcpy(cnt.data(), b.cnt, (N + 1) * sizeof(int), hipMemcpyDeviceToHost);
@@ -890,7 +971,47 @@ static int run_knn(const float* X, int64_t N, int64_t ldx, const float* Y, int64
         long long tot = 0, mx = 0, wtot = 0, wmx = 0, wfull = 0;
         for (int64_t i = 0; i < N; ++i) { tot += cnt[i]; mx = std::max<long long>(mx, cnt[i]); }
         for (size_t i = 0; i < nwg; ++i) { wtot += wq[i]; wmx = std::max<long long>(wmx, wq[i]); wfull += wq[i] >= p.qcap; }
-        fprintf(stderr, "[am knn sym] N=%lld k1=%d nchunks=%d stride=%d cap=%d qcap=%d | candidates/row mean %.1f max %lld | "
+        {
+            const int64_t rows_per_win = (int64_t)p.win_tiles * TB;
+            fprintf(stderr, "[am knn sym] mean candidates per row, by window of the row:");
+            for (int w = 0; w < p.nwin; ++w) {
+                long long t2 = 0, n2 = 0;
+                for (int64_t i = w * rows_per_win; i < std::min<int64_t>(N, (w + 1) * rows_per_win); ++i) { t2 += cnt[i]; ++n2; }
+                fprintf(stderr, " %.0f", n2 ? (double)t2 / n2 : 0.0);
+            }
+            fprintf(stderr, "\n");
+            std::vector<float> th(N), rr(N);
+            hipMemcpy(th.data(), b.thr, N * sizeof(float), hipMemcpyDeviceToHost);
+            hipMemcpy(rr.data(), out_r, N * sizeof(float), hipMemcpyDeviceToHost);
+            {
+                std::vector<float> pl((size_t)p.nwin * N * p.kcap);
+                hipMemcpy(pl.data(), b.partial, pl.size() * sizeof(float), hipMemcpyDeviceToHost);
+                double acc2 = 0; long long finite = 0;
+                for (int64_t i = 0; i < N; ++i) {
+                    std::vector<float> all;
+                    for (int w = 0; w < p.nwin; ++w)
+                        for (int s2 = 0; s2 < p.kcap; ++s2) {
+                            const float v = pl[((size_t)w * N + i) * p.kcap + s2];
+                            if (std::isfinite(v)) { all.push_back(v); ++finite; }
+                        }
+                    std::sort(all.begin(), all.end());
+                    const float cum = (int)all.size() >= k1 ? all[k1 - 1] : INFINITY;
+                    acc2 += (th[i] - cum) / cum;
+                }
+                fprintf(stderr, "[am knn sym] lane-local lists: %.1f finite entries per row; mean (final bound - cumulative)/cumulative x1e4 = %.2f\n",
+                        (double)finite / N, 1e4 * acc2 / N);
+            }
+            fprintf(stderr, "[am knn sym] mean (final bound - r2)/r2 by window, x1e4:");
+            for (int w = 0; w < p.nwin; ++w) {
+                double t2 = 0; long long n2 = 0;
+                for (int64_t i = w * rows_per_win; i < std::min<int64_t>(N, (w + 1) * rows_per_win); ++i) {
+                    const double r2 = (double)rr[i] * rr[i];
+                    t2 += (th[i] - r2) / r2; ++n2; }
+                fprintf(stderr, " %.1f", n2 ? 1e4 * t2 / n2 : 0.0);
+            }
+            fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "[am knn sym] N=%lld k1=%d windows=%d stride=%d cap=%d qcap=%d | candidates/row mean %.1f max %lld | "
                         "overflow rows %d | wg queue mean %.1f max %lld full %lld of %zu\n",
                 (long long)N, k1, p.nchunks, p.pre_stride, p.cap, p.qcap, (double)tot / N, mx, cnt[N], (double)wtot / nwg, wmx,
                 wfull, nwg);
