@@ -17,6 +17,7 @@
 // exit immediately, and the host only polls the state every few iterations.
 #include "am_common.h"
 #include <math.h>
+#include <algorithm>
 
 namespace am {
 
@@ -134,7 +135,8 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return s;
 }
 
-// norm = sqrt(sum block_sums); Y = A/norm; Z = I; state init
+// norm = sqrt(sum block_sums); Y = A/norm; Z = I; state init.  Every workgroup recomputes the (tiny) norm sum in
+// the same fixed order, so no inter-workgroup hand-off is needed; block 0 writes the state.
 __global__ void __launch_bounds__(256) ns_init_kernel(const double* __restrict__ A, const double* __restrict__ block_sums,
                                                       int nblocks, int n, double* __restrict__ Y, double* __restrict__ Z,
                                                       NsState* __restrict__ state) {
@@ -144,11 +146,12 @@ __global__ void __launch_bounds__(256) ns_init_kernel(const double* __restrict__
     const double nrm = sqrt(block_sum(v, red));
     const bool bad = !(nrm == nrm) || isinf(nrm);
     const double inv = (nrm > 0.0 && !bad) ? 1.0 / nrm : 0.0;
-    for (int64_t i = threadIdx.x; i < (int64_t)n * n; i += blockDim.x) {
+    const int64_t total = (int64_t)n * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         Y[i] = A[i] * inv;
         Z[i] = (i / n == i % n) ? 1.0 : 0.0;
     }
-    if (threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         state->prev_trace = (nrm > 0.0 && !bad) ? -INFINITY : 0.0;
         state->resid = 0.0;
         state->norm = bad ? 0.0 : nrm;
@@ -244,7 +247,8 @@ extern "C" int am_frechet_f64(const double* mu_x, const double* cov_x, const dou
     hipLaunchKernelGGL(gemm_f64_kernel<MODE_PLAIN>, grid1, blk, 0, st, GemmJob{cov_x, cov_y, A}, none, D,
                        (const NsState*)nullptr, sums);
     AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ns_init_kernel, dim3(1), blk, 0, st, A, sums, g * g, D, Yb[0], Zb[0], state);
+    hipLaunchKernelGGL(ns_init_kernel, dim3((unsigned)std::min<int64_t>(256, ceil_div((int64_t)D * D, 1024))), blk, 0, st, A, sums,
+                       g * g, D, Yb[0], Zb[0], state);
     AM_LAUNCH_CHECK();
     int cur = 0;
     NsState host_state;

@@ -79,9 +79,14 @@ struct WorkItem {
     int ntiles;
 };
 
-__device__ __forceinline__ WorkItem work_item(int64_t q_tiles, int nchunks) {
-    const int chunk = blockIdx.x % nchunks;        // consecutive blocks (= different XCDs) take different chunks
-    const int64_t rb = blockIdx.x / nchunks;
+__device__ __forceinline__ WorkItem work_item(int64_t q_tiles, int nchunks, int order = 0) {
+    int chunk = blockIdx.x % nchunks;              // consecutive blocks (= different XCDs) take different chunks
+    int64_t rb = blockIdx.x / nchunks;
+    if (order == 1) {                              // experiment: chunk-major (all row blocks of chunk 0 first)
+        const int64_t nrb = gridDim.x / nchunks;
+        chunk = (int)(blockIdx.x / nrb);
+        rb = blockIdx.x % nrb;
+    }
     WorkItem w;
     w.prow0 = rb * TB;
     w.qtile0 = q_tiles * chunk / nchunks;
@@ -299,15 +304,18 @@ struct KnnSymEpilogue {
                 yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
                 tq[g4] = *reinterpret_cast<const f32x4*>(a + TB + mt * 32 + g4 * 8);
             }
-            float tmax = 0.f;                             // loosest bound among this lane's 16 Q rows
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) tmax = fmaxf(tmax, tq[reg >> 2][reg & 3]);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                float tmin = INFINITY;
+                // one pass: tile minimum for the lane's own row (clamp commutes with min) and, for the mirrored
+                // direction, the smallest margin u - thr[j] (u <= thr  <=>  max(u,0) <= thr since valid thr >= 0;
+                // rows past the end carry thr = -1 and |y|^2 = +inf)
+                float tmin = INFINITY, marg = INFINITY;
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg)
-                    tmin = fminf(tmin, fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]));
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float u = fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
+                    tmin = fminf(tmin, u);
+                    marg = fminf(marg, u - tq[reg >> 2][reg & 3]);
+                }
                 tmin = fmaxf(tmin, 0.f);
                 // <= : an entry EQUAL to the bound may be the (k+1)-th smallest itself
                 if (!(ablate & 2) && __any(tmin < best[nt][KCAP - 1] && tmin <= flt[nt])) {
@@ -319,7 +327,7 @@ struct KnnSymEpilogue {
                     }
                 }
                 // <= again: if a bound is exactly tight, the entry that defines it may live in the mirrored half
-                if (mirror && __any(rowok[nt] && tmin <= tmax)) {
+                if (mirror && __any(rowok[nt] && marg <= 0.f)) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const float d2 = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
@@ -348,9 +356,22 @@ knn_sym_kernel(const float* __restrict__ X, int64_t N, int64_t ld, const float* 
     // in which other blocks generate the mirrored candidates for pb's rows - pb has already published a
     // bound over most of its half-range.
     const int W = nwin - 1 - (int)(blockIdx.x / per_win);
-    const int r = (int)(blockIdx.x % per_win);
     const int64_t q0 = (int64_t)W * win_tiles;
     const int64_t q1 = (q0 + win_tiles < T) ? q0 + win_tiles : T;
+    // Within a window, the row blocks that own ALL of its tiles (equal-sized work items, which therefore walk
+    // the window's Q tiles in lockstep and share them through L2) are issued first, the partial ones (blocks
+    // inside the window and blocks whose half-range ends inside it) last.
+    int r;
+    {
+        const int e = (int)(blockIdx.x % per_win);
+        const int wlen = (int)(q1 - q0);
+        const int full_lo = wlen - 1, full_hi = (int)(T / 2);          // r in [full_lo, full_hi]: pb <= q0, pb+noff >= q1
+        const int nfull = full_hi >= full_lo ? full_hi - full_lo + 1 : 0;
+        if (e < nfull) r = full_lo + e;
+        else if (e - nfull < full_lo) r = e - nfull;
+        else r = e + 1 - full_lo + full_lo;                            // = e + 1 ... beyond the full range
+        if (e >= nfull + full_lo) r = full_hi + 1 + (e - nfull - full_lo);
+    }
     int64_t pb = (q1 - 1 - r) % T;
     if (pb < 0) pb += T;
     // offsets 0 .. T/2; for even T the antipodal offset belongs to the lower-numbered block only
@@ -617,11 +638,11 @@ prdc_cross_kernel(const float* __restrict__ R, int64_t Nr, int64_t ldr, const fl
                   const float* __restrict__ C, int64_t Nc, int64_t ldc, const float* __restrict__ cnorm,
                   const float* __restrict__ cthr, int D, int nchunks,
                   int32_t* __restrict__ col_count, unsigned* __restrict__ row_min_bits,
-                  unsigned* __restrict__ row_any) {
+                  unsigned* __restrict__ row_any, int order) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
     const int64_t q_tiles = (Nc + TB - 1) / TB;
-    const WorkItem w = work_item(q_tiles, nchunks);
+    const WorkItem w = work_item(q_tiles, nchunks, order);
 
     CrossEpilogue epi(L);
     epi.qnorm = cnorm;
@@ -1092,7 +1113,7 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
         AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)PAIRWISE_LDS_BYTES));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES, st, R, Nr, ldr, rn, rt,
-                           C, Nc, ldc, cn, ct, D, nchunks, out_col_count, rmin, rany);
+                           C, Nc, ldc, cn, ct, D, nchunks, out_col_count, rmin, rany, env_int("AM_CROSS_ORDER", 0));
         AM_LAUNCH_CHECK();
         return AM_OK;
     };

@@ -58,14 +58,19 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
     }
 }
 
-// out[d] = (sum_b partial[b][d]) * scale
-__global__ void colsum_reduce_kernel(const double* __restrict__ partial, int nblocks, int D, double scale,
-                                     double* __restrict__ out) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= D) return;
+// out[d] = (sum_b partial[b][d]) * scale.  One workgroup per 64 columns; its 4 waves split the partial rows and
+// combine through LDS in a fixed order (deterministic).
+__global__ void __launch_bounds__(256) colsum_reduce_kernel(const double* __restrict__ partial, int nblocks, int D,
+                                                            double scale, double* __restrict__ out) {
+    __shared__ double red[4][64];
+    const int d = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
     double s = 0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * D + d];
-    out[d] = s * scale;
+    if (d < D)
+        for (int b = part; b < nblocks; b += 4) s += partial[(int64_t)b * D + d];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && d < D) out[d] = (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) * scale;
 }
 
 // ------------------------------------------------------------ centred scatter
@@ -239,7 +244,7 @@ struct StatsPlan {
 static StatsPlan plan_stats(int64_t N, int D) {
     StatsPlan p;
     int64_t b = ceil_div(N, 64);
-    if (b > 1024) b = 1024;
+    if (b > 512) b = 512;
     if (b < 1) b = 1;
     p.cs_rows = ceil_div(N, b);
     p.cs_blocks = (int)ceil_div(N, p.cs_rows);
@@ -274,7 +279,7 @@ static int run_colsum(const float* X, int64_t N, int D, int64_t ld, double scale
                       const StatsPlan& p, hipStream_t st) {
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.cs_blocks), dim3(256), 0, st, X, N, ld, D, p.cs_rows, partial);
     AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)ceil_div(D, 128)), dim3(128), 0, st, partial, p.cs_blocks, D,
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)ceil_div(D, 64)), dim3(256), 0, st, partial, p.cs_blocks, D,
                        scale, out);
     AM_LAUNCH_CHECK();
     return AM_OK;

@@ -136,7 +136,8 @@ def main():
         # of the tile pairs (+ a 1/32 column sample for bounds), so its ALGORITHMIC rate can exceed the MFMA peak.
         t_tiles = (n + 127) // 128
         sym = world == 1 and n >= 8192 and d >= 128
-        exec_frac_of_alg = ((t_tiles // 2 + 1) / t_tiles + 1.0 / 32) if sym else 1.0
+        # cyclic half of the tile pairs + the sampling pre-pass (1/16 of the column tiles for the rows of the top windows)
+        exec_frac_of_alg = ((t_tiles // 2 + 1) / t_tiles + 0.2 / 16) if sym else 1.0
         traffic = None
         try:                                                # PMC-derived bytes per launch, recorded from profiles/
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:

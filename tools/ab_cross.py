@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""A/B helper: time am_prdc_counts_f32 at the BASELINE size (development aid)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audio_metrics_amd import hip_ops as ops  # noqa: E402
+
+n = int(os.environ.get("AB_ROWS", "100000"))
+d = int(os.environ.get("AB_DIM", "512"))
+gen = torch.Generator(device="cuda").manual_seed(0)
+x = torch.randn(n, d, generator=gen, device="cuda")
+y = torch.randn(n, d, generator=gen, device="cuda") * 1.05 + 0.05
+rx, ry = ops.knn_radii(x, 5), ops.knn_radii(y, 5)
+ops.prdc_counts(x, y, rx, ry)
+torch.cuda.synchronize()
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    col, rany, rmin = ops.prdc_counts(x, y, rx, ry)
+    torch.cuda.synchronize()
+    ts.append(time.perf_counter() - t0)
+print(f"cross order={os.environ.get('AM_CROSS_ORDER', '0')} wg_target={os.environ.get('AM_WG_TARGET', '8192')} N={n} D={d}: "
+      f"best {min(ts) * 1e3:.2f} ms {2 * n * n * d / min(ts) / 1e12:.1f} TF  sum {int(col.sum())} {int(rany.sum())}", flush=True)
