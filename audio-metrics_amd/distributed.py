@@ -44,6 +44,15 @@ def _all_reduce(t, world, group):
     return t
 
 
+def _all_gather_into(out, local, world, group):
+    """all_gather_into_tensor where the backend has it for this device (RCCL), else the list form."""
+    try:
+        dist.all_gather_into_tensor(out, local, group=group)
+    except (RuntimeError, NotImplementedError):
+        parts = list(out.view(world, *local.shape).unbind(0))
+        dist.all_gather(parts, local.contiguous(), group=group)
+
+
 def _all_gather_rows(local, counts, world, group):
     """Concatenate row shards of unequal length (counts[r] rows from rank r)."""
     if world == 1:
@@ -53,7 +62,7 @@ def _all_gather_rows(local, counts, world, group):
     pad = torch.zeros((cmax, *width), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
     out = torch.empty((world * cmax, *width), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    _all_gather_into(out, pad, world, group)
     if all(c == cmax for c in counts):
         return out
     return torch.cat([out[r * cmax:r * cmax + counts[r]] for r in range(world)])
@@ -80,7 +89,7 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
     counts = torch.tensor([ref_local.shape[0], cand_local.shape[0]], dtype=torch.int64, device=dev)
     if world > 1:
         allc = torch.empty(world * 2, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(allc, counts, group=group)
+        _all_gather_into(allc, counts, world, group)
         allc = allc.view(world, 2).cpu().tolist()
     else:
         allc = [counts.cpu().tolist()]

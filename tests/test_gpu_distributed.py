@@ -1,0 +1,75 @@
+"""The row-sharded evaluate with the REAL HIP kernels: two processes share cuda:0 and talk over
+gloo (RCCL needs one GPU per rank, which the 1-GPU test box does not have).  Covers what the
+CPU gloo test cannot: shard-vs-gathered-columns k-NN, cross counts on row shards, the collectives
+on device tensors, unequal shard sizes."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_ref, n_cand, d, k, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from audio_metrics_amd.distributed import evaluate_sharded, shard_bounds
+    ref, cand = gi.pair("randn", 95, n_ref, n_cand, d)
+    rl, rh = shard_bounds(n_ref, world, rank)
+    cl, ch = shard_bounds(n_cand, world, rank)
+    dev = torch.device("cuda:0")
+    res = evaluate_sharded(torch.as_tensor(ref[rl:rh]).to(dev), torch.as_tensor(cand[cl:ch]).to(dev), nearest_k=k,
+                           kid_subsets=8, kid_subset_size=300)
+    out_q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_ref,n_cand", [(2600, 2600), (2501, 2333)])
+def test_sharded_evaluate_with_hip_kernels(n_ref, n_cand):
+    import audio_metrics_amd as am
+    from audio_metrics_amd.distributed import evaluate_sharded
+    d, k, world = 96, 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_ref, n_cand, d, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, cand = gi.pair("randn", 95, n_ref, n_cand, d)
+    dev = torch.device("cuda:0")
+    single = evaluate_sharded(torch.as_tensor(ref).to(dev), torch.as_tensor(cand).to(dev), nearest_k=k,
+                              kid_subsets=8, kid_subset_size=300)
+    assert results[0] == results[1]
+    for key, w in single.items():
+        if key in ("precision", "recall", "density", "coverage"):
+            assert results[0][key] == w, key              # integer counts: identical whatever the sharding
+        else:
+            assert abs(results[0][key] - w) <= max(1e-9 * abs(w), 1e-12), (key, results[0][key], w)
+    # and the single-process sharded path equals the object API
+    a, b = am.AudioMetricsData(True), am.AudioMetricsData(True)
+    a.add(torch.as_tensor(cand).to(dev))
+    b.add(torch.as_tensor(ref).to(dev))
+    assert am.prdc(b, a, k) == {key: single[key] for key in ("precision", "recall", "density", "coverage")}
+    assert abs(am.frechet_distance(a, b) - single["fad"]) <= 1e-9 * abs(single["fad"])
