@@ -344,7 +344,8 @@ template <int KCAP, bool KTAIL>
 __global__ void __launch_bounds__(ENGINE_THREADS, 2)
 knn_sym_kernel(const float* __restrict__ X, int64_t N, int64_t ld, const float* __restrict__ xnorm, float* thr, int D,
                int win_tiles, int nwin, int per_win, int k1, float* __restrict__ partial, float* __restrict__ cand,
-               int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, int qcap, int* __restrict__ wgq_count, int ablate) {
+               int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, int qcap, int* __restrict__ wgq_count, int ablate,
+               int part, int nparts) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
     const int64_t T = (N + TB - 1) / TB;
@@ -384,7 +385,8 @@ knn_sym_kernel(const float* __restrict__ X, int64_t N, int64_t ld, const float* 
         qb = (pb + noff - T < q1) ? pb + noff - T : q1;
     }
     const int ntiles = qb > qa ? (int)(qb - qa) : 0;
-    if (ntiles == 0) {                                 // nothing of this window belongs to this block
+    // multi-GPU: rank `part` of `nparts` owns the row blocks pb == part (mod nparts); see am_knn_sym_part_f32
+    if (ntiles == 0 || (int)(pb % nparts) != part) {   // nothing of this window belongs to this block
         if (L.tid == 0) wgq_count[blockIdx.x] = 0;
         return;
     }
@@ -469,12 +471,14 @@ __global__ void __launch_bounds__(256) knn_sym_scatter_kernel(const uint2* __res
 template <int KCAP>
 __global__ void knn_sym_merge_kernel(const float* __restrict__ partial, int64_t N, int nchunks, int k1,
                                      const float* __restrict__ cand, const int* __restrict__ cnt, int cap,
-                                     float* __restrict__ radii, int* __restrict__ ov_list, int* __restrict__ ov_count) {
+                                     float* __restrict__ radii, int* __restrict__ ov_list, int* __restrict__ ov_count,
+                                     float* __restrict__ out_lists) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int c = cnt[i];
     if (c > cap) {                                     // candidate buffer overflowed: exact recomputation later
-        ov_list[atomicAdd(ov_count, 1)] = (int)i;
+        if (out_lists != nullptr) out_lists[i * KCAP] = NAN;         // partitioned form: flag the row for every rank
+        else ov_list[atomicAdd(ov_count, 1)] = (int)i;
         return;
     }
     float m[KCAP];
@@ -486,6 +490,38 @@ __global__ void knn_sym_merge_kernel(const float* __restrict__ partial, int64_t 
     }
     const float* cs = cand + i * (int64_t)cap;
     for (int s = 0; s < c; ++s) list_insert<KCAP>(m, cs[s]);
+    if (out_lists != nullptr) {                        // partitioned form: this rank's KCAP smallest entries of the row
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) out_lists[i * KCAP + s] = m[s];
+        return;
+    }
+    float r2 = m[0];
+#pragma unroll
+    for (int s = 1; s < KCAP; ++s)
+        if (s == k1 - 1) r2 = m[s];
+    radii[i] = sqrt_rn(r2);
+}
+
+// Partitioned form, last step: merge the per-rank lists of every row; a NaN marker from any rank sends the row
+// to the exact fix-up kernel.
+template <int KCAP>
+__global__ void knn_lists_finish_kernel(const float* __restrict__ lists, int nparts, int64_t N, int k1,
+                                        float* __restrict__ radii, int* __restrict__ ov_list, int* __restrict__ ov_count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float m[KCAP];
+#pragma unroll
+    for (int s = 0; s < KCAP; ++s) m[s] = INFINITY;
+    bool flagged = false;
+    for (int p = 0; p < nparts; ++p) {
+        const float* src = lists + ((int64_t)p * N + i) * KCAP;
+        if (src[0] != src[0]) { flagged = true; break; }
+        for (int s = 0; s < KCAP; ++s) list_insert<KCAP>(m, src[s]);
+    }
+    if (flagged) {
+        ov_list[atomicAdd(ov_count, 1)] = (int)i;
+        return;
+    }
     float r2 = m[0];
 #pragma unroll
     for (int s = 1; s < KCAP; ++s)
@@ -821,7 +857,8 @@ static int launch_knn(const float* X, int64_t N, int64_t ldx, const float* xn, c
 template <int KCAP>
 static int launch_knn_sym(const float* X, int64_t N, int64_t ld, const float* xn, float* thr, int D, int k1, int win_tiles,
                           int nwin, int per_win, float* partial, float* cand, int* cnt, int cap, uint2* wgq, int qcap,
-                          int* wgq_count, int* ov_list, int* ov_count, float* out_r, hipStream_t st) {
+                          int* wgq_count, int* ov_list, int* ov_count, float* out_r, hipStream_t st, int part = 0,
+                          int nparts = 1, float* out_lists = nullptr) {
     const unsigned nwg = (unsigned)nwin * (unsigned)per_win;
     // slots of windows that do not touch a row stay +inf
     const int64_t nlist = (int64_t)nwin * N * KCAP;
@@ -833,7 +870,7 @@ static int launch_knn_sym(const float* X, int64_t N, int64_t ld, const float* xn
                                        (int)PAIRWISE_LDS_BYTES + 16));
         hipLaunchKernelGGL(kernel, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st,
                            X, N, ld, xn, thr, D, win_tiles, nwin, per_win, k1, partial, cand, cnt, cap, wgq, qcap, wgq_count,
-                           env_int("AM_KNN_SYM_ABL", 0));
+                           env_int("AM_KNN_SYM_ABL", 0), part, nparts);
         AM_LAUNCH_CHECK();
         return AM_OK;
     };
@@ -842,8 +879,9 @@ static int launch_knn_sym(const float* X, int64_t N, int64_t ld, const float* xn
     hipLaunchKernelGGL(knn_sym_scatter_kernel, dim3(nwg), dim3(256), 0, st, wgq, qcap, wgq_count, cand, cnt, cap);
     AM_LAUNCH_CHECK();
     hipLaunchKernelGGL(knn_sym_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, partial, N, nwin, k1,
-                       cand, cnt, cap, out_r, ov_list, ov_count);
+                       cand, cnt, cap, out_r, ov_list, ov_count, out_lists);
     AM_LAUNCH_CHECK();
+    if (out_lists != nullptr) return AM_OK;            // partitioned form: fix-up happens after the lists are merged
     hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
                        xn, D, k1, ov_list, ov_count, out_r);
     AM_LAUNCH_CHECK();
@@ -1070,6 +1108,114 @@ extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const fl
         case 11: return run_knn<11>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
         case 16: return run_knn<16>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
         default: return run_knn<32>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
+    }
+}
+
+// ---- partitioned symmetric k-NN (multi-GPU; every rank holds the full set) --------------------------
+extern "C" int am_knn_sym_eligible(int64_t N, int D, int k) {
+    if (N < 1 || D < 1 || k < 1 || k > AM_MAX_K) return 0;
+    return plan_knn(N, N, D, k, true).sym ? 1 : 0;
+}
+
+extern "C" int am_knn_list_width(int k) { return (k < 1 || k > AM_MAX_K) ? 0 : kcap_for(k + 1); }
+
+extern "C" size_t am_knn_part_workspace_bytes(int64_t N, int k) {
+    if (N < 1 || k < 1 || k > AM_MAX_K) return 0;
+    const KnnPlan p = plan_knn(N, N, 1 << 20, k, true);
+    Carver c(nullptr, 0);
+    KnnBuffers b;
+    return carve_knn(c, N, N, p, b);
+}
+
+extern "C" int am_knn_bounds_f32(const float* X, int64_t N, int64_t ld, int D, int k, int64_t row0, int64_t nrows,
+                                 float* out_bound_sq, void* ws, size_t ws_bytes, am_stream_t stream) {
+    int rc;
+    if ((rc = check_matrix(X, N, ld, D, "X")) != AM_OK) return rc;
+    AM_REQUIRE(out_bound_sq != nullptr, AM_ERR_BAD_ARG, "out_bound_sq is null");
+    AM_REQUIRE(k >= 1 && k <= AM_MAX_K, AM_ERR_UNSUPPORTED_K, "nearest_k %d outside [1, %d]", k, AM_MAX_K);
+    AM_REQUIRE(row0 >= 0 && nrows >= 1 && row0 + nrows <= N, AM_ERR_BAD_SHAPE, "row range [%lld, +%lld) outside %lld rows",
+               (long long)row0, (long long)nrows, (long long)N);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const KnnPlan p = plan_knn(N, N, D, k, true);
+    AM_REQUIRE(p.sym, AM_ERR_BAD_SHAPE, "the symmetric k-NN path does not apply to %lld x %d (see am_knn_sym_eligible)",
+               (long long)N, D);
+    Carver c(ws, ws_bytes);
+    float* xn = c.take<float>(N);
+    float* partial = c.take<float>((size_t)p.pre_chunks * nrows * p.kcap);
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    if ((rc = launch_norms(X, N, ld, D, xn, st)) != AM_OK) return rc;
+    const float* Xr = X + row0 * ld;
+    switch (p.kcap) {
+        case 6:  return launch_knn<6>(Xr, nrows, ld, xn + row0, X, N, ld, xn, D, k + 1, p.pre_chunks, p.pre_stride, true, partial, out_bound_sq, st);
+        case 11: return launch_knn<11>(Xr, nrows, ld, xn + row0, X, N, ld, xn, D, k + 1, p.pre_chunks, p.pre_stride, true, partial, out_bound_sq, st);
+        case 16: return launch_knn<16>(Xr, nrows, ld, xn + row0, X, N, ld, xn, D, k + 1, p.pre_chunks, p.pre_stride, true, partial, out_bound_sq, st);
+        default: return launch_knn<32>(Xr, nrows, ld, xn + row0, X, N, ld, xn, D, k + 1, p.pre_chunks, p.pre_stride, true, partial, out_bound_sq, st);
+    }
+}
+
+template <int KCAP>
+static int run_knn_part(const float* X, int64_t N, int64_t ld, int D, int k1, int part, int nparts, float* bounds,
+                        float* out_lists, const KnnPlan& p, const KnnBuffers& b, hipStream_t st) {
+    AM_HIP_TRY(hipMemsetAsync(b.cnt, 0, (size_t)(N + 1) * sizeof(int), st));
+    return launch_knn_sym<KCAP>(X, N, ld, b.xn, bounds, D, k1, p.win_tiles, p.nwin, p.per_win, b.partial, b.cand, b.cnt, p.cap,
+                                b.wgq, p.qcap, b.wgq_count, b.ov_list, b.ov_count, nullptr, st, part, nparts, out_lists);
+}
+
+extern "C" int am_knn_sym_part_f32(const float* X, int64_t N, int64_t ld, int D, int k, int part, int nparts,
+                                   float* bounds_sq, float* out_lists, void* ws, size_t ws_bytes, am_stream_t stream) {
+    int rc;
+    if ((rc = check_matrix(X, N, ld, D, "X")) != AM_OK) return rc;
+    AM_REQUIRE(bounds_sq && out_lists, AM_ERR_BAD_ARG, "null pointer");
+    AM_REQUIRE(k >= 1 && k <= AM_MAX_K, AM_ERR_UNSUPPORTED_K, "nearest_k %d outside [1, %d]", k, AM_MAX_K);
+    AM_REQUIRE((int64_t)k + 1 <= N, AM_ERR_BAD_SHAPE, "k + 1 exceeds the number of rows");
+    AM_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, AM_ERR_BAD_ARG, "part %d of %d", part, nparts);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const KnnPlan p = plan_knn(N, N, D, k, true);
+    AM_REQUIRE(p.sym, AM_ERR_BAD_SHAPE, "the symmetric k-NN path does not apply to %lld x %d (see am_knn_sym_eligible)",
+               (long long)N, D);
+    Carver c(ws, ws_bytes);
+    KnnBuffers b;
+    carve_knn(c, N, N, p, b);
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    if ((rc = launch_norms(X, N, ld, D, b.xn, st)) != AM_OK) return rc;
+    switch (p.kcap) {
+        case 6:  return run_knn_part<6>(X, N, ld, D, k + 1, part, nparts, bounds_sq, out_lists, p, b, st);
+        case 11: return run_knn_part<11>(X, N, ld, D, k + 1, part, nparts, bounds_sq, out_lists, p, b, st);
+        case 16: return run_knn_part<16>(X, N, ld, D, k + 1, part, nparts, bounds_sq, out_lists, p, b, st);
+        default: return run_knn_part<32>(X, N, ld, D, k + 1, part, nparts, bounds_sq, out_lists, p, b, st);
+    }
+}
+
+template <int KCAP>
+static int run_lists_finish(const float* lists, int nparts, const float* X, int64_t N, int64_t ld, int D, int k1, float* xn,
+                            int* ov_list, int* ov_count, float* out_r, hipStream_t st) {
+    hipLaunchKernelGGL(knn_lists_finish_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, lists, nparts, N, k1,
+                       out_r, ov_list, ov_count);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
+                       xn, D, k1, ov_list, ov_count, out_r);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+extern "C" int am_knn_lists_finish_f32(const float* lists, int nparts, const float* X, int64_t N, int64_t ld, int D, int k,
+                                       float* out_r, void* ws, size_t ws_bytes, am_stream_t stream) {
+    int rc;
+    if ((rc = check_matrix(X, N, ld, D, "X")) != AM_OK) return rc;
+    AM_REQUIRE(lists && out_r, AM_ERR_BAD_ARG, "null pointer");
+    AM_REQUIRE(k >= 1 && k <= AM_MAX_K && nparts >= 1, AM_ERR_BAD_ARG, "k=%d nparts=%d", k, nparts);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carver c(ws, ws_bytes);
+    float* xn = c.take<float>(N);
+    int* ov = c.take<int>(N + 1);
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    if ((rc = launch_norms(X, N, ld, D, xn, st)) != AM_OK) return rc;
+    AM_HIP_TRY(hipMemsetAsync(ov + N, 0, sizeof(int), st));
+    switch (kcap_for(k + 1)) {
+        case 6:  return run_lists_finish<6>(lists, nparts, X, N, ld, D, k + 1, xn, ov, ov + N, out_r, st);
+        case 11: return run_lists_finish<11>(lists, nparts, X, N, ld, D, k + 1, xn, ov, ov + N, out_r, st);
+        case 16: return run_lists_finish<16>(lists, nparts, X, N, ld, D, k + 1, xn, ov, ov + N, out_r, st);
+        default: return run_lists_finish<32>(lists, nparts, X, N, ld, D, k + 1, xn, ov, ov + N, out_r, st);
     }
 }
 

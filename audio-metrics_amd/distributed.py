@@ -78,6 +78,25 @@ def global_stats(local, n_total, ops, world, group):
     return mean, sc / float(n_total - 1)
 
 
+def sharded_radii(local, full, counts, k, ops, world, rank, group):
+    """k-NN radii of a row-sharded set whose gathered copy `full` every rank holds.
+    Returns (radii of this rank's rows, radii of all rows).  Wide, large sets take the partitioned symmetric
+    kernel (half the tile pairs; rank r owns the 128-row blocks pb == r mod world; per-row lists all-gathered
+    and merged); otherwise every rank runs the general kernel on its row shard against all columns."""
+    n, d = full.shape
+    lo = sum(counts[:rank])
+    hi = lo + counts[rank]
+    if world > 1 and hasattr(ops, "knn_sym_part") and ops.knn_sym_eligible(n, d, k):
+        bounds = _all_gather_rows(ops.knn_bounds(full, k, lo, counts[rank]), counts, world, group)
+        lists = ops.knn_sym_part(full, k, rank, world, bounds)
+        all_lists = torch.empty((world, *lists.shape), dtype=lists.dtype, device=lists.device)
+        _all_gather_into(all_lists.view(-1), lists.view(-1), world, group)
+        r_full = ops.knn_lists_finish(all_lists, full, k)
+        return r_full[lo:hi], r_full
+    r_local = ops.knn_radii(local, k, columns=full)
+    return r_local, _all_gather_rows(r_local, counts, world, group)
+
+
 def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), nearest_k=5, group=None, ops=None,
                      kid_subsets=KID_SUBSETS, kid_subset_size=KID_SUBSET_SIZE, rng_seed=1234):
     """FAD / KD / PRDC of (candidate vs reference) from this rank's row shards.
@@ -126,9 +145,8 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
 
     if "prdc" in metrics:
         k = nearest_k
-        r_ref_l = ops.knn_radii(ref_local, k, columns=ref_full)
-        r_cand_l = ops.knn_radii(cand_local, k, columns=cand_full)
-        r_cand = _all_gather_rows(r_cand_l, cand_counts, world, group)
+        r_ref_l, _ = sharded_radii(ref_local, ref_full, ref_counts, k, ops, world, rank, group)
+        _, r_cand = sharded_radii(cand_local, cand_full, cand_counts, k, ops, world, rank, group)
         col, rany, rmin = ops.prdc_counts(ref_local, cand_full, r_ref_l, r_cand)
         _all_reduce(col, world, group)
         tot = ops.prdc_reduce(col, rany, rmin, r_ref_l)        # [n_prec, n_rec(local), sum_cnt, n_cov(local)]

@@ -208,6 +208,53 @@ def knn_radii(x, k, columns=None):
     return out
 
 
+# ---- partitioned symmetric k-NN (multi-GPU, every rank holds the full set) ----
+def knn_sym_eligible(n, d, k):
+    return bool(_lib.load().am_knn_sym_eligible(int(n), int(d), int(k)))
+
+
+def knn_bounds(x_full, k, row0, nrows):
+    """Squared upper bounds for rows [row0, row0+nrows) of the full set (column-sample pre-pass)."""
+    lib = _lib.load()
+    x = as_matrix(x_full)
+    n, d = x.shape
+    out = torch.empty(int(nrows), dtype=torch.float32, device=x.device)
+    nb = lib.am_knn_part_workspace_bytes(n, int(k))
+    ws = _workspace(nb, x.device)
+    _call(lib, "am_knn_bounds_f32", _ptr(x), n, _ld(x), d, int(k), int(row0), int(nrows), _ptr(out), _ptr(ws), nb, _stream())
+    return out
+
+
+def knn_sym_part(x_full, k, part, nparts, bounds_sq):
+    """This rank's share of the symmetric k-NN: [N, width] smallest entries per row (+inf padded)."""
+    lib = _lib.load()
+    x = as_matrix(x_full)
+    n, d = x.shape
+    width = lib.am_knn_list_width(int(k))
+    bounds_sq = bounds_sq.to(torch.float32).contiguous().clone()
+    out = torch.empty((n, width), dtype=torch.float32, device=x.device)
+    nb = lib.am_knn_part_workspace_bytes(n, int(k))
+    ws = _workspace(nb, x.device)
+    _call(lib, "am_knn_sym_part_f32", _ptr(x), n, _ld(x), d, int(k), int(part), int(nparts), _ptr(bounds_sq), _ptr(out),
+          _ptr(ws), nb, _stream())
+    return out
+
+
+def knn_lists_finish(lists, x_full, k):
+    """[nparts, N, width] per-rank lists -> radii f32[N] (bit-identical to knn_radii(x_full, k))."""
+    lib = _lib.load()
+    x = as_matrix(x_full)
+    n, d = x.shape
+    lists = lists.to(torch.float32).contiguous()
+    nparts = lists.shape[0]
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    nb = 2 * (4 * (n + 64) + 512)
+    ws = _workspace(nb, x.device)
+    _call(lib, "am_knn_lists_finish_f32", _ptr(lists), nparts, _ptr(x), n, _ld(x), d, int(k), _ptr(out), _ptr(ws), nb,
+          _stream())
+    return out
+
+
 def prdc_counts(ref, cand, r_ref, r_cand):
     """col_count i32[Nc], row_any u8[Nr], row_min f32[Nr] (prdc.py:34-48)."""
     lib = _lib.load()

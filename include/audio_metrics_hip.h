@@ -125,6 +125,29 @@ int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx,
                      float* out_r, void* ws, size_t ws_bytes, am_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * A9, partitioned form for one-process-per-GPU callers that all hold the FULL set X.
+ * The self-distance matrix is bitwise symmetric, so only half of the tile pairs are multiplied
+ * (csrc/pairwise.hip, knn_sym_kernel); rank `part` of `nparts` owns the 128-row blocks pb == part (mod nparts).
+ *   am_knn_sym_eligible     1 if this path applies to the shape (else use am_knn_radii_f32 on row shards)
+ *   am_knn_bounds_f32       upper bounds (SQUARED distances) of the final values of rows [row0, row0+nrows)
+ *                           from a column sample; ranks split the rows and all-gather the result
+ *   am_knn_sym_part_f32     this rank's share: out_lists[N][am_knn_list_width(k)] = its smallest entries per row
+ *                           (+inf padded; a NaN in slot 0 flags a row whose candidate buffer overflowed);
+ *                           bounds_sq[N] is read and tightened in place
+ *   am_knn_lists_finish_f32 lists[nparts][N][width] (all-gathered) -> out_r[N]; flagged rows are recomputed exactly
+ * The result is bit-identical to am_knn_radii_f32(X, X).
+ * ------------------------------------------------------------------------- */
+int am_knn_sym_eligible(int64_t N, int D, int k);
+int am_knn_list_width(int k);
+size_t am_knn_part_workspace_bytes(int64_t N, int k);
+int am_knn_bounds_f32(const float* X, int64_t N, int64_t ld, int D, int k, int64_t row0, int64_t nrows,
+                      float* out_bound_sq, void* ws, size_t ws_bytes, am_stream_t stream);
+int am_knn_sym_part_f32(const float* X, int64_t N, int64_t ld, int D, int k, int part, int nparts,
+                        float* bounds_sq, float* out_lists, void* ws, size_t ws_bytes, am_stream_t stream);
+int am_knn_lists_finish_f32(const float* lists, int nparts, const float* X, int64_t N, int64_t ld, int D, int k,
+                            float* out_r, void* ws, size_t ws_bytes, am_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * A10  hypersphere membership counts            reference: prdc.py:34-48
  *   With d(i,j) the distance between reference row i and candidate row j:
  *   out_col_count[j] = #{ i : d(i,j) < r_ref[i] }      (precision, density)

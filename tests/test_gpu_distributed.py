@@ -65,6 +65,10 @@ def test_sharded_evaluate_with_hip_kernels(n_ref, n_cand):
     for key, w in single.items():
         if key in ("precision", "recall", "density", "coverage"):
             assert results[0][key] == w, key              # integer counts: identical whatever the sharding
+        elif key == "fad":
+            # the f32 product chains of the covariance kernel break at slab boundaries, which move with the
+            # sharding: covariances agree to ~1e-7, and FAD amplifies that by trace/FAD
+            assert abs(results[0][key] - w) <= 1e-5 * abs(w), (key, results[0][key], w)
         else:
             assert abs(results[0][key] - w) <= max(1e-9 * abs(w), 1e-12), (key, results[0][key], w)
     # and the single-process sharded path equals the object API
@@ -72,4 +76,49 @@ def test_sharded_evaluate_with_hip_kernels(n_ref, n_cand):
     a.add(torch.as_tensor(cand).to(dev))
     b.add(torch.as_tensor(ref).to(dev))
     assert am.prdc(b, a, k) == {key: single[key] for key in ("precision", "recall", "density", "coverage")}
-    assert abs(am.frechet_distance(a, b) - single["fad"]) <= 1e-9 * abs(single["fad"])
+    assert abs(am.frechet_distance(a, b) - single["fad"]) <= 1e-5 * abs(single["fad"])
+
+
+@pytest.mark.parametrize("nparts,k", [(2, 5), (3, 10), (8, 5)])
+def test_partitioned_symmetric_knn_bit_identical(nparts, k):
+    """The multi-GPU form of the symmetric k-NN, emulated on one GPU: every part computed in turn, lists
+    stacked as the all-gather would, then merged - bit-identical to the single-GPU result."""
+    import numpy as np
+    from audio_metrics_amd import hip_ops as ops
+    x = torch.as_tensor(gi.randn(97, 9100, 136)).to("cuda:0")
+    n = x.shape[0]
+    assert ops.knn_sym_eligible(n, x.shape[1], k)
+    want = ops.knn_radii(x, k).cpu().numpy()
+    bounds = torch.cat([ops.knn_bounds(x, k, lo, hi - lo) for lo, hi in
+                        [(n * p // nparts, n * (p + 1) // nparts) for p in range(nparts)]])
+    lists = torch.stack([ops.knn_sym_part(x, k, p, nparts, bounds) for p in range(nparts)])
+    got = ops.knn_lists_finish(lists, x, k).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # a flagged row (NaN marker from any rank) is recomputed exactly
+    lists[0, 17, 0] = float("nan")
+    lists[nparts - 1, 4000, 0] = float("nan")
+    got = ops.knn_lists_finish(lists, x, k).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_sharded_evaluate_takes_symmetric_path():
+    """2 ranks on cuda:0 over gloo with sets large and wide enough for the partitioned symmetric kernel."""
+    from audio_metrics_amd.distributed import evaluate_sharded
+    n_ref, n_cand, d, k, world = 8300, 8200, 128, 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_ref, n_cand, d, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, cand = gi.pair("randn", 95, n_ref, n_cand, d)
+    dev = torch.device("cuda:0")
+    single = evaluate_sharded(torch.as_tensor(ref).to(dev), torch.as_tensor(cand).to(dev), nearest_k=k,
+                              kid_subsets=8, kid_subset_size=300)
+    assert results[0] == results[1]
+    for key in ("precision", "recall", "density", "coverage"):
+        assert results[0][key] == single[key], key
