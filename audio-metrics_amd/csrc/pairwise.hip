@@ -385,8 +385,10 @@ knn_sym_kernel(const float* __restrict__ X, int64_t N, int64_t ld, const float* 
         qb = (pb + noff - T < q1) ? pb + noff - T : q1;
     }
     const int ntiles = qb > qa ? (int)(qb - qa) : 0;
-    // multi-GPU: rank `part` of `nparts` owns the row blocks pb == part (mod nparts); see am_knn_sym_part_f32
-    if (ntiles == 0 || (int)(pb % nparts) != part) {   // nothing of this window belongs to this block
+    // multi-GPU: rank `part` of `nparts` owns the CONTIGUOUS range of row blocks with floor(pb*nparts/T) == part
+    // (see am_knn_sym_part_f32).  Not pb mod nparts: consecutive blockIdx map to consecutive pb, and ownership
+    // by residue would put every owned workgroup of a window on the same XCD (blockIdx % 8).
+    if (ntiles == 0 || (int)(pb * nparts / T) != part) {   // nothing of this window belongs to this block
         if (L.tid == 0) wgq_count[blockIdx.x] = 0;
         return;
     }

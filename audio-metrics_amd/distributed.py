@@ -81,7 +81,7 @@ def global_stats(local, n_total, ops, world, group):
 def sharded_radii(local, full, counts, k, ops, world, rank, group):
     """k-NN radii of a row-sharded set whose gathered copy `full` every rank holds.
     Returns (radii of this rank's rows, radii of all rows).  Wide, large sets take the partitioned symmetric
-    kernel (half the tile pairs; rank r owns the 128-row blocks pb == r mod world; per-row lists all-gathered
+    kernel (half the tile pairs; rank r owns a contiguous range of the 128-row blocks; per-row lists all-gathered
     and merged); otherwise every rank runs the general kernel on its row shard against all columns."""
     n, d = full.shape
     lo = sum(counts[:rank])

@@ -127,7 +127,7 @@ int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx,
 /* ---------------------------------------------------------------------------
  * A9, partitioned form for one-process-per-GPU callers that all hold the FULL set X.
  * The self-distance matrix is bitwise symmetric, so only half of the tile pairs are multiplied
- * (csrc/pairwise.hip, knn_sym_kernel); rank `part` of `nparts` owns the 128-row blocks pb == part (mod nparts).
+ * (csrc/pairwise.hip, knn_sym_kernel); rank `part` of `nparts` owns a contiguous range of the 128-row blocks.
  *   am_knn_sym_eligible     1 if this path applies to the shape (else use am_knn_radii_f32 on row shards)
  *   am_knn_bounds_f32       upper bounds (SQUARED distances) of the final values of rows [row0, row0+nrows)
  *                           from a column sample; ranks split the rows and all-gather the result

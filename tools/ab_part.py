@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Time one rank's share of the partitioned symmetric k-NN at the BASELINE size (single GPU emulation)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audio_metrics_amd import hip_ops as ops  # noqa: E402
+
+n, d, k = 100000, 512, 5
+x = torch.randn(n, d, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+
+
+def t(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best * 1e3
+
+
+for g in (2, 4, 8):
+    rows = n // g
+    tb = t(lambda: ops.knn_bounds(x, k, 0, rows))
+    bounds = torch.cat([ops.knn_bounds(x, k, p * rows, rows) for p in range(g)])
+    tp = t(lambda: ops.knn_sym_part(x, k, 0, g, bounds))
+    lists = torch.stack([ops.knn_sym_part(x, k, p, g, bounds) for p in range(g)])
+    tf = t(lambda: ops.knn_lists_finish(lists, x, k))
+    tg = t(lambda: ops.knn_radii(x[:rows], k, columns=x))
+    print(f"world={g}: bounds {tb:.2f} ms + part {tp:.2f} ms + finish {tf:.2f} ms = {tb + tp + tf:.2f} ms   (general shard kernel {tg:.2f} ms)")
