@@ -14,6 +14,7 @@ from .metrics.prdc import prdc, nearest_neighbour_distances                   # 
 from .metrics.apa import apa, apa_compute_d_x_xp                              # noqa: F401
 
 from .embed import ItemCategory, embedding_pipeline                            # noqa: F401
+from .projection import IncrementalPCA                                         # noqa: F401
 from .audio_metrics import AudioMetrics                                        # noqa: F401
 
 __version__ = "0.1.0"

@@ -16,6 +16,7 @@ from .metrics.fad import frechet_distance
 from .metrics.kd import kernel_distance
 from .metrics.prdc import prdc
 from .mix_functions import DEFAULT_MIX_FUNCTION, MIX_FUNCTIONS
+from .projection import IncrementalPCA
 
 
 class AudioMetrics:
@@ -30,12 +31,12 @@ class AudioMetrics:
         self.need_apa = "apa" in self.metrics
         self.win_dur = win_dur
         self.input_sr = input_sr
-        if n_pca is not None:
-            # the sklearn IncrementalPCA projection sits between the aggregation and the
-            # metric kernels; it is the next row to build, not part of this one.
-            raise NotImplementedError("n_pca (PCA projection of the embeddings) is not implemented in this build yet")
-        self.stem_projection = None
-        self.mix_projection = None
+        if n_pca is None:
+            self.stem_projection = None
+            self.mix_projection = None
+        else:
+            self.stem_projection = IncrementalPCA(n_components=n_pca, device=self.device)
+            self.mix_projection = IncrementalPCA(n_components=n_pca, device=self.device)
         self.embedder = self.get_embedder(embedder) if embedder is None or isinstance(embedder, str) else embedder
         self.mix_function = (self.get_mix_function(mix_function)
                              if mix_function is None or isinstance(mix_function, str) else mix_function)
@@ -94,6 +95,10 @@ class AudioMetrics:
             item = state.get(attr)
             if item:
                 state[attr] = item.serialize()
+        for attr in ("stem_projection", "mix_projection"):
+            item = state.get(attr)
+            if item:
+                state[attr] = item.__getstate__().copy()
         torch.save(state, fp)
 
     def load_state(self, fp: str | Path):
@@ -103,8 +108,10 @@ class AudioMetrics:
             if item:
                 state[attr] = AudioMetricsData.deserialize(item, device=self.device)
         for attr in ("stem_projection", "mix_projection"):
-            if state.get(attr):
-                raise NotImplementedError("state files with a PCA projection are not supported by this build yet")
+            item = state.get(attr)
+            if item:
+                getattr(self, attr).__setstate__(item)
+                del state[attr]
         self.__dict__.update(state)
 
     def reset_reference(self, _init=False):
@@ -133,6 +140,42 @@ class AudioMetrics:
             raise ValueError(msg)
         if self.need_apa and self.mix_reference.n is None:
             raise ValueError(msg)
+
+    # ------------------------------------------------------------ PCA projection (audio_metrics.py:163-209)
+    def ensure_stem_projection(self, ref, cand):
+        if self.stem_projection is None:
+            return ref, cand
+        store_embs = any(metric in self._need_embeddings for metric in self.metrics)
+        if self.stem_reference_pca is None:
+            self.stem_projection.partial_fit(ref.embeddings)
+            ref_emb = self.stem_projection.transform(ref.embeddings)
+            ref = AudioMetricsData(store_embs, device=self.device)
+            ref.add(ref_emb)
+            self.stem_reference_pca = ref
+        ref = self.stem_reference_pca
+        cand_emb = self.stem_projection.transform(cand.embeddings)
+        cand = AudioMetricsData(store_embs, device=self.device)
+        cand.add(cand_emb)
+        return ref, cand
+
+    def ensure_mix_projection(self, ref, anti_ref, cand):
+        if self.mix_projection is None:
+            return ref, anti_ref, cand
+        if self.mix_reference_pca is None:
+            self.mix_projection.partial_fit(ref.embeddings)
+            ref_emb = self.mix_projection.transform(ref.embeddings)
+            anti_ref_emb = self.mix_projection.transform(anti_ref.embeddings)
+            ref = AudioMetricsData(store_embeddings=False, device=self.device)
+            anti_ref = AudioMetricsData(store_embeddings=False, device=self.device)
+            ref.add(ref_emb)
+            anti_ref.add(anti_ref_emb)
+            self.mix_reference_pca = ref
+            self.mix_anti_reference_pca = anti_ref
+        ref, anti_ref = self.mix_reference_pca, self.mix_anti_reference_pca
+        cand_emb = self.mix_projection.transform(cand.embeddings)
+        cand = AudioMetricsData(store_embeddings=False, device=self.device)
+        cand.add(cand_emb)
+        return ref, anti_ref, cand
 
     # ------------------------------------------------------------ the two entry points
     def _pipeline(self, waveforms, apa_mode):
@@ -171,8 +214,12 @@ class AudioMetrics:
             raise ValueError("No stem candidate embeddings were computed")
         if self.need_apa and (apa_cand is None or apa_cand.n is None):
             raise ValueError("No apa candidate embeddings were computed")
-        if self.need_apa and self.apa_d_x_xp is None:
-            self.apa_d_x_xp = apa_compute_d_x_xp(apa_ref, apa_anti_ref)
+        if self.stems_mode:
+            stem_ref, stem_cand = self.ensure_stem_projection(stem_ref, stem_cand)
+        if self.need_apa:
+            apa_ref, apa_anti_ref, apa_cand = self.ensure_mix_projection(apa_ref, apa_anti_ref, apa_cand)
+            if self.apa_d_x_xp is None:
+                self.apa_d_x_xp = apa_compute_d_x_xp(apa_ref, apa_anti_ref)
 
         result = {}
         if "fad" in self.metrics:

@@ -24,9 +24,15 @@ struct GatherRows {           // local row -> X[idx[tile*128 + row]], zero rows 
     }
 };
 
+// kernel value from the f32 dot product: polynomial (dot*gamma + coef0)^degree (kd.py:112-116) or, with
+// rbf != 0, exp(-(|x|^2 + |y|^2 - 2 dot) / (2 sigma^2)) (kd.py:86-109; gamma then holds 1/(2 sigma^2) and
+// qn / pn the f64 squared norms of the subset rows, +inf for padded rows so that they contribute exactly 0).
 struct KdEpilogue {
     double gamma, coef0;
     int degree, m;
+    int rbf;
+    const double* qn;          // [m] squared norms of the Q rows of this subset (RBF only)
+    const double* pn;
     int q0, p0;                // first subset position of the Q (register) / P (lane) rows of this tile
     bool drop_diag;
     double sum;
@@ -42,7 +48,36 @@ struct KdEpilogue {
     }
     // Sums ALL 128x128 entries of the tile; padded (zero) rows give exactly kval(0) each, which the
     // caller subtracts analytically.  Diagonal entries of Kxx / Kyy are removed here (valid ones only).
+    __device__ __forceinline__ void finish_rbf(f32x16 (&acc)[2][2]) {
+        double s = 0.0;
+        double pnorm[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int p = p0 + L.wn * 64 + nt * 32 + L.r;
+            pnorm[nt] = p < m ? pn[p] : INFINITY;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int q = q0 + L.wm * 64 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * L.h;
+                const double qnorm = q < m ? qn[q] : INFINITY;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int p = p0 + L.wn * 64 + nt * 32 + L.r;
+                    double d2 = (qnorm + pnorm[nt]) - 2.0 * (double)acc[mt][nt][i];
+                    d2 = d2 < 0.0 ? 0.0 : d2;
+                    const double k = exp(-d2 * gamma);                  // padded rows: exp(-inf) = 0
+                    s += (drop_diag && p == q) ? 0.0 : k;
+                }
+            }
+        sum = s;
+    }
     __device__ __forceinline__ void finish(int, int64_t, f32x16 (&acc)[2][2]) {
+        if (rbf) {
+            finish_rbf(acc);
+            return;
+        }
         double s = 0.0;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -68,7 +103,8 @@ struct KdEpilogue {
 __global__ void __launch_bounds__(ENGINE_THREADS, 2)
 kd_tile_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ Y, int64_t ldy, int D,
                const int64_t* __restrict__ idx1, const int64_t* __restrict__ idx2, int m, int T, int ntri,
-               double gamma, double coef0, int degree, double* __restrict__ partial) {
+               double gamma, double coef0, int degree, double* __restrict__ partial, int rbf,
+               const double* __restrict__ sub_norm1, const double* __restrict__ sub_norm2) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
     const int per_subset = 2 * ntri + T * T;
@@ -101,6 +137,9 @@ kd_tile_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict
     epi.p0 = tp * TB;
     epi.drop_diag = (which != 2) && (tq == tp);
     epi.sum = 0.0;
+    epi.rbf = rbf;
+    epi.qn = rbf ? (which == 1 ? sub_norm2 : sub_norm1) + (int64_t)s * m : nullptr;
+    epi.pn = rbf ? (which == 0 ? sub_norm1 : sub_norm2) + (int64_t)s * m : nullptr;
     tile_pipeline(qsrc, psrc, 1, D, lds, L, epi);
 
     double v = epi.sum;
@@ -112,7 +151,7 @@ kd_tile_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict
     if (L.tid == 0) {
         const double w = (which != 2 && tq != tp) ? 2.0 : 1.0;   // symmetric blocks: count the mirrored tile too
         const int vq = min(TB, m - tq * TB), vp = min(TB, m - tp * TB);
-        const double pad = (double)(TB * TB - vq * vp) * epi.kval(0.f);
+        const double pad = rbf ? 0.0 : (double)(TB * TB - vq * vp) * epi.kval(0.f);
         partial[blockIdx.x] = w * ((((red[0] + red[1]) + red[2]) + red[3]) - pad);
     }
 }
@@ -132,7 +171,66 @@ __global__ void kd_finish_kernel(const double* __restrict__ partial, int S, int 
     out[s] = (sxx + syy) / (dm * (dm - 1.0)) - 2.0 * sxy / (dm * dm);
 }
 
+// sub_norm[s][p] = |X[idx[s][p]]|^2 in f64 (one wave per subset row)
+__global__ void __launch_bounds__(256) kd_gather_norms_kernel(const float* __restrict__ X, int64_t ld, int D,
+                                                              const int64_t* __restrict__ idx, int64_t total,
+                                                              double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= total) return;
+    const float* x = X + idx[e] * ld;
+    double acc = 0.0;
+    for (int k = lane * 4; k < D; k += 256) {
+        const f32x4 v = load_k4(x, k, D);
+        acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) out[e] = acc;
+}
+
 constexpr size_t KD_LDS_BYTES = ENGINE_LDS_FLOATS * sizeof(float);
+
+static int run_kd(const float* X, int64_t N1, int64_t ldx, const float* Y, int64_t N2, int64_t ldy, int D, const int64_t* idx1,
+                  const int64_t* idx2, int S, int m, double gamma, double coef0, int degree, int rbf, double* out_mmd, void* ws,
+                  size_t ws_bytes, hipStream_t st) {
+    AM_REQUIRE(X && Y && idx1 && idx2 && out_mmd, AM_ERR_BAD_ARG, "null pointer");
+    AM_REQUIRE(N1 >= 1 && N2 >= 1 && D >= 1 && S >= 1 && m >= 1, AM_ERR_BAD_SHAPE,
+               "N1=%lld N2=%lld D=%d S=%d m=%d", (long long)N1, (long long)N2, D, S, m);
+    AM_REQUIRE(m <= N1 && m <= N2, AM_ERR_BAD_SHAPE, "subset size %d exceeds a set size", m);
+    AM_REQUIRE(aligned16(X) && aligned16(Y) && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= D && ldy >= D, AM_ERR_BAD_ARG,
+               "X/Y must be 16-byte aligned with ld %% 4 == 0 and ld >= D");
+    const int T = (int)ceil_div(m, TB);
+    const int ntri = T * (T + 1) / 2;
+    const int per_subset = 2 * ntri + T * T;
+    Carver c(ws, ws_bytes);
+    double* partial = c.take<double>((size_t)S * per_subset);
+    double *n1 = nullptr, *n2 = nullptr;
+    if (rbf) {
+        n1 = c.take<double>((size_t)S * m);
+        n2 = c.take<double>((size_t)S * m);
+    }
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    if (rbf) {
+        const int64_t total = (int64_t)S * m;
+        hipLaunchKernelGGL(kd_gather_norms_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st, X, ldx, D, idx1, total, n1);
+        hipLaunchKernelGGL(kd_gather_norms_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st, Y, ldy, D, idx2, total, n2);
+        AM_LAUNCH_CHECK();
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_tile_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)KD_LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kd_tile_kernel, dim3((unsigned)((int64_t)S * per_subset)), dim3(ENGINE_THREADS), KD_LDS_BYTES, st,
+                       X, ldx, Y, ldy, D, idx1, idx2, m, T, ntri, gamma, coef0, degree, partial, rbf, n1, n2);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(kd_finish_kernel, dim3((unsigned)ceil_div(S, 64)), dim3(64), 0, st, partial, S, m, T, ntri,
+                       out_mmd);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
 
 }  // namespace am
 
@@ -149,31 +247,25 @@ extern "C" size_t am_kd_workspace_bytes(int S, int m) {
 extern "C" int am_kd_poly_f32(const float* X, int64_t N1, int64_t ldx, const float* Y, int64_t N2, int64_t ldy, int D,
                               const int64_t* idx1, const int64_t* idx2, int S, int m, double gamma, double coef0,
                               int degree, double* out_mmd, void* ws, size_t ws_bytes, am_stream_t stream) {
-    AM_REQUIRE(X && Y && idx1 && idx2 && out_mmd, AM_ERR_BAD_ARG, "null pointer");
-    AM_REQUIRE(N1 >= 1 && N2 >= 1 && D >= 1 && S >= 1 && m >= 1, AM_ERR_BAD_SHAPE,
-               "N1=%lld N2=%lld D=%d S=%d m=%d", (long long)N1, (long long)N2, D, S, m);
-    AM_REQUIRE(m <= N1 && m <= N2, AM_ERR_BAD_SHAPE, "subset size %d exceeds a set size", m);
     AM_REQUIRE(degree >= 0 && degree <= 16, AM_ERR_BAD_ARG, "degree %d outside [0, 16]", degree);
-    AM_REQUIRE(aligned16(X) && aligned16(Y) && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= D && ldy >= D, AM_ERR_BAD_ARG,
-               "X/Y must be 16-byte aligned with ld %% 4 == 0 and ld >= D");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    return run_kd(X, N1, ldx, Y, N2, ldy, D, idx1, idx2, S, m, gamma, coef0, degree, 0, out_mmd, ws, ws_bytes,
+                  static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t am_kd_rbf_workspace_bytes(int S, int m) {
+    if (S < 1 || m < 1) return 0;
     const int T = (int)ceil_div(m, TB);
-    const int ntri = T * (T + 1) / 2;
-    const int per_subset = 2 * ntri + T * T;
-    Carver c(ws, ws_bytes);
-    double* partial = c.take<double>((size_t)S * per_subset);
-    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
-    static bool attr_done = false;
-    if (!attr_done) {
-        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_tile_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)KD_LDS_BYTES));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kd_tile_kernel, dim3((unsigned)((int64_t)S * per_subset)), dim3(ENGINE_THREADS), KD_LDS_BYTES, st,
-                       X, ldx, Y, ldy, D, idx1, idx2, m, T, ntri, gamma, coef0, degree, partial);
-    AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(kd_finish_kernel, dim3((unsigned)ceil_div(S, 64)), dim3(64), 0, st, partial, S, m, T, ntri,
-                       out_mmd);
-    AM_LAUNCH_CHECK();
-    return AM_OK;
+    Carver c(nullptr, 0);
+    c.take<double>((size_t)S * (T * (T + 1) + T * T));
+    c.take<double>((size_t)S * m);
+    c.take<double>((size_t)S * m);
+    return c.off;
+}
+
+extern "C" int am_kd_rbf_f32(const float* X, int64_t N1, int64_t ldx, const float* Y, int64_t N2, int64_t ldy, int D,
+                             const int64_t* idx1, const int64_t* idx2, int S, int m, double sigma, double* out_mmd,
+                             void* ws, size_t ws_bytes, am_stream_t stream) {
+    AM_REQUIRE(sigma > 0, AM_ERR_BAD_ARG, "sigma must be positive");
+    return run_kd(X, N1, ldx, Y, N2, ldy, D, idx1, idx2, S, m, 1.0 / (2.0 * sigma * sigma), 0.0, 0, 1, out_mmd, ws, ws_bytes,
+                  static_cast<hipStream_t>(stream));
 }

@@ -190,6 +190,21 @@ def kd_poly(x, y, idx1, idx2, gamma, coef0, degree):
     return out
 
 
+def kd_rbf(x, y, idx1, idx2, sigma):
+    """Per-subset unbiased MMD^2 with the RBF kernel exp(-|x-y|^2 / (2 sigma^2)) (f64[S] device tensor)."""
+    lib = _lib.load()
+    x, y = as_matrix(x, "features_1"), as_matrix(y, "features_2")
+    idx1 = idx1.to(torch.int64).contiguous()
+    idx2 = idx2.to(torch.int64).contiguous()
+    s, m = idx1.shape
+    out = torch.empty(s, dtype=torch.float64, device=x.device)
+    nb = lib.am_kd_rbf_workspace_bytes(s, m)
+    ws = _workspace(nb, x.device)
+    _call(lib, "am_kd_rbf_f32", _ptr(x), x.shape[0], _ld(x), _ptr(y), y.shape[0], _ld(y), x.shape[1], _ptr(idx1), _ptr(idx2),
+          s, m, float(sigma), _ptr(out), _ptr(ws), nb, _stream())
+    return out
+
+
 # ------------------------------------------------------------------ PRDC
 def knn_radii(x, k, columns=None):
     """(k+1)-th smallest distance from each row of x to the rows of `columns`

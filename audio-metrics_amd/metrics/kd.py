@@ -18,6 +18,7 @@ KID_SUBSET_SIZE = 1000
 KID_DEGREE = 3
 KID_GAMMA = None
 KID_COEF0 = 1
+KID_SIGMA = 10.0      # RBF kernel width (kd.py:26)
 
 
 def kernel_distance(x: AudioMetricsData, y: AudioMetricsData):
@@ -45,8 +46,7 @@ def _device_features(f):
 
 def kid_features_to_metric(features_1, features_2, **kwargs):
     kernel_type = kwargs.get("kernel_type", "polynomial")
-    if kernel_type != "polynomial":
-        # the reference also offers an RBF kernel (kd.py:86-109) that AudioMetrics never selects
+    if kernel_type not in ("polynomial", "rbf"):
         raise NotImplementedError(f'Unknown kernel_type "{kernel_type}"')
     features_1, features_2 = _device_features(features_1), _device_features(features_2)
     assert features_1.ndim == 2
@@ -72,7 +72,11 @@ def kid_features_to_metric(features_1, features_2, **kwargs):
     idx1, idx2 = subset_indices(n_samples_1, n_samples_2, kid_subsets, kid_subset_size,
                                 kwargs.get("rng_seed", 1234))
     dev = features_1.device
-    mmds = ops.kd_poly(features_1, features_2, torch.as_tensor(idx1).to(dev), torch.as_tensor(idx2).to(dev),
-                       gamma, kwargs.get("kid_coef0", KID_COEF0), kwargs.get("kid_degree", KID_DEGREE))
+    if kernel_type == "rbf":          # kd.py:136-140
+        mmds = ops.kd_rbf(features_1, features_2, torch.as_tensor(idx1).to(dev), torch.as_tensor(idx2).to(dev),
+                          kwargs.get("kid_sigma", KID_SIGMA))
+    else:
+        mmds = ops.kd_poly(features_1, features_2, torch.as_tensor(idx1).to(dev), torch.as_tensor(idx2).to(dev),
+                           gamma, kwargs.get("kid_coef0", KID_COEF0), kwargs.get("kid_degree", KID_DEGREE))
     mmds = mmds.cpu().numpy()
     return {KEY_METRIC_KID_MEAN: float(np.mean(mmds)), KEY_METRIC_KID_STD: float(np.std(mmds))}

@@ -111,6 +111,14 @@ int am_kd_poly_f32(const float* X, int64_t N1, int64_t ldx,
                    double gamma, double coef0, int degree,
                    double* out_mmd, void* ws, size_t ws_bytes, am_stream_t stream);
 
+/* RBF variant (reference kd.py:86-109, selected with kernel_type="rbf"): K = exp(-|x-y|^2 / (2 sigma^2)),
+ * squared distances |x|^2 + |y|^2 - 2 x.y with f64 norms and the f32 matrix-core dot product. */
+size_t am_kd_rbf_workspace_bytes(int S, int m);
+int am_kd_rbf_f32(const float* X, int64_t N1, int64_t ldx,
+                  const float* Y, int64_t N2, int64_t ldy, int D,
+                  const int64_t* idx1, const int64_t* idx2, int S, int m, double sigma,
+                  double* out_mmd, void* ws, size_t ws_bytes, am_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * A9  k-NN radii                                reference: prdc.py:4-14, data.py:60-66
  *   out_r[i] = (k+1)-th smallest Euclidean distance from row i of X to the M

@@ -45,6 +45,12 @@ def poly_kernel(x, y, degree=DEGREE, gamma=GAMMA, coef0=COEF0):
     return (np.matmul(x, y.T) * gamma + coef0) ** degree
 
 
+def rbf_kernel(x, y, sigma=10.0):
+    """exp(-|x-y|^2 / (2 sigma^2)) with scipy's sqeuclidean cdist (f64) - kd.py:86-109."""
+    from scipy.spatial.distance import cdist
+    return np.exp(-cdist(x, y, "sqeuclidean") / (2 * sigma ** 2))
+
+
 def mmd2_unbiased(k_xx, k_xy, k_yy):
     """Unbiased MMD^2 estimate (kd.py:50-79, ``mmd_est='unbiased'``): within-set
     sums drop the diagonal and are divided by m(m-1); the cross term keeps its
@@ -62,8 +68,8 @@ def mmd2_unbiased(k_xx, k_xy, k_yy):
 
 
 def kid_from_features(f1, f2, subsets=SUBSETS, subset_size=SUBSET_SIZE, degree=DEGREE,
-                      gamma=GAMMA, coef0=COEF0, seed=SEED, return_all=False):
-    """kd.py:127-194 for the polynomial kernel."""
+                      gamma=GAMMA, coef0=COEF0, seed=SEED, return_all=False, kernel_type="polynomial", sigma=10.0):
+    """kd.py:127-194 (polynomial kernel by default; kernel_type="rbf" selects kd.py:136-140)."""
     f1, f2 = _to_numpy(f1), _to_numpy(f2)
     assert f1.ndim == 2 and f2.ndim == 2 and f1.shape[1] == f2.shape[1]
     n1, n2 = len(f1), len(f2)
@@ -72,6 +78,9 @@ def kid_from_features(f1, f2, subsets=SUBSETS, subset_size=SUBSET_SIZE, degree=D
     mmds = np.zeros(subsets)
     for s in range(subsets):
         a, b = f1[idx1[s]], f2[idx2[s]]
+        if kernel_type == "rbf":
+            mmds[s] = mmd2_unbiased(rbf_kernel(a, a, sigma), rbf_kernel(a, b, sigma), rbf_kernel(b, b, sigma))
+            continue
         mmds[s] = mmd2_unbiased(poly_kernel(a, a, degree, gamma, coef0),
                                 poly_kernel(a, b, degree, gamma, coef0),
                                 poly_kernel(b, b, degree, gamma, coef0))

@@ -112,6 +112,12 @@ def gen_kd():
         out[f"{name}/first_idx1"] = first[0]
         out[f"{name}/first_idx2"] = first[1]
         print("kd", name, res)
+        if n1 <= 3000:                      # RBF option (kd.py:86-109, 136-140); sigma chosen to give a non-trivial kernel
+            for sigma in ((10.0, 3.0) if kind != "unit" else (10.0, 0.5)):
+                rr = r_kd.kid_features_to_metric(f1, f2, kernel_type="rbf", kid_sigma=sigma)
+                out[f"{name}/rbf_{sigma}/mean"] = rr["kernel_distance_mean"]
+                out[f"{name}/rbf_{sigma}/std"] = rr["kernel_distance_std"]
+                print("kd rbf", name, sigma, rr)
     np.savez_compressed(os.path.join(HERE, "kd.npz"), **out)
 
 
@@ -199,15 +205,20 @@ def gen_e2e():
 
     c = gi.E2E
     out = {"versions": VERSIONS}
-    for tag, metrics in (("all", ["fad", "kd", "prdc", "apa"]), ("stems", ["fad", "kd", "prdc"]), ("apa", ["apa"])):
+    for tag, metrics, n_pca in (("all", ["fad", "kd", "prdc", "apa"], None), ("stems", ["fad", "kd", "prdc"], None),
+                                ("apa", ["apa"], None), ("pca", ["fad", "kd", "prdc", "apa"], 8),
+                                ("pca2", ["fad", "apa"], 8)):
         random.seed(c["random_seed"])
         am = audio_metrics.AudioMetrics(metrics=metrics, embedder=gi.NumpyEmbedder(c["dim"], c["sr"]),
-                                        mix_function=gi.e2e_mix, win_dur=c["win_dur"])
+                                        mix_function=gi.e2e_mix, win_dur=c["win_dur"], n_pca=n_pca)
         ref = gi.e2e_pairs(c["seed"], c["n_ref"], c["seconds"], c["sr"])
         cand = gi.e2e_pairs(c["seed"] + 1, c["n_cand"], c["seconds"], c["sr"], stem_gain=1.3)
         if tag == "stems":
             ref, cand = [x[:, 1] for x in ref], [x[:, 1] for x in cand]
         am.add_reference(ref)
+        if tag == "pca2":                  # second reference batch + evaluate twice: incremental partial_fit path
+            out[f"{tag}/first_apa"] = am.evaluate(cand)["apa"]
+            am.add_reference(gi.e2e_pairs(c["seed"] + 2, 30, c["seconds"], c["sr"], stem_gain=0.8))
         res = am.evaluate(cand)
         for k, v in res.items():
             out[f"{tag}/{k}"] = v
@@ -222,8 +233,28 @@ def gen_e2e():
     np.savez_compressed(os.path.join(HERE, "e2e.npz"), **out)
 
 
+def gen_pca():
+    """The reference's IncrementalPCA wrapper (projection.py:6-46) on its own: first fit, incremental
+    update, transform."""
+    r_proj = importlib.import_module("audio_metrics.projection")
+    out = {"versions": VERSIONS + f"; sklearn {__import__('sklearn').__version__}"}
+    x1 = gi.decaying(61, 500, 24, decades=1.5, shift=0.3)
+    x2 = gi.decaying(62, 300, 24, decades=1.5, scale=1.2, shift=0.1)
+    xt = gi.decaying(63, 40, 24, decades=1.5)
+    pca = r_proj.IncrementalPCA(n_components=6)
+    for step, x in (("fit1", x1), ("fit2", x2)):
+        pca.partial_fit(x.copy())
+        for k in ("components_", "mean_", "var_", "singular_values_", "explained_variance_", "explained_variance_ratio_"):
+            out[f"{step}/{k}"] = np.asarray(getattr(pca, k), dtype=np.float64)
+        out[f"{step}/noise_variance_"] = float(pca.noise_variance_)
+        out[f"{step}/n_samples_seen_"] = int(pca.n_samples_seen_)
+        out[f"{step}/transform"] = pca.transform(xt).numpy()
+    np.savez_compressed(os.path.join(HERE, "pca.npz"), **out)
+    print("pca singular values", out["fit1/singular_values_"], out["fit2/singular_values_"])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["stats", "fad", "kd", "prdc", "apa", "e2e"]
+    which = sys.argv[1:] or ["stats", "fad", "kd", "prdc", "apa", "pca", "e2e"]
     for w in which:
         globals()[f"gen_{w}"]()
     print("done", VERSIONS)

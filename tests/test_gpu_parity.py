@@ -235,6 +235,22 @@ def test_kd_vs_golden(am, golden, name):
     assert np.all(np.abs(mm - g[f"{name}/mmds"]) <= np.maximum(REL * np.abs(g[f"{name}/mmds"]), KD_ABS_FLOOR))
 
 
+@pytest.mark.parametrize("name", [n for n, c in gi.KD_CASES.items() if c[2] <= 3000])
+def test_kd_rbf_vs_golden(am, golden, name):
+    """RBF kernel option (reference kd.py:86-109), against the reference's own outputs."""
+    g = golden("kd")
+    kind, seed, n1, n2, d = gi.KD_CASES[name]
+    f2, f1 = gi.pair(kind, seed, n2, n1, d)
+    keys = [k for k in g.files if k.startswith(f"{name}/rbf_") and k.endswith("/mean")]
+    assert keys
+    for key in keys:
+        sigma = float(key.split("rbf_")[1].split("/")[0])
+        res = am.kid_features_to_metric(dev(f1), dev(f2), kernel_type="rbf", kid_sigma=sigma)
+        for k2, gk in (("kernel_distance_mean", key), ("kernel_distance_std", key.replace("/mean", "/std"))):
+            want = float(g[gk])
+            assert abs(res[k2] - want) <= max(REL * abs(want), KD_ABS_FLOOR), (k2, sigma, res[k2], want)
+
+
 def test_kd_argument_order_and_kwargs(am):
     f2, f1 = gi.pair("randn", 32, 3000, 3000, 64)
     import oracle
@@ -282,3 +298,33 @@ def test_knn_symmetric_fallbacks_agree():
         assert m, res.stdout + res.stderr
         outs.append(m.group(1))
     assert len(set(outs)) == 1, outs
+
+
+# ----------------------------------------------------------------- PCA projection (n_pca)
+def test_incremental_pca_vs_reference(am, golden):
+    """Device PCA against the reference's scikit-learn based IncrementalPCA: first fit, incremental update,
+    projection.  Components are unit vectors with sklearn's sign convention (compared absolutely)."""
+    g = golden("pca")
+    x1 = gi.decaying(61, 500, 24, decades=1.5, shift=0.3)
+    x2 = gi.decaying(62, 300, 24, decades=1.5, scale=1.2, shift=0.1)
+    xt = gi.decaying(63, 40, 24, decades=1.5)
+    pca = am.IncrementalPCA(n_components=6)
+    for step, x in (("fit1", x1), ("fit2", x2)):
+        pca.partial_fit(dev(x))
+        assert pca.n_samples_seen_ == int(g[f"{step}/n_samples_seen_"])
+        np.testing.assert_allclose(pca.singular_values_.cpu().numpy(), g[f"{step}/singular_values_"], rtol=2e-5)
+        np.testing.assert_allclose(pca.components_.cpu().numpy(), g[f"{step}/components_"], atol=5e-5)
+        np.testing.assert_allclose(pca.mean_.cpu().numpy(), g[f"{step}/mean_"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(pca.var_.cpu().numpy(), g[f"{step}/var_"], rtol=1e-5)
+        np.testing.assert_allclose(pca.explained_variance_.cpu().numpy(), g[f"{step}/explained_variance_"], rtol=5e-5)
+        np.testing.assert_allclose(pca.explained_variance_ratio_.cpu().numpy(), g[f"{step}/explained_variance_ratio_"],
+                                   rtol=5e-5)
+        assert abs(pca.noise_variance_ - float(g[f"{step}/noise_variance_"])) <= 5e-5 * float(g[f"{step}/noise_variance_"])
+        y = pca.transform(dev(xt))
+        assert y.dtype == torch.float64 and y.shape == (40, 6)
+        np.testing.assert_allclose(y.cpu().numpy(), g[f"{step}/transform"], atol=1e-4)
+    clone = am.IncrementalPCA(n_components=6)
+    clone.__setstate__(pca.__getstate__())
+    assert torch.equal(clone.transform(dev(xt)).cpu(), pca.transform(dev(xt)).cpu())
+    with pytest.raises(ValueError):
+        am.IncrementalPCA(n_components=30).partial_fit(dev(x1))       # more components than features

@@ -82,6 +82,18 @@ def test_kd(golden, name):
     assert abs(res["kernel_distance_std"] - float(g[f"{name}/std"])) <= 1e-4 * abs(float(g[f"{name}/std"])) + floor
 
 
+@pytest.mark.parametrize("name", [n for n, c in gi.KD_CASES.items() if c[2] <= 3000])
+def test_kd_rbf(golden, name):
+    g = golden("kd")
+    kind, seed, n1, n2, d = gi.KD_CASES[name]
+    f2, f1 = gi.pair(kind, seed, n2, n1, d)
+    for key in [k for k in g.files if k.startswith(f"{name}/rbf_") and k.endswith("/mean")]:
+        sigma = float(key.split("rbf_")[1].split("/")[0])
+        res = oracle.kid_from_features(f1, f2, kernel_type="rbf", sigma=sigma)
+        assert abs(res["kernel_distance_mean"] - float(g[key])) <= 1e-9 + 1e-7 * abs(float(g[key]))
+        assert abs(res["kernel_distance_std"] - float(g[key.replace("/mean", "/std")])) <= 1e-9 + 1e-6 * abs(float(g[key.replace("/mean", "/std")]))
+
+
 def test_kd_first_draws_match_survey():
     """first draws of default_rng(1234) at n=100000."""
     i1, i2 = oracle.draw_subsets(100000, 100000, subsets=1)
