@@ -74,7 +74,7 @@ struct KdEpilogue {
         sum = s;
     }
     __device__ __forceinline__ void finish(int, int64_t, f32x16 (&acc)[2][2]) {
-        if (rbf) {
+        if (rbf) {                                   // compile-time constant per kernel instantiation
             finish_rbf(acc);
             return;
         }
@@ -100,11 +100,13 @@ struct KdEpilogue {
 };
 
 // partial[(s * blocks_per_subset) + b] = weighted tile sum
+// MODE bits: 1 = inner-dimension tail (D % 32 != 0), 2 = RBF kernel, 4 = generic pointer pipeline (matrices >= 4 GiB)
+template <int MODE>
 __global__ void __launch_bounds__(ENGINE_THREADS, 2)
 kd_tile_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ Y, int64_t ldy, int D,
                const int64_t* __restrict__ idx1, const int64_t* __restrict__ idx2, int m, int T, int ntri,
                double gamma, double coef0, int degree, double* __restrict__ partial, int rbf,
-               const double* __restrict__ sub_norm1, const double* __restrict__ sub_norm2) {
+               const double* __restrict__ sub_norm1, const double* __restrict__ sub_norm2, int64_t N1, int64_t N2) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
     const int per_subset = 2 * ntri + T * T;
@@ -128,6 +130,7 @@ kd_tile_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict
     // Kxy[a][b] = k(x_a, y_b): Q rows (register axis) from set 1, P rows (lane axis) from set 2
     const GatherRows qsrc{which == 1 ? Y : X, which == 1 ? ldy : ldx, which == 1 ? i2 : i1, m, tq};
     const GatherRows psrc{which == 0 ? X : Y, which == 0 ? ldx : ldy, which == 0 ? i1 : i2, m, tp};
+    const int64_t n_q_rows = which == 1 ? N2 : N1, n_p_rows = which == 0 ? N1 : N2;
     KdEpilogue epi(L);
     epi.gamma = gamma;
     epi.coef0 = coef0;
@@ -137,10 +140,40 @@ kd_tile_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict
     epi.p0 = tp * TB;
     epi.drop_diag = (which != 2) && (tq == tp);
     epi.sum = 0.0;
-    epi.rbf = rbf;
+    epi.rbf = (MODE & 2) ? 1 : 0;
     epi.qn = rbf ? (which == 1 ? sub_norm2 : sub_norm1) + (int64_t)s * m : nullptr;
     epi.pn = rbf ? (which == 0 ? sub_norm1 : sub_norm2) + (int64_t)s * m : nullptr;
-    tile_pipeline(qsrc, psrc, 1, D, lds, L, epi);
+    // single tile per workgroup; rows gathered through the subset's index list.  One buffer descriptor spans the
+    // whole matrix (the 32-bit offsets need N*ld*4 < 4 GiB; larger sets take the generic pointer pipeline)
+    if constexpr ((MODE & 4) == 0) {
+        const int srow = L.tid >> 3, scol = (L.tid & 7) * 4;
+        auto make = [&](const GatherRows& g, int64_t n_rows) {
+            TileAddr a;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(g.base) & 0xffffffffu));
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(g.base) >> 32));
+            const unsigned bytes = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)n_rows * (uint64_t)g.ld * 4u));
+            a.rs.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((static_cast<uintptr_t>(hi) << 32) | lo), 0,
+                                                          (int)bytes, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = g.tile * TB + q * 32 + srow;
+                a.vo[q] = p < g.m ? (unsigned)((g.idx[p] * g.ld + scol) * 4) : 0xffffffffu;   // padded rows read as 0
+            }
+            return a;
+        };
+        const TileAddr qa = make(qsrc, n_q_rows), pa = make(psrc, n_p_rows);
+        auto qaddr = [&](int t) {
+            TileAddr a = qa;
+            if (t > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a.vo[q] = 0xffffffffu;   // the pipeline prefetches one tile past the end
+            }
+            return a;
+        };
+        addr_pipeline_early<0, (MODE & 1) != 0>(qaddr, pa, 1, D, 0, lds, L, epi);
+    } else {
+        tile_pipeline(qsrc, psrc, 1, D, lds, L, epi);
+    }
 
     double v = epi.sum;
 #pragma unroll
@@ -217,15 +250,26 @@ static int run_kd(const float* X, int64_t N1, int64_t ldx, const float* Y, int64
         hipLaunchKernelGGL(kd_gather_norms_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st, Y, ldy, D, idx2, total, n2);
         AM_LAUNCH_CHECK();
     }
-    static bool attr_done = false;
-    if (!attr_done) {
-        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_tile_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)KD_LDS_BYTES));
-        attr_done = true;
+    const bool generic = (uint64_t)N1 * (uint64_t)ldx * 4u >= 0xffffffffull || (uint64_t)N2 * (uint64_t)ldy * 4u >= 0xffffffffull;
+    const int mode = (((D % BK) != 0 && !generic) ? 1 : 0) | (rbf ? 2 : 0) | (generic ? 4 : 0);
+    auto launch = [&](auto kernel) -> int {
+        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)KD_LDS_BYTES));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)((int64_t)S * per_subset)), dim3(ENGINE_THREADS), KD_LDS_BYTES, st,
+                           X, ldx, Y, ldy, D, idx1, idx2, m, T, ntri, gamma, coef0, degree, partial, rbf, n1, n2, N1, N2);
+        AM_LAUNCH_CHECK();
+        return AM_OK;
+    };
+    int rc;
+    switch (mode) {
+        case 0: rc = launch(&kd_tile_kernel<0>); break;
+        case 1: rc = launch(&kd_tile_kernel<1>); break;
+        case 2: rc = launch(&kd_tile_kernel<2>); break;
+        case 3: rc = launch(&kd_tile_kernel<3>); break;
+        case 4: rc = launch(&kd_tile_kernel<4>); break;
+        default: rc = launch(&kd_tile_kernel<6>); break;
     }
-    hipLaunchKernelGGL(kd_tile_kernel, dim3((unsigned)((int64_t)S * per_subset)), dim3(ENGINE_THREADS), KD_LDS_BYTES, st,
-                       X, ldx, Y, ldy, D, idx1, idx2, m, T, ntri, gamma, coef0, degree, partial, rbf, n1, n2);
-    AM_LAUNCH_CHECK();
+    if (rc != AM_OK) return rc;
     hipLaunchKernelGGL(kd_finish_kernel, dim3((unsigned)ceil_div(S, 64)), dim3(64), 0, st, partial, S, m, T, ntri,
                        out_mmd);
     AM_LAUNCH_CHECK();

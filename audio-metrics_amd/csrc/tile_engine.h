@@ -325,12 +325,64 @@ struct CyclicTiles {              // (start + t) mod T : the cyclic half-range u
     }
 };
 
+// How the 4 staging rows of a thread are addressed for one 128-row operand tile: a buffer descriptor plus one
+// 32-bit byte offset per row.  Dense tiles use a per-tile descriptor (rows past the end fall outside it and read
+// as 0); gathered tiles (kernel distance subsets) use one descriptor for the whole matrix and per-row offsets
+// through the index list, with 0xffffffff for padded rows.
+struct TileAddr {
+    TileRsrc rs;
+    unsigned vo[4];
+};
+
+template <int V, bool KTAIL, class QAddrFn, class Epi>
+__device__ __forceinline__ void addr_pipeline_early(const QAddrFn& qaddr, const TileAddr& paddr, int ntiles, int D,
+                                                    int64_t q_tiles_total, float* __restrict__ lds, const LaneInfo& L,
+                                                    Epi& epi);
+
 template <int V, bool KTAIL, class TileMap, class Epi>
 __device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q, int64_t nq, int64_t ldq,
                                                      const TileMap& tmap,
                                                      const float* __restrict__ P, int64_t np, int64_t ldp, int64_t prow0,
                                                      int ntiles, int D, float* __restrict__ lds, const LaneInfo& L,
                                                      Epi& epi) {
+    const int srow = L.tid >> 3;
+    const int scol = (L.tid & 7) * 4;
+    TileAddr pa;
+    pa.rs = make_tile_rsrc(P, ldp, np, prow0);
+    unsigned voq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        voq[q] = (unsigned)(((int64_t)(q * 32 + srow) * ldq + scol) * 4);
+        pa.vo[q] = (unsigned)(((int64_t)(q * 32 + srow) * ldp + scol) * 4);
+    }
+    // past this workgroup's last tile: row0 = nq -> zero valid rows -> every load returns 0
+    auto qaddr = [&](int t) {
+        TileAddr a;
+        a.rs = make_tile_rsrc(Q, ldq, nq, t < ntiles ? tmap(t) * TB : nq);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a.vo[q] = voq[q];
+        return a;
+    };
+    struct AbsTile {                 // the epilogue wants absolute Q tile indices
+        const TileMap& m;
+        int n;
+        int64_t past;
+        __device__ __forceinline__ int64_t operator()(int t) const { return t < n ? m(t) : past; }
+    };
+    const AbsTile abs_tile{tmap, ntiles, (nq + TB - 1) / TB};
+    struct Shim {
+        Epi& e;
+        const AbsTile& at;
+        __device__ __forceinline__ void aux_issue(int t, int64_t) { e.aux_issue(t, at(t)); }
+        __device__ __forceinline__ void aux_commit(int t) { e.aux_commit(t); }
+        __device__ __forceinline__ void finish(int t, int64_t, f32x16 (&acc)[2][2]) { e.finish(t, at(t), acc); }
+    } shim{epi, abs_tile};
+    addr_pipeline_early<V, KTAIL>(qaddr, pa, ntiles, D, 0, lds, L, shim);
+}
+
+template <int V, bool KTAIL, class QAddrFn, class Epi>
+__device__ __forceinline__ void addr_pipeline_early(const QAddrFn& qaddr, const TileAddr& paddr, int ntiles, int D,
+                                                    int64_t, float* __restrict__ lds, const LaneInfo& L, Epi& epi) {
     const int nk = (D + BK - 1) / BK;
     const int G = ntiles * nk;
     const int srow = L.tid >> 3;
@@ -338,30 +390,22 @@ __device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q
     f32x16 acc[2][2];
     zero_acc(acc);
 
-    const TileRsrc prs = make_tile_rsrc(P, ldp, np, prow0);
-    unsigned voq[4], vop[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        voq[q] = (unsigned)(((int64_t)(q * 32 + srow) * ldq + scol) * 4);
-        vop[q] = (unsigned)(((int64_t)(q * 32 + srow) * ldp + scol) * 4);
-    }
     // (tile, k-slab) of the stage being fetched; runs two stages ahead of the compute stage
     int ft = 0, fkt = 0;
-    TileRsrc qrs = make_tile_rsrc(Q, ldq, nq, tmap(0) * TB);
+    TileAddr qa = qaddr(0);
     auto fetch_advance = [&]() {
         if (++fkt == nk) {
             fkt = 0;
             ++ft;
-            // past this workgroup's last tile: row0 = nq -> zero valid rows -> every load returns 0
-            qrs = make_tile_rsrc(Q, ldq, nq, ft < ntiles ? tmap(ft) * TB : nq);
+            qa = qaddr(ft);
         }
     };
     auto issue = [&](f32x4 (&r)[8]) {
         const unsigned so = (unsigned)(fkt * BK * 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            r[q] = rsrc_load(qrs, voq[q], so);
-            r[4 + q] = rsrc_load(prs, vop[q], so);
+            r[q] = rsrc_load(qa.rs, qa.vo[q], so);
+            r[4 + q] = rsrc_load(paddr.rs, paddr.vo[q], so);
         }
         fetch_advance();
     };
@@ -384,7 +428,7 @@ __device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q
     f32x4 ra[8], rb[8];
     issue(ra);                                     // stage 0
     issue(rb);                                     // stage 1 (an empty descriptor if there is none)
-    epi.aux_issue(0, tmap(0));
+    epi.aux_issue(0, 0);
     commit(ra, 0, 0);
     epi.aux_commit(0);
     __syncthreads();
@@ -400,7 +444,7 @@ __device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q
         const int nt_ = last_k ? t + 1 : t;
         const int nkt = last_k ? 0 : kt + 1;
         issue(ri);
-        if (last_k) epi.aux_issue(nt_, nt_ < ntiles ? tmap(nt_) : (nq + TB - 1) / TB);
+        if (last_k) epi.aux_issue(nt_, nt_);
         const float* sq = lds + (g & 1) * STAGE_FLOATS + (L.wm * 64 + L.r) * LDK + L.h * 4;
         const float* sp = lds + (g & 1) * STAGE_FLOATS + TILE_FLOATS + (L.wn * 64 + L.r) * LDK + L.h * 4;
         FragSet f0 = read_frags(sq, sp, 0);
@@ -413,7 +457,7 @@ __device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q
         mfma_chunk(f0, acc);
         mfma_chunk(f1, acc);
         if (last_k) {
-            epi.finish(t, tmap(t), acc);
+            epi.finish(t, t, acc);
             zero_acc(acc);
             epi.aux_commit(nt_);
         }

@@ -115,18 +115,27 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
     ref_counts, cand_counts = [c[0] for c in allc], [c[1] for c in allc]
     n_ref, n_cand = sum(ref_counts), sum(cand_counts)
     d = ref_local.shape[1]
-    result = {}
-
-    if "fad" in metrics:
-        mu_r, cov_r = global_stats(ref_local, n_ref, ops, world, group)
-        mu_c, cov_c = global_stats(cand_local, n_cand, ops, world, group)
-        result["fad"] = ops.frechet(mu_c, cov_c, mu_r, cov_r)["fd"]
-
+    # Issue order: the long asynchronous PRDC chain first, then the host-side preparation of the KD index
+    # table (numpy PCG64 draws, ~10 ms) and the FAD solver (which synchronises to read its convergence
+    # state) while the GPU is busy.  The result dict keeps the reference's key order.
     need_full = ("kd" in metrics) or ("prdc" in metrics)
     if need_full:
         ref_full = _all_gather_rows(ref_local, ref_counts, world, group)
         cand_full = _all_gather_rows(cand_local, cand_counts, world, group)
 
+    prdc_pending = None
+    if "prdc" in metrics:
+        k = nearest_k
+        r_ref_l, _ = sharded_radii(ref_local, ref_full, ref_counts, k, ops, world, rank, group)
+        _, r_cand = sharded_radii(cand_local, cand_full, cand_counts, k, ops, world, rank, group)
+        col, rany, rmin = ops.prdc_counts(ref_local, cand_full, r_ref_l, r_cand)
+        _all_reduce(col, world, group)
+        tot = ops.prdc_reduce(col, rany, rmin, r_ref_l)        # [n_prec, n_rec(local), sum_cnt, n_cov(local)]
+        rows = tot[[1, 3]].clone()
+        _all_reduce(rows, world, group)
+        prdc_pending = (tot, rows, k)
+
+    kd_pending = None
     if "kd" in metrics:
         m = kid_subset_size
         if m >= min(n_ref, n_cand):
@@ -139,19 +148,19 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
                                torch.as_tensor(idx2[mine]).to(dev), 1.0 / d, KID_COEF0, KID_DEGREE)
             mmds[torch.as_tensor(mine, device=dev)] = part
         _all_reduce(mmds, world, group)
-        mm = mmds.cpu().numpy()
+        kd_pending = mmds
+
+    result = {}
+    if "fad" in metrics:
+        mu_r, cov_r = global_stats(ref_local, n_ref, ops, world, group)
+        mu_c, cov_c = global_stats(cand_local, n_cand, ops, world, group)
+        result["fad"] = ops.frechet(mu_c, cov_c, mu_r, cov_r)["fd"]
+    if kd_pending is not None:
+        mm = kd_pending.cpu().numpy()
         result["kernel_distance_mean"] = float(np.mean(mm))
         result["kernel_distance_std"] = float(np.std(mm))
-
-    if "prdc" in metrics:
-        k = nearest_k
-        r_ref_l, _ = sharded_radii(ref_local, ref_full, ref_counts, k, ops, world, rank, group)
-        _, r_cand = sharded_radii(cand_local, cand_full, cand_counts, k, ops, world, rank, group)
-        col, rany, rmin = ops.prdc_counts(ref_local, cand_full, r_ref_l, r_cand)
-        _all_reduce(col, world, group)
-        tot = ops.prdc_reduce(col, rany, rmin, r_ref_l)        # [n_prec, n_rec(local), sum_cnt, n_cov(local)]
-        rows = tot[[1, 3]].clone()
-        _all_reduce(rows, world, group)
+    if prdc_pending is not None:
+        tot, rows, k = prdc_pending
         n_prec, sum_cnt = int(tot[0]), int(tot[2])
         n_rec, n_cov = int(rows[0]), int(rows[1])
         result.update(precision=n_prec / n_cand, recall=n_rec / n_ref,
