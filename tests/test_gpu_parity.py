@@ -328,3 +328,27 @@ def test_incremental_pca_vs_reference(am, golden):
     assert torch.equal(clone.transform(dev(xt)).cpu(), pca.transform(dev(xt)).cpu())
     with pytest.raises(ValueError):
         am.IncrementalPCA(n_components=30).partial_fit(dev(x1))       # more components than features
+
+
+def test_knn_and_prdc_on_clustered_data_bit_exact(am):
+    """Adversarial input for the filters of the symmetric kernel: 20 tight clusters (intra-cluster squared
+    distances ~1e-4 of the squared norms, so the matmul-form d2 is dominated by cancellation noise, clamps to 0
+    and ties abound).  Radii, counts and flags must still equal the C model bit for bit."""
+    from oracle import exact
+    rng = np.random.default_rng(123)
+    centers = rng.standard_normal((20, 128)).astype(np.float32)
+    lab = rng.integers(0, 20, 8600)
+    x = (centers[lab] + 1e-3 * rng.standard_normal((8600, 128))).astype(np.float32)
+    y = (centers[rng.integers(0, 20, 8300)] + 1.5e-3 * rng.standard_normal((8300, 128))).astype(np.float32)
+    k = 5
+    rx = am.nearest_neighbour_distances(dev(x), k)
+    ry = am.nearest_neighbour_distances(dev(y), k)
+    ex, ey = exact.knn_radii(x, k), exact.knn_radii(y, k)
+    assert np.array_equal(rx.cpu().numpy().view(np.uint32), ex.view(np.uint32))
+    assert np.array_equal(ry.cpu().numpy().view(np.uint32), ey.view(np.uint32))
+    col, rany, rmin = am.hip_ops.prdc_counts(dev(x), dev(y), rx, ry)
+    ecol, eany, emin = exact.prdc_counts(x, y, ex, ey)
+    assert np.array_equal(col.cpu().numpy(), ecol)
+    assert np.array_equal(rany.cpu().numpy(), eany)
+    assert np.array_equal(rmin.cpu().numpy().view(np.uint32), emin.view(np.uint32))
+    assert int(col.sum()) > len(y)
