@@ -27,6 +27,15 @@ import torch.distributed as dist
 from .metrics.kd import subset_indices, KID_SUBSETS, KID_SUBSET_SIZE, KID_DEGREE, KID_COEF0
 
 
+def _upload(array, dev):
+    """Host array -> device without blocking the host behind the work already queued on the stream
+    (a pageable copy is synchronous and stream-ordered; a pinned one can be asynchronous)."""
+    t = torch.as_tensor(np.ascontiguousarray(array))
+    if getattr(dev, "type", "cpu") != "cuda":
+        return t
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 def _world(group):
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(group), dist.get_rank(group)
@@ -131,7 +140,7 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
         col, rany, rmin = ops.prdc_counts(ref_local, cand_full, r_ref_l, r_cand)
         _all_reduce(col, world, group)
         tot = ops.prdc_reduce(col, rany, rmin, r_ref_l)        # [n_prec, n_rec(local), sum_cnt, n_cov(local)]
-        rows = tot[[1, 3]].clone()
+        rows = torch.stack((tot[1], tot[3]))                   # (no host-side index list: that would be a blocking H2D copy)
         _all_reduce(rows, world, group)
         prdc_pending = (tot, rows, k)
 
@@ -141,12 +150,11 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
         if m >= min(n_ref, n_cand):
             m = max(1, min(n_ref, n_cand) // 2)
         idx1, idx2 = subset_indices(n_cand, n_ref, kid_subsets, m, rng_seed)     # features_1 = candidate
-        mine = list(range(rank, kid_subsets, world))
         mmds = torch.zeros(kid_subsets, dtype=torch.float64, device=dev)
-        if mine:
-            part = ops.kd_poly(cand_full, ref_full, torch.as_tensor(idx1[mine]).to(dev),
-                               torch.as_tensor(idx2[mine]).to(dev), 1.0 / d, KID_COEF0, KID_DEGREE)
-            mmds[torch.as_tensor(mine, device=dev)] = part
+        if rank < kid_subsets:                                 # this rank's subsets: rank, rank + world, ...
+            part = ops.kd_poly(cand_full, ref_full, _upload(idx1[rank::world], dev), _upload(idx2[rank::world], dev),
+                               1.0 / d, KID_COEF0, KID_DEGREE)
+            mmds[rank::world] = part
         _all_reduce(mmds, world, group)
         kd_pending = mmds
 
