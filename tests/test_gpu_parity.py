@@ -352,3 +352,49 @@ def test_knn_and_prdc_on_clustered_data_bit_exact(am):
     assert np.array_equal(rany.cpu().numpy(), eany)
     assert np.array_equal(rmin.cpu().numpy().view(np.uint32), emin.view(np.uint32))
     assert int(col.sum()) > len(y)
+
+
+# ----------------------------------------------------------------- scale and odd shapes
+def test_prdc_self_consistency_300k(am):
+    """Beyond the BASELINE size (config 4 shards 1M rows over 8 GPUs): 300k x 256 on one GPU exercises the
+    64-bit indexing, the larger window / queue plans and the candidate buffers of the symmetric kernel."""
+    torch.manual_seed(1)
+    x = torch.randn(300000, 256, device="cuda:0")
+    a = am.AudioMetricsData(True)
+    a.add(x)
+    res = am.prdc(a, a, 3)
+    assert (res["precision"], res["recall"], res["coverage"]) == (1.0, 1.0, 1.0)
+    total = round(res["density"] * 3 * 300000)
+    assert 900000 - 100 <= total <= 900000, total
+
+
+@pytest.mark.parametrize("n_ref,n_cand,d,k", [(2, 3, 1, 1), (5, 4, 2, 2), (130, 127, 3, 4), (129, 257, 33, 7),
+                                              (64, 1000, 7, 1), (1000, 64, 130, 9)])
+def test_prdc_odd_shapes_bit_exact(am, n_ref, n_cand, d, k):
+    """Tiny sets, D of 1..3, rows just past a tile edge, very unequal set sizes."""
+    from oracle import exact
+    ref, cand = gi.pair("shifted", 300 + d, n_ref, n_cand, d)
+    a, b = amd_of(am, ref), amd_of(am, cand)
+    res = am.prdc(a, b, k)
+    want, aux = exact.prdc(ref, cand, k)
+    assert np.array_equal(a.get_radii(k).cpu().numpy().view(np.uint32), aux["r_ref"].view(np.uint32))
+    assert np.array_equal(b.get_radii(k).cpu().numpy().view(np.uint32), aux["r_cand"].view(np.uint32))
+    assert res == want
+
+
+def test_embedding_buffer_growth_and_views(am):
+    """Many small adds (amortised-doubling HBM buffer) keep row order, stats and cached radii semantics."""
+    x = gi.randn(400, 3000, 20)
+    a = am.AudioMetricsData(True)
+    s = 0
+    for b in [1, 2, 3, 500, 31, 700, 1, 1762]:
+        a.add(dev(x[s:s + b]))
+        s += b
+    assert s == 3000 and a.n == 3000
+    np.testing.assert_array_equal(a.embeddings.cpu().numpy(), x)
+    r1 = a.get_radii(3)
+    a.add(dev(x[:10]))                              # reference quirk: the radii cache is NOT invalidated
+    assert a.get_radii(3) is r1 and a.embeddings.shape[0] == 3010
+    b = am.AudioMetricsData(False)
+    b.add(dev(x))
+    assert b.embeddings is None and b.get_radii(3) is None
