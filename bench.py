@@ -65,6 +65,27 @@ def cpu_baseline(ref, cand, k, sample_rows=8000):
     }
 
 
+def warm_evaluate(am, ref, cand, k, steps):
+    """SURVEY 8(d) 'warm' figure (never `value`): the reference side is cached the way a second
+    AudioMetrics.evaluate() finds it (statistics and radii_k kept on the reference object, data.py:60-66), so a step
+    recomputes only the candidate's statistics and radii, the cross counts, KD and FAD."""
+    reference = am.AudioMetricsData(True)
+    reference.add(ref)
+    reference.get_radii(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        candidate = am.AudioMetricsData(True)
+        candidate.add(cand)
+        res = {"fad": am.frechet_distance(candidate, reference)}
+        res.update(am.kernel_distance(candidate, reference))
+        res.update(am.prdc(reference, candidate, k))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": (len(ref) + len(cand)) / dt, "unit": "embeddings/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "what": "reference statistics and radii cached (second evaluate() against the same reference)", "result": res}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,11 +103,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Test hooks (tests/test_gpu_distributed.py runs the N=2 launch on a 1-GPU box): AM_BENCH_DEVICE pins every
+    # rank to one device, AM_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on the same GPU.
+    device_index = int(os.environ.get("AM_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("AM_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import audio_metrics_amd as am
     from audio_metrics_amd import hip_ops as ops
@@ -126,18 +154,23 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        calls, ms = kern["am_knn_radii_f32"]
+        # Dominant kernel: the k-NN tile kernel.  One GPU: am_knn_radii_f32 (symmetric or general form inside);
+        # several GPUs and an eligible shape: the partitioned symmetric form, am_knn_sym_part_f32.
+        part_form = "am_knn_sym_part_f32" in kern
+        knn_entry = "am_knn_sym_part_f32" if part_form else "am_knn_radii_f32"
+        calls, ms = kern[knn_entry]
         knn_ms = ms / calls
         ccalls, cms = kern["am_prdc_counts_f32"]
         rows_local = hi - lo
-        flop_per_launch = 2.0 * rows_local * n * d            # algorithmic: one dot product per (row, column)
+        flop_per_launch = 2.0 * rows_local * n * d            # algorithmic: one dot product per (row, column) of this rank's share
         achieved = flop_per_launch / (knn_ms * 1e-3) / 1e12
-        # The self-distance matrix is bitwise symmetric; on one GPU the k-NN kernel multiplies only a cyclic half
-        # of the tile pairs (+ a 1/32 column sample for bounds), so its ALGORITHMIC rate can exceed the MFMA peak.
+        # The self-distance matrix is bitwise symmetric; the symmetric kernel multiplies only a cyclic half of the
+        # tile pairs (+ a sampled pre-pass for bounds), so its ALGORITHMIC rate can exceed the MFMA peak.
         t_tiles = (n + 127) // 128
-        sym = world == 1 and n >= 8192 and d >= 128
-        # cyclic half of the tile pairs + the sampling pre-pass (1/16 of the column tiles for the rows of the top windows)
-        exec_frac_of_alg = ((t_tiles // 2 + 1) / t_tiles + 0.2 / 16) if sym else 1.0
+        sym = part_form or (world == 1 and n >= 8192 and d >= 128)
+        # cyclic half of the tile pairs; one GPU adds the sampling pre-pass (1/16 of the column tiles for the rows of
+        # the top windows), the partitioned form runs its pre-pass in a separate entry point (am_knn_bounds_f32)
+        exec_frac_of_alg = ((t_tiles // 2 + 1) / t_tiles + (0.0 if part_form else 0.2 / 16)) if sym else 1.0
         traffic = None
         try:                                                # PMC-derived bytes per launch, recorded from profiles/
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
@@ -163,7 +196,7 @@ def main():
                        "sharding": f"rows/{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": ("knn_sym_kernel" if sym else "knn_partial_kernel") + " (am_knn_radii_f32, 2 launches/step)",
+                         "kernel": ("knn_sym_kernel" if sym else "knn_partial_kernel") + f" ({knn_entry}, 2 launches/step)",
                          "launch_ms": knn_ms, "flop_per_launch": flop_per_launch,
                          "executed_flop_per_launch": flop_per_launch * exec_frac_of_alg,
                          "executed_frac": achieved * exec_frac_of_alg / F32_MFMA_PEAK_TFLOPS,
@@ -177,6 +210,8 @@ def main():
                              "frac": 2.0 * rows_local * n * d / (cms / ccalls * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS},
             "result": result,
         }
+        if world == 1:
+            out["warm"] = warm_evaluate(am, ref, cand, k, max(1, min(args.steps, 3)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ref, cand, k)
         print(json.dumps(out), flush=True)

@@ -122,3 +122,38 @@ def test_sharded_evaluate_takes_symmetric_path():
     assert results[0] == results[1]
     for key in ("precision", "recall", "density", "coverage"):
         assert results[0][key] == single[key], key
+
+
+@pytest.mark.parametrize("rows,dim", [(3000, 64), (9000, 128)])
+def test_bench_two_rank_launch(rows, dim):
+    """bench.py launched the way the driver launches it for N=2 (torch.distributed.run, one JSON line from
+    rank 0).  Both ranks share cuda:0 over gloo (bench.py's AM_BENCH_* test hooks); 9000x128 is eligible for the
+    partitioned symmetric k-NN, 3000x64 takes the general kernel on row shards.  The 2-rank result must equal the
+    1-rank result of the same command."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "1", "--warmup", "1", "--rows", str(rows), "--dim", str(dim), "--no-cpu-baseline"]
+    env = dict(os.environ, AM_BENCH_DEVICE="0", AM_BENCH_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, two.stdout[-2000:]
+    out2 = json.loads(lines[0])
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    out1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert out2["n_gpus"] == 2 and out1["n_gpus"] == 1
+    for key in ("metric", "value", "unit", "ms_per_step", "scaling", "roofline", "config"):
+        assert key in out2
+    assert out2["roofline"]["frac"] > 0
+    if rows >= 8192 and dim >= 128:
+        assert "am_knn_sym_part_f32" in out2["roofline"]["kernel"]
+    for key in ("precision", "recall", "density", "coverage"):
+        assert out2["result"][key] == out1["result"][key], key
+    assert abs(out2["result"]["fad"] - out1["result"]["fad"]) <= 1e-5 * abs(out1["result"]["fad"])
+    assert abs(out2["result"]["kernel_distance_mean"] - out1["result"]["kernel_distance_mean"]) <= 1e-9
