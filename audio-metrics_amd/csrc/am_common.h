@@ -40,6 +40,10 @@ void set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// optional hipEvent bracket around the tile kernels (am_kernel_clock_enable / am_kernel_clock_read)
+void clock_begin(int kernel, hipStream_t st);
+void clock_end(int kernel, hipStream_t st);
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -2,6 +2,10 @@
 #include "am_common.h"
 #include <stdarg.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace am {
 static thread_local char g_err[512] = "";
@@ -12,7 +16,74 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- kernel clock ---------------------------------------------------------------------------------
+namespace {
+constexpr int N_CLOCKED = 2;
+std::atomic<int> g_clock_on{0};
+std::mutex g_clock_mu;
+struct ClockRecord {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> done;   // begin/end pairs, both recorded
+    hipEvent_t open = nullptr;                              // begin recorded, end pending
+};
+ClockRecord g_clock[N_CLOCKED];
+}  // namespace
+
+void clock_begin(int kernel, hipStream_t st) {
+    if (!g_clock_on.load(std::memory_order_relaxed) || kernel < 0 || kernel >= N_CLOCKED) return;
+    std::lock_guard<std::mutex> lock(g_clock_mu);
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    if (hipEventRecord(e, st) != hipSuccess) { (void)hipEventDestroy(e); return; }
+    if (g_clock[kernel].open) (void)hipEventDestroy(g_clock[kernel].open);
+    g_clock[kernel].open = e;
+}
+
+void clock_end(int kernel, hipStream_t st) {
+    if (!g_clock_on.load(std::memory_order_relaxed) || kernel < 0 || kernel >= N_CLOCKED) return;
+    std::lock_guard<std::mutex> lock(g_clock_mu);
+    ClockRecord& r = g_clock[kernel];
+    if (!r.open) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, st) == hipSuccess) {
+        r.done.emplace_back(r.open, e);
+    } else {
+        (void)hipEventDestroy(r.open);
+    }
+    r.open = nullptr;
+}
 }  // namespace am
+
+extern "C" int am_kernel_clock_enable(int on) {
+    am::g_clock_on.store(on ? 1 : 0);
+    return AM_OK;
+}
+
+extern "C" int am_kernel_clock_read(int kernel, int64_t* launches, double* total_ms) {
+    AM_REQUIRE(kernel >= 0 && kernel < am::N_CLOCKED, AM_ERR_BAD_ARG, "am_kernel_clock_read: unknown kernel id %d", kernel);
+    AM_REQUIRE(launches != nullptr && total_ms != nullptr, AM_ERR_BAD_ARG, "am_kernel_clock_read: null output pointer");
+    std::lock_guard<std::mutex> lock(am::g_clock_mu);
+    am::ClockRecord& r = am::g_clock[kernel];
+    int64_t n = 0;
+    double ms = 0.0;
+    int rc = AM_OK;
+    for (auto& pr : r.done) {
+        float t = 0.f;
+        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) {
+            ++n;
+            ms += t;
+        } else {
+            am::set_error("am_kernel_clock_read: event query failed");
+            rc = AM_ERR_HIP;
+        }
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    r.done.clear();
+    *launches = n;
+    *total_ms = ms;
+    return rc;
+}
 
 extern "C" const char* am_version(void) { return "audio_metrics_hip 0.1.0 (gfx950)"; }
 

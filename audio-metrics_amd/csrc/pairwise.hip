@@ -817,8 +817,10 @@ static int launch_knn_vt(const float* X, int64_t N, int64_t ldx, const float* xn
         attr_done = true;
     }
     const int64_t blocks = ceil_div(N, TB) * nchunks;
+    if (qstride == 1) clock_begin(AM_KERNEL_KNN, st);         // main pass only; qstride > 1 is the sampled pre-pass
     hipLaunchKernelGGL((knn_partial_kernel<KCAP, V, KTAIL>), dim3((unsigned)blocks), dim3(ENGINE_THREADS),
                        PAIRWISE_LDS_BYTES, st, X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial);
+    if (qstride == 1) clock_end(AM_KERNEL_KNN, st);
     AM_LAUNCH_CHECK();
     return AM_OK;
 }
@@ -870,9 +872,11 @@ static int launch_knn_sym(const float* X, int64_t N, int64_t ld, const float* xn
     auto launch = [&](auto kernel) -> int {
         AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)PAIRWISE_LDS_BYTES + 16));
+        clock_begin(AM_KERNEL_KNN, st);
         hipLaunchKernelGGL(kernel, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st,
                            X, N, ld, xn, thr, D, win_tiles, nwin, per_win, k1, partial, cand, cnt, cap, wgq, qcap, wgq_count,
                            env_int("AM_KNN_SYM_ABL", 0), part, nparts);
+        clock_end(AM_KERNEL_KNN, st);
         AM_LAUNCH_CHECK();
         return AM_OK;
     };
@@ -1260,8 +1264,10 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
     auto launch = [&](auto kernel) -> int {
         AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)PAIRWISE_LDS_BYTES));
+        clock_begin(AM_KERNEL_PRDC_CROSS, st);
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES, st, R, Nr, ldr, rn, rt,
                            C, Nc, ldc, cn, ct, D, nchunks, out_col_count, rmin, rany, env_int("AM_CROSS_ORDER", 0));
+        clock_end(AM_KERNEL_PRDC_CROSS, st);
         AM_LAUNCH_CHECK();
         return AM_OK;
     };

@@ -48,6 +48,22 @@ class KernelTimer:
         return out
 
 
+KERNEL_KNN, KERNEL_PRDC_CROSS = 0, 1        # enum am_clocked_kernel
+
+
+def kernel_clock_enable(on=True):
+    """Bracket every launch of the two tile kernels with hipEvents inside the library (bench.py)."""
+    _lib.check(_lib.load().am_kernel_clock_enable(1 if on else 0), "am_kernel_clock_enable")
+
+
+def kernel_clock_read(kernel):
+    """(launches, total_ms) of the clocked kernel since the last read; waits for the recorded launches."""
+    import ctypes
+    n, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+    _lib.check(_lib.load().am_kernel_clock_read(int(kernel), ctypes.byref(n), ctypes.byref(ms)), "am_kernel_clock_read")
+    return n.value, ms.value
+
+
 def _call(lib, name, *args):
     timer = KernelTimer.active
     if timer is not None:

@@ -175,6 +175,19 @@ int am_prdc_reduce(const int32_t* col_count, int64_t Nc,
                    const uint8_t* row_any, const float* row_min, const float* r_ref, int64_t Nr,
                    int64_t* out4, am_stream_t stream);
 
+/* ---- optional kernel clock (benchmark support; bench.py's roofline) --------------------------------
+ * When enabled, the library brackets every launch of the two tile kernels with a hipEvent pair recorded on
+ * the caller's stream, so a benchmark can report the duration of exactly that kernel (the figure
+ * `rocprofv3 --kernel-trace --stats` prints for it) rather than of the whole entry point.
+ *   AM_KERNEL_KNN         knn_sym_kernel, or knn_partial_kernel's main pass when the general form runs
+ *                         (the sampled pre-pass of the symmetric form is not counted)
+ *   AM_KERNEL_PRDC_CROSS  prdc_cross_kernel
+ * am_kernel_clock_read waits for the recorded launches, returns their count and summed duration in
+ * milliseconds, and resets that kernel's record.  Disabled by default; no cost when disabled. */
+enum am_clocked_kernel { AM_KERNEL_KNN = 0, AM_KERNEL_PRDC_CROSS = 1 };
+int am_kernel_clock_enable(int on);
+int am_kernel_clock_read(int kernel, int64_t* launches, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,9 @@ PRDC_CASES = {
     "unit_2000_512_k10": ("unit", 44, 2000, 2000, 512, 10),
     "ragged_300_500_24_k3": ("shifted", 45, 300, 500, 24, 3),
     "tiny_12_9_8_k2": ("shifted", 46, 12, 9, 8, 2),
+    # N >= 8192 and D >= 128: the sets the HIP path sends through the symmetric k-NN kernel
+    "randn_8300_128_k5": ("randn", 47, 8300, 8300, 128, 5),
+    "unit_8300_8200_128_k10": ("unit", 48, 8300, 8200, 128, 10),
 }
 
 
