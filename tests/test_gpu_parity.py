@@ -397,3 +397,32 @@ def test_embedding_buffer_growth_and_views(am):
     b = am.AudioMetricsData(False)
     b.add(dev(x))
     assert b.embeddings is None and b.get_radii(3) is None
+
+
+def test_kernel_clock_counts_tile_kernel_launches(am):
+    """am_kernel_clock_*: off by default (nothing recorded); when on, one record per tile-kernel launch with a positive
+    duration no longer than the host-side bracket of the whole entry point; reading resets the record."""
+    from audio_metrics_amd import hip_ops as ops
+    x = torch.as_tensor(gi.randn(71, 4000, 64)).cuda()
+    y = torch.as_tensor(gi.randn(72, 3000, 64)).cuda()
+    ops.kernel_clock_enable(False)
+    r_off = ops.knn_radii(x, 3)
+    assert ops.kernel_clock_read(ops.KERNEL_KNN) == (0, 0.0)
+    ops.kernel_clock_enable(True)
+    try:
+        with ops.KernelTimer() as timer:
+            r_x = ops.knn_radii(x, 3)
+            r_y = ops.knn_radii(y, 3)
+            ops.prdc_counts(x, y, r_x, r_y)
+        outer = timer.summary()
+        n_knn, ms_knn = ops.kernel_clock_read(ops.KERNEL_KNN)
+        n_cross, ms_cross = ops.kernel_clock_read(ops.KERNEL_PRDC_CROSS)
+        assert n_knn == 2 and n_cross == 1
+        assert 0.0 < ms_knn <= outer["am_knn_radii_f32"][1] * 1.05
+        assert 0.0 < ms_cross <= outer["am_prdc_counts_f32"][1] * 1.05
+        assert ops.kernel_clock_read(ops.KERNEL_KNN) == (0, 0.0)
+        assert torch.equal(r_off, r_x)                       # the clock does not change results
+        with pytest.raises(am._lib.HipLibraryError):
+            ops.kernel_clock_read(7)
+    finally:
+        ops.kernel_clock_enable(False)
