@@ -1273,6 +1273,7 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
     };
     if (engine_variant() == 0) rc = launch(&prdc_cross_kernel<0, false>);
     else if ((D % BK) != 0) rc = launch(&prdc_cross_kernel<EV_DEFAULT, true>);
+    else if (engine_variant() == (EV_DEFAULT | EV_LDS)) rc = launch(&prdc_cross_kernel<EV_DEFAULT | EV_LDS, false>);
     else rc = launch(&prdc_cross_kernel<EV_DEFAULT, false>);
     if (rc != AM_OK) return rc;
     hipLaunchKernelGGL(prdc_finish_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, rmin, rany, Nr,

@@ -281,6 +281,20 @@ __device__ __forceinline__ void dense_pipeline(const float* __restrict__ Q, int6
 }
 
 constexpr int EV_EARLY = 32;     // loads issued two stages ahead, LDS writes placed inside the MFMA stream
+constexpr int EV_LDS = 64;       // operands go global -> LDS directly (buffer_load ... lds); needs D % 32 == 0
+
+// LDS image of the LDS-direct variant: unpadded 128-B rows (a wave's buffer_load_dwordx4 ... lds writes 64 x 16 B
+// contiguously = 8 whole rows), 16-B chunks XOR-swizzled by (row & 7) so the MFMA fragment reads stay conflict-free.
+constexpr int LDR = 32;
+constexpr int TILE_FLOATS_R = TB * LDR;
+constexpr int STAGE_FLOATS_R = 2 * TILE_FLOATS_R;
+
+// float offset inside a slab row that staging thread `tid` fetches (its LDS slot is always tid & 7)
+template <bool DIRECT>
+__device__ __forceinline__ int staging_col(int tid) {
+    if constexpr (DIRECT) return (((tid & 7) ^ ((tid >> 3) & 7)) * 4);
+    else return (tid & 7) * 4;
+}
 
 struct FragSet {
     f32x4 qa, qb, pa, pb;
@@ -339,14 +353,19 @@ __device__ __forceinline__ void addr_pipeline_early(const QAddrFn& qaddr, const 
                                                     int64_t q_tiles_total, float* __restrict__ lds, const LaneInfo& L,
                                                     Epi& epi);
 
+template <class QAddrFn, class Epi>
+__device__ __forceinline__ void addr_pipeline_lds(const QAddrFn& qaddr, const TileAddr& paddr, int ntiles, int D,
+                                                  float* __restrict__ lds, const LaneInfo& L, Epi& epi);
+
 template <int V, bool KTAIL, class TileMap, class Epi>
 __device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q, int64_t nq, int64_t ldq,
                                                      const TileMap& tmap,
                                                      const float* __restrict__ P, int64_t np, int64_t ldp, int64_t prow0,
                                                      int ntiles, int D, float* __restrict__ lds, const LaneInfo& L,
                                                      Epi& epi) {
+    constexpr bool DIRECT = (V & EV_LDS) != 0 && !KTAIL;
     const int srow = L.tid >> 3;
-    const int scol = (L.tid & 7) * 4;
+    const int scol = staging_col<DIRECT>(L.tid);
     TileAddr pa;
     pa.rs = make_tile_rsrc(P, ldp, np, prow0);
     unsigned voq[4];
@@ -377,7 +396,93 @@ __device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q
         __device__ __forceinline__ void aux_commit(int t) { e.aux_commit(t); }
         __device__ __forceinline__ void finish(int t, int64_t, f32x16 (&acc)[2][2]) { e.finish(t, at(t), acc); }
     } shim{epi, abs_tile};
-    addr_pipeline_early<V, KTAIL>(qaddr, pa, ntiles, D, 0, lds, L, shim);
+    if constexpr (DIRECT) addr_pipeline_lds(qaddr, pa, ntiles, D, lds, L, shim);
+    else addr_pipeline_early<V, KTAIL>(qaddr, pa, ntiles, D, 0, lds, L, shim);
+}
+
+// LDS-direct schedule (EV_LDS).  Stage g multiplies LDS buffer g&1 while the slab of stage g+1 streams from
+// global memory straight into buffer (g+1)&1 - no staging registers, no ds_write.  Each wave fills 8 rows per
+// instruction (lane l -> row l>>3, 16-B slot l&7, fetching chunk (l&7)^(l>>3) of that row).  The loads must have
+// landed before the barrier that ends the stage (explicit vmcnt(0)); the prefetch distance is therefore one stage,
+// against two for the register-staged schedule.  Same slab order and arithmetic: bit-identical results.
+__device__ __forceinline__ void lds_direct_b128(const TileRsrc& r, float* lds_wave_base, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff,
+                                             (int)soff, 0, 0);
+}
+
+template <class QAddrFn, class Epi>
+__device__ __forceinline__ void addr_pipeline_lds(const QAddrFn& qaddr, const TileAddr& paddr, int ntiles, int D,
+                                                  float* __restrict__ lds, const LaneInfo& L, Epi& epi) {
+    const int nk = D / BK;
+    const int G = ntiles * nk;
+    const int wave = __builtin_amdgcn_readfirstlane(L.tid >> 6);
+    f32x16 acc[2][2];
+    zero_acc(acc);
+
+    int ft = 0, fkt = 0;                            // (tile, k-slab) of the next fetch
+    TileAddr qa = qaddr(0);
+    auto issue = [&](int g) {
+        const unsigned so = (unsigned)(fkt * BK * 4);
+        float* s = lds + (g & 1) * STAGE_FLOATS_R + wave * 8 * LDR;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lds_direct_b128(qa.rs, s + q * 32 * LDR, qa.vo[q], so);
+            lds_direct_b128(paddr.rs, s + TILE_FLOATS_R + q * 32 * LDR, paddr.vo[q], so);
+        }
+        if (++fkt == nk) {
+            fkt = 0;
+            ++ft;
+            qa = qaddr(ft);
+        }
+    };
+    // fragment addresses: logical 16-B chunk 2c+h of row r sits in slot (2c+h) ^ (r & 7)
+    const int sw = L.r & 7;
+    int coff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) coff[c] = ((2 * c + L.h) ^ sw) * 4;
+    const int qrow = (L.wm * 64 + L.r) * LDR;
+    const int prow = TILE_FLOATS_R + (L.wn * 64 + L.r) * LDR;
+    auto frags = [&](const float* st, int c) {
+        FragSet f;
+        f.qa = *reinterpret_cast<const f32x4*>(st + qrow + coff[c]);
+        f.qb = *reinterpret_cast<const f32x4*>(st + qrow + 32 * LDR + coff[c]);
+        f.pa = *reinterpret_cast<const f32x4*>(st + prow + coff[c]);
+        f.pb = *reinterpret_cast<const f32x4*>(st + prow + 32 * LDR + coff[c]);
+        return f;
+    };
+
+    issue(0);
+    epi.aux_issue(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+    epi.aux_commit(0);
+    __syncthreads();
+
+    int t = 0, kt = 0;
+    for (int g = 0; g < G; ++g) {
+        const bool last_k = (kt == nk - 1);
+        const int nt_ = last_k ? t + 1 : t;
+        const int nkt = last_k ? 0 : kt + 1;
+        if (g + 1 < G) issue(g + 1);
+        if (last_k) epi.aux_issue(nt_, nt_);
+        const float* st = lds + (g & 1) * STAGE_FLOATS_R;
+        FragSet f0 = frags(st, 0);
+        FragSet f1 = frags(st, 1);
+        mfma_chunk(f0, acc);
+        f0 = frags(st, 2);
+        mfma_chunk(f1, acc);
+        f1 = frags(st, 3);
+        mfma_chunk(f0, acc);
+        mfma_chunk(f1, acc);
+        if (last_k) {
+            epi.finish(t, t, acc);
+            zero_acc(acc);
+            epi.aux_commit(nt_);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);         // the slab of stage g+1 has landed in LDS
+        __syncthreads();
+        t = nt_;
+        kt = nkt;
+    }
 }
 
 template <int V, bool KTAIL, class QAddrFn, class Epi>

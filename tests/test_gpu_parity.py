@@ -300,6 +300,26 @@ def test_knn_symmetric_fallbacks_agree():
     assert len(set(outs)) == 1, outs
 
 
+def test_cross_kernel_schedules_agree():
+    """The membership-count kernel under its three schedules - plain pointer staging (variant 0), the production
+    register-staged early-commit pipeline (35) and the LDS-direct pipeline (99, buffer_load ... lds with
+    XOR-swizzled rows) - produces identical counts, row flags and row minima."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ, AB_ROWS="5000", AB_DIM="160")
+    outs = []
+    for variant in ("0", "35", "99"):
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_cross.py")],
+                             env=dict(base, AM_ENGINE_VARIANT=variant), capture_output=True, text=True, timeout=600)
+        m = re.search(r"sha1 ([0-9a-f]+)", res.stdout)
+        assert m, res.stdout + res.stderr
+        outs.append(m.group(1))
+    assert len(set(outs)) == 1, outs
+
+
 # ----------------------------------------------------------------- PCA projection (n_pca)
 def test_incremental_pca_vs_reference(am, golden):
     """Device PCA against the reference's scikit-learn based IncrementalPCA: first fit, incremental update,

@@ -23,5 +23,7 @@ for _ in range(3):
     col, rany, rmin = ops.prdc_counts(x, y, rx, ry)
     torch.cuda.synchronize()
     ts.append(time.perf_counter() - t0)
-print(f"cross order={os.environ.get('AM_CROSS_ORDER', '0')} wg_target={os.environ.get('AM_WG_TARGET', '8192')} N={n} D={d}: "
+import hashlib  # noqa: E402
+digest = hashlib.sha1(col.cpu().numpy().tobytes() + rany.cpu().numpy().tobytes() + rmin.cpu().numpy().tobytes()).hexdigest()[:12]
+print(f"variant={os.environ.get('AM_ENGINE_VARIANT', 'default')} sha1 {digest} cross order={os.environ.get('AM_CROSS_ORDER', '0')} wg_target={os.environ.get('AM_WG_TARGET', '8192')} N={n} D={d}: "
       f"best {min(ts) * 1e3:.2f} ms {2 * n * n * d / min(ts) / 1e12:.1f} TF  sum {int(col.sum())} {int(rany.sum())}", flush=True)
