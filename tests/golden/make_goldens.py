@@ -229,6 +229,13 @@ def gen_e2e():
                 out[f"{tag}/{attr}/n"] = d.n
                 out[f"{tag}/{attr}/mean"] = d.mean.numpy()
                 out[f"{tag}/{attr}/cov"] = d.cov.numpy()
+        if tag in ("all", "pca"):
+            # a state file WRITTEN BY THE REFERENCE (audio_metrics.py:78-89): the build's load_state must read it.
+            # save_state calls self.__getstate__(), which plain objects only have from Python 3.11 on (there it
+            # returns the instance __dict__); this container runs 3.10, so supply exactly that default.
+            if not hasattr(object, "__getstate__"):
+                audio_metrics.AudioMetrics.__getstate__ = lambda self: self.__dict__
+            am.save_state(os.path.join(HERE, f"reference_state_{tag}.pt"))
         print("e2e", tag, res)
     np.savez_compressed(os.path.join(HERE, "e2e.npz"), **out)
 

@@ -76,6 +76,28 @@ def test_evaluate_matches_reference(am, golden, tag, metrics, n_pca):
         assert abs(res2[key] - res[key]) <= 1e-9 * max(1.0, abs(res[key]))
 
 
+@pytest.mark.parametrize("tag,metrics,n_pca", [("all", ["fad", "kd", "prdc", "apa"], None),
+                                               ("pca", ["fad", "kd", "prdc", "apa"], 8)])
+def test_load_state_written_by_reference(am, golden, tag, metrics, n_pca):
+    """N3: a state file written by the REFERENCE's save_state (tests/golden/reference_state_*.pt, produced by
+    make_goldens.py) restores the reference side here - statistics, stored embeddings, cached radii and d_x_xp, PCA
+    projections - and evaluate() of the same candidates then gives the reference's results."""
+    import os
+    g = golden("e2e")
+    fp = os.path.join(os.path.dirname(os.path.abspath(gi.__file__)), f"reference_state_{tag}.pt")
+    m = make(am, metrics, n_pca=n_pca)
+    m.load_state(fp)
+    assert m.stem_reference.n == int(g[f"{tag}/stem_reference/n"])
+    assert m.stem_reference.embeddings.is_cuda and m.stem_reference.mean.is_cuda
+    _, cand = data()
+    res = m.evaluate(cand)
+    assert list(res) == [str(k) for k in g[f"{tag}/keys"]]
+    for key, v in res.items():
+        want = float(g[f"{tag}/{key}"])
+        extra = 1e-6 if key == "apa" else 0.0
+        assert abs(v - want) <= tol(key, want) + extra, (key, v, want)
+
+
 def test_input_containers(am):
     """ndarray (B, n, 2), generator of (n, 2) arrays and torch tensor are all accepted (embed.py:110-147)."""
     ref, cand = data()
