@@ -93,7 +93,8 @@ class AudioMetricsData:
             self.cov = ensure_tensor(state["cov"]).to(dev, torch.float64)
         if state.get("embeddings") is not None:
             self._append(self._to_device_matrix(state["embeddings"]))
-        self.radii = {k: ensure_tensor(v).to(dev) for k, v in (state.get("radii") or {}).items()}
+        # the kernels compare in f32; a reference-written state may carry f64 radii (f64 embeddings after its PCA)
+        self.radii = {k: ensure_tensor(v).to(dev, torch.float32) for k, v in (state.get("radii") or {}).items()}
         self.dtype = state.get("dtype", torch.float64)
         return self
 

@@ -312,6 +312,15 @@ def prdc_reduce(col, rany, rmin, r_ref):
     """Four integer totals as a device int64[4]:
     (#cols with count>0, #rows with any, sum of counts, #rows with row_min < r_ref)."""
     lib = _lib.load()
+    for t, name in ((col, "col_count"), (rany, "row_any"), (rmin, "row_min"), (r_ref, "r_ref")):
+        _require_cuda(t, name)
+    # the C ABI takes raw pointers: hand it exactly the element types it reads
+    col = col.to(torch.int32).contiguous()
+    rany = rany.to(torch.uint8).contiguous()
+    rmin = rmin.to(torch.float32).contiguous()
+    r_ref = r_ref.to(torch.float32).contiguous()
+    if rmin.numel() != rany.numel() or r_ref.numel() != rany.numel():
+        raise ValueError("row_any / row_min / r_ref lengths differ")
     out = torch.empty(4, dtype=torch.int64, device=col.device)
     _call(lib, "am_prdc_reduce", _ptr(col), col.numel(), _ptr(rany), _ptr(rmin), _ptr(r_ref), rany.numel(),
                                   _ptr(out), _stream())
