@@ -676,8 +676,10 @@ prdc_cross_kernel(const float* __restrict__ R, int64_t Nr, int64_t ldr, const fl
                   const float* __restrict__ C, int64_t Nc, int64_t ldc, const float* __restrict__ cnorm,
                   const float* __restrict__ cthr, int D, int nchunks,
                   int32_t* __restrict__ col_count, unsigned* __restrict__ row_min_bits,
-                  unsigned* __restrict__ row_any, int order) {
+                  unsigned* __restrict__ row_any, int order, const int* __restrict__ run_flag) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // fallback launch behind the filter-and-verify path (pairwise_fast.h): runs only if that path gave up
+    if (run_flag != nullptr && *run_flag == 0) return;
     const LaneInfo L;
     const int64_t q_tiles = (Nc + TB - 1) / TB;
     const WorkItem w = work_item(q_tiles, nchunks, order);
@@ -1225,12 +1227,15 @@ extern "C" int am_knn_lists_finish_f32(const float* lists, int nparts, const flo
     }
 }
 
-extern "C" size_t am_prdc_workspace_bytes(int64_t Nr, int64_t Nc) {
-    if (Nr < 1 || Nc < 1) return 0;
+#include "pairwise_fast.h"      // bf16 filter + exact verification form of the membership counts
+
+extern "C" size_t am_prdc_workspace_bytes(int64_t Nr, int64_t Nc, int D) {
+    if (Nr < 1 || Nc < 1 || D < 1) return 0;
     Carver c(nullptr, 0);
     c.take<float>(Nr); c.take<float>(Nr);          // |r|^2, T(r_ref)
     c.take<float>(Nc); c.take<float>(Nc);          // |c|^2, T(r_cand)
     c.take<unsigned>(Nr); c.take<unsigned>(Nr);    // row_min bits, row_any words
+    if (cross_fast_enabled(Nr, Nc, D)) carve_cross_fast(c, Nr, Nc, D, plan_cross_fast(Nr, Nc));
     return c.off;
 }
 
@@ -1250,6 +1255,13 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
     float* ct = c.take<float>(Nc);
     unsigned* rmin = c.take<unsigned>(Nr);
     unsigned* rany = c.take<unsigned>(Nr);
+    const bool fast = cross_fast_enabled(Nr, Nc, D);
+    CrossFastPlan fplan{};
+    CrossFastBuffers fbuf{};
+    if (fast) {
+        fplan = plan_cross_fast(Nr, Nc);
+        fbuf = carve_cross_fast(c, Nr, Nc, D, fplan);
+    }
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
     if ((rc = launch_norms(R, Nr, ldr, D, rn, st)) != AM_OK) return rc;
     if ((rc = launch_norms(C, Nc, ldc, D, cn, st)) != AM_OK) return rc;
@@ -1259,15 +1271,24 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
     AM_LAUNCH_CHECK();
     AM_HIP_TRY(hipMemsetAsync(rany, 0, (size_t)Nr * sizeof(unsigned), st));
     AM_HIP_TRY(hipMemsetAsync(out_col_count, 0, (size_t)Nc * sizeof(int32_t), st));
+    const int* run_flag = nullptr;
+    if (fast) {
+        // bf16 filter pass + exact verification of the queued pairs (pairwise_fast.h): same outputs, bit for bit.
+        // The exact kernel is still launched behind it, but its workgroups return at once unless the filter path
+        // raised its device-side fail flag (both queues overflowed).
+        if ((rc = run_cross_fast(R, Nr, ldr, rn, rt, C, Nc, ldc, cn, ct, D, fplan, fbuf, out_col_count, rmin, rany, st)) != AM_OK)
+            return rc;
+        run_flag = fbuf.ov_count + 1;
+    }
     const int nchunks = choose_chunks(Nr, Nc);
     const int64_t blocks = ceil_div(Nr, TB) * nchunks;
     auto launch = [&](auto kernel) -> int {
         AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)PAIRWISE_LDS_BYTES));
-        clock_begin(AM_KERNEL_PRDC_CROSS, st);
+        if (!fast) clock_begin(AM_KERNEL_PRDC_CROSS, st);
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES, st, R, Nr, ldr, rn, rt,
-                           C, Nc, ldc, cn, ct, D, nchunks, out_col_count, rmin, rany, env_int("AM_CROSS_ORDER", 0));
-        clock_end(AM_KERNEL_PRDC_CROSS, st);
+                           C, Nc, ldc, cn, ct, D, nchunks, out_col_count, rmin, rany, env_int("AM_CROSS_ORDER", 0), run_flag);
+        if (!fast) clock_end(AM_KERNEL_PRDC_CROSS, st);
         AM_LAUNCH_CHECK();
         return AM_OK;
     };

@@ -301,7 +301,7 @@ def prdc_counts(ref, cand, r_ref, r_cand):
     col = torch.empty(nc, dtype=torch.int32, device=ref.device)
     rany = torch.empty(nr, dtype=torch.uint8, device=ref.device)
     rmin = torch.empty(nr, dtype=torch.float32, device=ref.device)
-    nb = lib.am_prdc_workspace_bytes(nr, nc)
+    nb = lib.am_prdc_workspace_bytes(nr, nc, d)
     ws = _workspace(nb, ref.device)
     _call(lib, "am_prdc_counts_f32", _ptr(ref), nr, _ld(ref), _ptr(cand), nc, _ld(cand), d, _ptr(r_ref),
                                       _ptr(r_cand), _ptr(col), _ptr(rany), _ptr(rmin), _ptr(ws), nb, _stream())

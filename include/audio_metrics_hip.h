@@ -165,7 +165,7 @@ int am_knn_lists_finish_f32(const float* lists, int nparts, const float* X, int6
  *   totals { #cols with count>0, #rows with any, sum of counts, #rows with
  *   row_min < r_ref } (device int64[4]); the caller divides in f64.
  * ------------------------------------------------------------------------- */
-size_t am_prdc_workspace_bytes(int64_t Nr, int64_t Nc);
+size_t am_prdc_workspace_bytes(int64_t Nr, int64_t Nc, int D);
 int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr,
                        const float* C, int64_t Nc, int64_t ldc, int D,
                        const float* r_ref, const float* r_cand,

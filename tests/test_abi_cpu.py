@@ -44,7 +44,7 @@ def test_host_side_entry_points():
     assert lib.am_stats_workspace_bytes(100000, 512) > 0
     assert lib.am_frechet_workspace_bytes(512) >= 6 * 512 * 512 * 8
     assert lib.am_kd_workspace_bytes(100, 1000) > 0
-    assert lib.am_prdc_workspace_bytes(1000, 2000) > 0
+    assert lib.am_prdc_workspace_bytes(1000, 2000, 128) > 0
 
 
 def test_no_cpu_fallback():
