@@ -724,12 +724,21 @@ prdc_cross_kernel(const float* __restrict__ R, int64_t Nr, int64_t ldr, const fl
     }
 }
 
+// row_cover[i] = some candidate lies strictly inside reference row i's ball = (min_j d(i,j) < r_ref[i]), the
+// reference's coverage predicate (prdc.py:45-47).  The exact kernel accumulates the row minimum and the flag is
+// derived from it; the filter-and-verify path accumulates the flag itself (cov_w) and the minimum only on request.
+// use_cov_flag: device flag, non-zero = the exact kernel ran after all (cov_w is void, row_min_bits is valid).
 __global__ void prdc_finish_kernel(const unsigned* __restrict__ row_min_bits, const unsigned* __restrict__ row_any_w,
-                                   int64_t Nr, float* __restrict__ row_min, uint8_t* __restrict__ row_any) {
+                                   const unsigned* __restrict__ cov_w, const int* __restrict__ exact_ran,
+                                   const float* __restrict__ r_ref, int64_t Nr, float* __restrict__ row_min,
+                                   uint8_t* __restrict__ row_any, uint8_t* __restrict__ row_cover) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Nr) return;
-    row_min[i] = sqrt_rn(__uint_as_float(row_min_bits[i]));
+    const bool from_min = cov_w == nullptr || (exact_ran != nullptr && *exact_ran != 0);
+    const float mn = sqrt_rn(__uint_as_float(row_min_bits[i]));
+    if (row_min != nullptr) row_min[i] = mn;
     row_any[i] = row_any_w[i] ? 1 : 0;
+    row_cover[i] = from_min ? (mn < r_ref[i] ? 1 : 0) : (cov_w[i] ? 1 : 0);
 }
 
 __global__ void fill_u32_kernel(unsigned* __restrict__ p, int64_t n, unsigned v) {
@@ -737,11 +746,10 @@ __global__ void fill_u32_kernel(unsigned* __restrict__ p, int64_t n, unsigned v)
     if (i < n) p[i] = v;
 }
 
-// four integer totals: { #cols count>0, #rows any, sum counts, #rows row_min < r_ref }
+// four integer totals: { #cols count>0, #rows any, sum counts, #rows covered }
 __global__ void __launch_bounds__(256) prdc_reduce_kernel(const int32_t* __restrict__ col_count, int64_t Nc,
                                                           const uint8_t* __restrict__ row_any,
-                                                          const float* __restrict__ row_min,
-                                                          const float* __restrict__ r_ref, int64_t Nr,
+                                                          const uint8_t* __restrict__ row_cover, int64_t Nr,
                                                           unsigned long long* __restrict__ out4) {
     unsigned long long v[4] = {0, 0, 0, 0};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -752,7 +760,7 @@ __global__ void __launch_bounds__(256) prdc_reduce_kernel(const int32_t* __restr
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < Nr; i += stride) {
         v[1] += row_any[i] != 0;
-        v[3] += row_min[i] < r_ref[i];
+        v[3] += row_cover[i] != 0;
     }
     __shared__ unsigned long long red[4][4];
 #pragma unroll
@@ -1235,18 +1243,19 @@ extern "C" size_t am_prdc_workspace_bytes(int64_t Nr, int64_t Nc, int D) {
     c.take<float>(Nr); c.take<float>(Nr);          // |r|^2, T(r_ref)
     c.take<float>(Nc); c.take<float>(Nc);          // |c|^2, T(r_cand)
     c.take<unsigned>(Nr); c.take<unsigned>(Nr);    // row_min bits, row_any words
+    c.take<unsigned>(Nr);                          // row_cover words
     if (cross_fast_enabled(Nr, Nc, D)) carve_cross_fast(c, Nr, Nc, D, plan_cross_fast(Nr, Nc));
     return c.off;
 }
 
 extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const float* C, int64_t Nc, int64_t ldc,
                                   int D, const float* r_ref, const float* r_cand, int32_t* out_col_count,
-                                  uint8_t* out_row_any, float* out_row_min, void* ws, size_t ws_bytes,
-                                  am_stream_t stream) {
+                                  uint8_t* out_row_any, uint8_t* out_row_cover, float* out_row_min, void* ws,
+                                  size_t ws_bytes, am_stream_t stream) {
     int rc;
     if ((rc = check_matrix(R, Nr, ldr, D, "R")) != AM_OK) return rc;
     if ((rc = check_matrix(C, Nc, ldc, D, "C")) != AM_OK) return rc;
-    AM_REQUIRE(r_ref && r_cand && out_col_count && out_row_any && out_row_min, AM_ERR_BAD_ARG, "null radius/output pointer");
+    AM_REQUIRE(r_ref && r_cand && out_col_count && out_row_any && out_row_cover, AM_ERR_BAD_ARG, "null radius/output pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carver c(ws, ws_bytes);
     float* rn = c.take<float>(Nr);
@@ -1255,6 +1264,7 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
     float* ct = c.take<float>(Nc);
     unsigned* rmin = c.take<unsigned>(Nr);
     unsigned* rany = c.take<unsigned>(Nr);
+    unsigned* rcov = c.take<unsigned>(Nr);
     const bool fast = cross_fast_enabled(Nr, Nc, D);
     CrossFastPlan fplan{};
     CrossFastBuffers fbuf{};
@@ -1270,13 +1280,15 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, rmin, Nr, 0x7f800000u);
     AM_LAUNCH_CHECK();
     AM_HIP_TRY(hipMemsetAsync(rany, 0, (size_t)Nr * sizeof(unsigned), st));
+    AM_HIP_TRY(hipMemsetAsync(rcov, 0, (size_t)Nr * sizeof(unsigned), st));
     AM_HIP_TRY(hipMemsetAsync(out_col_count, 0, (size_t)Nc * sizeof(int32_t), st));
     const int* run_flag = nullptr;
     if (fast) {
         // bf16 filter pass + exact verification of the queued pairs (pairwise_fast.h): same outputs, bit for bit.
         // The exact kernel is still launched behind it, but its workgroups return at once unless the filter path
         // raised its device-side fail flag (both queues overflowed).
-        if ((rc = run_cross_fast(R, Nr, ldr, rn, rt, C, Nc, ldc, cn, ct, D, fplan, fbuf, out_col_count, rmin, rany, st)) != AM_OK)
+        if ((rc = run_cross_fast(R, Nr, ldr, rn, rt, C, Nc, ldc, cn, ct, D, fplan, fbuf, out_col_count, rmin, rany, rcov,
+                                 out_row_min != nullptr, st)) != AM_OK)
             return rc;
         run_flag = fbuf.ov_count + 1;
     }
@@ -1297,22 +1309,22 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
     else if (engine_variant() == (EV_DEFAULT | EV_LDS)) rc = launch(&prdc_cross_kernel<EV_DEFAULT | EV_LDS, false>);
     else rc = launch(&prdc_cross_kernel<EV_DEFAULT, false>);
     if (rc != AM_OK) return rc;
-    hipLaunchKernelGGL(prdc_finish_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, rmin, rany, Nr,
-                       out_row_min, out_row_any);
+    hipLaunchKernelGGL(prdc_finish_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, rmin, rany,
+                       fast ? rcov : static_cast<unsigned*>(nullptr), run_flag, r_ref, Nr, out_row_min, out_row_any, out_row_cover);
     AM_LAUNCH_CHECK();
     return AM_OK;
 }
 
-extern "C" int am_prdc_reduce(const int32_t* col_count, int64_t Nc, const uint8_t* row_any, const float* row_min,
-                              const float* r_ref, int64_t Nr, int64_t* out4, am_stream_t stream) {
-    AM_REQUIRE(col_count && row_any && row_min && r_ref && out4, AM_ERR_BAD_ARG, "null pointer");
+extern "C" int am_prdc_reduce(const int32_t* col_count, int64_t Nc, const uint8_t* row_any, const uint8_t* row_cover,
+                              int64_t Nr, int64_t* out4, am_stream_t stream) {
+    AM_REQUIRE(col_count && row_any && row_cover && out4, AM_ERR_BAD_ARG, "null pointer");
     AM_REQUIRE(Nc >= 1 && Nr >= 1, AM_ERR_BAD_SHAPE, "empty input");
     hipStream_t st = static_cast<hipStream_t>(stream);
     AM_HIP_TRY(hipMemsetAsync(out4, 0, 4 * sizeof(int64_t), st));
     const int64_t n = Nc > Nr ? Nc : Nr;
     int blocks = (int)ceil_div(n, 256 * 8);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(prdc_reduce_kernel, dim3(blocks), dim3(256), 0, st, col_count, Nc, row_any, row_min, r_ref, Nr,
+    hipLaunchKernelGGL(prdc_reduce_kernel, dim3(blocks), dim3(256), 0, st, col_count, Nc, row_any, row_cover, Nr,
                        reinterpret_cast<unsigned long long*>(out4));
     AM_LAUNCH_CHECK();
     return AM_OK;

@@ -125,7 +125,7 @@ struct CrossFastEpilogue {
     int dbg;
     int64_t prow[2];
     float xn[2], thi[2], tlo[2], e2[2], m[2];
-    bool rowok[2], anyf[2];
+    bool rowok[2], anyf[2], covf[2];
     float aux_n, aux_hi, aux_lo;
     const LaneInfo& L;
 
@@ -163,10 +163,11 @@ struct CrossFastEpilogue {
             d[2 * TB] = aux_lo;
         }
     }
-    template <bool PRE>
+    template <bool PRE, bool WANT_MIN>
     __device__ __forceinline__ void finish_impl(int t, int64_t qtile, f32x16 (&acc)[2][2]) {
         const float* a = aux + (t & 1) * 3 * TB + L.wm * 64 + L.h * 4;
         const int64_t jbase = qtile * TB + L.wm * 64 + L.h * 4;
+        if (dbg & 8) return;                                   // timing experiment: MFMA pipeline only
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             f32x4 yn[4], th[4];
@@ -184,12 +185,12 @@ struct CrossFastEpilogue {
                     tmin = fminf(tmin, u);
                     marg = fminf(marg, u - th[reg >> 2][reg & 3]);          // +inf - (-inf) = +inf past nq
                 }
-                m[nt] = fminf(m[nt], fmaxf(tmin, 0.f));
+                if constexpr (WANT_MIN) m[nt] = fminf(m[nt], fmaxf(tmin, 0.f));
                 if constexpr (PRE) {
                     anyf[nt] = anyf[nt] || (marg < 0.f);                     // some a < T'_j - E'_j
                 } else {
-                    const float prow_thr = fmaxf(thi[nt], m[nt] + e2[nt]);
-                    if (__any(rowok[nt] && (tmin <= prow_thr || (!anyf[nt] && marg <= 0.f)))) {
+                    const float prow_thr = WANT_MIN ? fmaxf(thi[nt], m[nt] + e2[nt]) : thi[nt];
+                    if (!(dbg & 4) && __any(rowok[nt] && (tmin <= prow_thr || (!anyf[nt] && marg <= 0.f)))) {
                         const float* alo = a + 2 * TB + mt * 32;
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
@@ -203,8 +204,9 @@ struct CrossFastEpilogue {
                                 if (lo) atomicAdd(col_count + j - L.h * 4, lo);
                                 if (hi) atomicAdd(col_count + j - L.h * 4 + 4, hi);
                             }
+                            covf[nt] = covf[nt] || sure;                              // inside for certain: the row is covered
                             bool want = rowok[nt] && !sure && u <= thi[nt];           // ambiguous count
-                            want = want || (rowok[nt] && u <= m[nt] + e2[nt]);        // row-minimum candidate
+                            if constexpr (WANT_MIN) want = want || (rowok[nt] && u <= m[nt] + e2[nt]);   // row-minimum candidate
                             if (rowok[nt] && !anyf[nt] && u <= th[reg >> 2][reg & 3]) {
                                 if (u < alo[(reg >> 2) * 8 + (reg & 3)]) { anyf[nt] = true; if (dbg & 1) want = true; }   // certain witness
                                 else want = true;                                     // ambiguous "any"
@@ -218,22 +220,24 @@ struct CrossFastEpilogue {
     }
 };
 
-template <bool PRE>
-struct CrossFastShim {            // picks the PRE / main epilogue body at compile time
+template <bool PRE, bool WANT_MIN>
+struct CrossFastShim {            // picks the epilogue body at compile time
     CrossFastEpilogue& e;
     __device__ __forceinline__ void aux_issue(int t, int64_t q) { e.aux_issue(t, q); }
     __device__ __forceinline__ void aux_commit(int t) { e.aux_commit(t); }
-    __device__ __forceinline__ void finish(int t, int64_t q, f32x16 (&acc)[2][2]) { e.template finish_impl<PRE>(t, q, acc); }
+    __device__ __forceinline__ void finish(int t, int64_t q, f32x16 (&acc)[2][2]) {
+        e.template finish_impl<PRE, WANT_MIN>(t, q, acc);
+    }
 };
 
 // Rb / Cb: bf16 copies viewed as f32 words (ld and Dh in words, Dh % 32 == 0).
-template <bool PRE>
+template <bool PRE, bool WANT_MIN>
 __global__ void __launch_bounds__(ENGINE_THREADS, 2)
 cross_fast_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const float* __restrict__ rnorm,
                   const float* __restrict__ rthr, const float* __restrict__ Cb, int64_t Nc, int64_t ldc,
                   const float* __restrict__ cnorm, const float* __restrict__ cthr, int Dh, int nchunks, int qstride,
                   const unsigned* __restrict__ maxn, unsigned* __restrict__ rmin_approx, unsigned* __restrict__ row_any,
-                  int32_t* __restrict__ col_count, uint2* __restrict__ wgq, int qcap, int* __restrict__ wgq_count,
+                  unsigned* __restrict__ row_cover, int32_t* __restrict__ col_count, uint2* __restrict__ wgq, int qcap, int* __restrict__ wgq_count,
                   uint2* __restrict__ ovq, int* __restrict__ ov_count, int ovcap, int* __restrict__ fail, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
@@ -269,20 +273,24 @@ cross_fast_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const f
         epi.thi[nt] = ok ? rthr[i] + e : -INFINITY;
         epi.tlo[nt] = ok ? rthr[i] - e : -INFINITY;
         epi.e2[nt] = 2.f * e;
-        epi.m[nt] = ok ? __uint_as_float(rmin_approx[i]) : INFINITY;
+        epi.m[nt] = (WANT_MIN && ok) ? __uint_as_float(rmin_approx[i]) : INFINITY;
         epi.anyf[nt] = ok ? (row_any[i] != 0u && !(dbg & 2)) : true;
+        epi.covf[nt] = false;
     }
-    CrossFastShim<PRE> shim{epi};
+    CrossFastShim<PRE, WANT_MIN> shim{epi};
     dense_pipeline_early<EV_FAST, false>(Cb, Nc, ldc, LinearTiles{w.qtile0, qstride}, Rb, Nr, ldr, w.prow0, w.ntiles, Dh,
                                          lds, L, shim);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const float mn = fminf(epi.m[nt], __shfl_xor(epi.m[nt], 32));
         const int other = __shfl_xor((int)epi.anyf[nt], 32);                  // unconditionally: every lane must take part
+        const int other_c = __shfl_xor((int)epi.covf[nt], 32);
         const bool any = epi.anyf[nt] || other != 0;
+        const bool cov = epi.covf[nt] || other_c != 0;
         if (L.h == 0 && epi.rowok[nt]) {
-            atomicMin(rmin_approx + epi.prow[nt], __float_as_uint(mn));      // mn >= 0: uint order == float order
+            if constexpr (WANT_MIN) atomicMin(rmin_approx + epi.prow[nt], __float_as_uint(mn));   // mn >= 0: uint order == float order
             if (any) atomicOr(row_any + epi.prow[nt], 1u);
+            if (cov) atomicOr(row_cover + epi.prow[nt], 1u);
         }
     }
     if constexpr (!PRE) {
@@ -293,10 +301,13 @@ cross_fast_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const f
 
 // Exact value of one queued pair applied to the exact kernel's accumulators.
 __device__ __forceinline__ void cross_apply(float t, int64_t j, unsigned jflag, float ti, const float* __restrict__ cthr,
-                                            int32_t* __restrict__ col_count, float& mn, bool& any) {
+                                            int32_t* __restrict__ col_count, float& mn, bool& any, bool& cov) {
     mn = fminf(mn, t);
     any = any || (t < cthr[j]);
-    if (!(jflag & FAST_COUNTED) && t < ti) atomicAdd(col_count + j, 1);
+    if (t < ti) {
+        cov = true;
+        if (!(jflag & FAST_COUNTED)) atomicAdd(col_count + j, 1);
+    }
 }
 
 // Verification of one workgroup region (same grid as the filter pass): the entries are bucketed by reference
@@ -308,7 +319,8 @@ __global__ void __launch_bounds__(256) cross_verify_kernel(const float* __restri
                                                            const float* __restrict__ cnorm, const float* __restrict__ cthr, int D,
                                                            int nchunks, const uint2* __restrict__ wgq, int qcap,
                                                            const int* __restrict__ wgq_count, int32_t* __restrict__ col_count,
-                                                           unsigned* __restrict__ row_min_bits, unsigned* __restrict__ row_any) {
+                                                           unsigned* __restrict__ row_min_bits, unsigned* __restrict__ row_any,
+                                                           unsigned* __restrict__ row_cover) {
     extern __shared__ __attribute__((aligned(16))) float vlds[];       // [4][dp] rows, then qcap sorted entries
     __shared__ int bucket[TB], start[TB];
     const int n = wgq_count[blockIdx.x];
@@ -355,22 +367,23 @@ __global__ void __launch_bounds__(256) cross_verify_kernel(const float* __restri
         __builtin_amdgcn_wave_barrier();                               // same wave wrote the row: LDS ops stay in order
         const float xi = rnorm[i], ti = rthr[i];
         float mn = INFINITY;
-        bool any = false;
+        bool any = false, cov = false;
         for (int e0 = 0; e0 < cnt; e0 += 64) {
             const int e = e0 + lane;
             if (e < cnt) {
                 const unsigned jf = sorted[start[lr] + e];
                 const int64_t j = jf & ~FAST_COUNTED;
                 const float t = fmaxf(fmaf(-2.f, exact_pair_dot(xs, C + j * ldc, D), xi + cnorm[j]), 0.f);
-                cross_apply(t, j, jf, ti, cthr, col_count, mn, any);
+                cross_apply(t, j, jf, ti, cthr, col_count, mn, any, cov);
             }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
-        const bool wave_any = __any(any);
+        const bool wave_any = __any(any), wave_cov = __any(cov);
         if (lane == 0) {
-            atomicMin(row_min_bits + i, __float_as_uint(mn));          // t >= 0: uint order == float order
+            if (row_min_bits != nullptr) atomicMin(row_min_bits + i, __float_as_uint(mn));   // t >= 0: uint order == float order
             if (wave_any) atomicOr(row_any + i, 1u);
+            if (wave_cov) atomicOr(row_cover + i, 1u);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -385,7 +398,7 @@ __global__ void __launch_bounds__(256) cross_verify_overflow_kernel(const float*
                                                                     const int* __restrict__ ov_count, int ovcap,
                                                                     const int* __restrict__ fail, int32_t* __restrict__ col_count,
                                                                     unsigned* __restrict__ row_min_bits,
-                                                                    unsigned* __restrict__ row_any) {
+                                                                    unsigned* __restrict__ row_any, unsigned* __restrict__ row_cover) {
     if (*fail) return;
     const int n = *ov_count < ovcap ? *ov_count : ovcap;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
@@ -406,10 +419,11 @@ __global__ void __launch_bounds__(256) cross_verify_overflow_kernel(const float*
         }
         const float t = fmaxf(fmaf(-2.f, acc, rnorm[i] + cnorm[j]), 0.f);
         float mn = INFINITY;
-        bool any = false;
-        cross_apply(t, j, v.y, rthr[i], cthr, col_count, mn, any);
-        atomicMin(row_min_bits + i, __float_as_uint(mn));
+        bool any = false, cov = false;
+        cross_apply(t, j, v.y, rthr[i], cthr, col_count, mn, any, cov);
+        if (row_min_bits != nullptr) atomicMin(row_min_bits + i, __float_as_uint(mn));
         if (any) atomicOr(row_any + i, 1u);
+        if (cov) atomicOr(row_cover + i, 1u);
     }
 }
 
@@ -417,12 +431,14 @@ __global__ void __launch_bounds__(256) cross_verify_overflow_kernel(const float*
 // exact kernel, which then really runs (its workgroups return at once otherwise), starts from a clean state.
 __global__ void __launch_bounds__(256) cross_fail_reset_kernel(const int* __restrict__ fail, int32_t* __restrict__ col_count,
                                                                int64_t Nc, unsigned* __restrict__ row_min_bits,
-                                                               unsigned* __restrict__ row_any, int64_t Nr) {
+                                                               unsigned* __restrict__ row_any, unsigned* __restrict__ row_cover,
+                                                               int64_t Nr) {
     if (!*fail) return;
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < Nc; j += (int64_t)gridDim.x * 256) col_count[j] = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < Nr; i += (int64_t)gridDim.x * 256) {
-        row_min_bits[i] = 0x7f800000u;
+        row_min_bits[i] = 0x7f800000u;          // the exact kernel always accumulates the minimum
         row_any[i] = 0u;
+        row_cover[i] = 0u;
     }
 }
 
@@ -479,7 +495,7 @@ static bool cross_fast_enabled(int64_t Nr, int64_t Nc, int D) {
 // to run after all.
 static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* rn, const float* rt, const float* C, int64_t Nc,
                           int64_t ldc, const float* cn, const float* ct, int D, const CrossFastPlan& p, const CrossFastBuffers& b,
-                          int32_t* col_count, unsigned* rmin, unsigned* rany, hipStream_t st) {
+                          int32_t* col_count, unsigned* rmin, unsigned* rany, unsigned* rcov, bool want_min, hipStream_t st) {
     int rc;
     if ((rc = launch_to_bf16(R, Nr, ldr, D, b.rb, st)) != AM_OK) return rc;
     if ((rc = launch_to_bf16(C, Nc, ldc, D, b.cb, st)) != AM_OK) return rc;
@@ -496,32 +512,40 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
     int* fail = b.ov_count + 1;
     static bool attr_done = false;
     if (!attr_done) {
-        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_fast_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FAST_LDS_BYTES));
-        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_fast_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FAST_LDS_BYTES));
+        const void* kernels[] = {reinterpret_cast<const void*>(&cross_fast_kernel<true, true>),
+                                 reinterpret_cast<const void*>(&cross_fast_kernel<true, false>),
+                                 reinterpret_cast<const void*>(&cross_fast_kernel<false, true>),
+                                 reinterpret_cast<const void*>(&cross_fast_kernel<false, false>)};
+        for (const void* k : kernels)
+            AM_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FAST_LDS_BYTES));
         attr_done = true;
     }
-    // sampled pre-pass: approximate row minima and certain "any" witnesses over every 16th column tile
-    hipLaunchKernelGGL(cross_fast_kernel<true>, dim3((unsigned)(ceil_div(Nr, TB) * p.pre_chunks)), dim3(ENGINE_THREADS),
-                       FAST_LDS_BYTES, st, Rb, Nr, ldb / 2, rn, rt, Cb, Nc, ldb / 2, cn, ct, Dh, p.pre_chunks, p.qstride, b.maxn,
-                       b.rmin_approx, rany, col_count, b.wgq, p.qcap, b.wgq_count, b.ovq, b.ov_count, p.ovcap, fail,
-                       env_int("AM_FAST_DBG", 0));
+    const int dbg = env_int("AM_FAST_DBG", 0);
+    // sampled pre-pass over every 16th column tile: certain "any" witnesses (and, when the row minimum is wanted,
+    // an approximate minimum that bounds its candidate queue)
+    auto launch_filter = [&](auto kernel, unsigned grid, int nchunks, int qstride) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(ENGINE_THREADS), FAST_LDS_BYTES, st, Rb, Nr, ldb / 2, rn, rt, Cb, Nc, ldb / 2,
+                           cn, ct, Dh, nchunks, qstride, b.maxn, b.rmin_approx, rany, rcov, col_count, b.wgq, p.qcap, b.wgq_count,
+                           b.ovq, b.ov_count, p.ovcap, fail, dbg);
+    };
+    const unsigned pre_grid = (unsigned)(ceil_div(Nr, TB) * p.pre_chunks);
+    if (want_min) launch_filter(&cross_fast_kernel<true, true>, pre_grid, p.pre_chunks, p.qstride);
+    else launch_filter(&cross_fast_kernel<true, false>, pre_grid, p.pre_chunks, p.qstride);
     AM_LAUNCH_CHECK();
     clock_begin(AM_KERNEL_PRDC_CROSS, st);
-    hipLaunchKernelGGL(cross_fast_kernel<false>, dim3((unsigned)p.blocks), dim3(ENGINE_THREADS), FAST_LDS_BYTES, st, Rb, Nr,
-                       ldb / 2, rn, rt, Cb, Nc, ldb / 2, cn, ct, Dh, p.nchunks, 1, b.maxn, b.rmin_approx, rany, col_count, b.wgq,
-                       p.qcap, b.wgq_count, b.ovq, b.ov_count, p.ovcap, fail, env_int("AM_FAST_DBG", 0));
+    if (want_min) launch_filter(&cross_fast_kernel<false, true>, (unsigned)p.blocks, p.nchunks, 1);
+    else launch_filter(&cross_fast_kernel<false, false>, (unsigned)p.blocks, p.nchunks, 1);
     clock_end(AM_KERNEL_PRDC_CROSS, st);
     AM_LAUNCH_CHECK();
+    unsigned* rmin_or_null = want_min ? rmin : nullptr;
     const size_t verify_lds = (size_t)(4 * ((D + 7) / 8 * 8) + p.qcap) * sizeof(float);
     hipLaunchKernelGGL(cross_verify_kernel, dim3((unsigned)p.blocks), dim3(256), verify_lds, st, R, Nr, ldr, rn, rt, C, ldc, cn, ct,
-                       D, p.nchunks, b.wgq, p.qcap, b.wgq_count, col_count, rmin, rany);
+                       D, p.nchunks, b.wgq, p.qcap, b.wgq_count, col_count, rmin_or_null, rany, rcov);
     AM_LAUNCH_CHECK();
     hipLaunchKernelGGL(cross_verify_overflow_kernel, dim3(1024), dim3(256), 0, st, R, ldr, rn, rt, C, ldc, cn, ct, D, b.ovq,
-                       b.ov_count, p.ovcap, fail, col_count, rmin, rany);
+                       b.ov_count, p.ovcap, fail, col_count, rmin_or_null, rany, rcov);
     AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(cross_fail_reset_kernel, dim3(256), dim3(256), 0, st, fail, col_count, Nc, rmin, rany, Nr);
+    hipLaunchKernelGGL(cross_fail_reset_kernel, dim3(256), dim3(256), 0, st, fail, col_count, Nc, rmin, rany, rcov, Nr);
     AM_LAUNCH_CHECK();
     static const int debug = env_int("AM_FAST_DEBUG", 0);
     if (debug) {                                       // development aid: synchronises

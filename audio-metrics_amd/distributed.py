@@ -137,9 +137,9 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
         k = nearest_k
         r_ref_l, _ = sharded_radii(ref_local, ref_full, ref_counts, k, ops, world, rank, group)
         _, r_cand = sharded_radii(cand_local, cand_full, cand_counts, k, ops, world, rank, group)
-        col, rany, rmin = ops.prdc_counts(ref_local, cand_full, r_ref_l, r_cand)
+        col, rany, rcov = ops.prdc_counts(ref_local, cand_full, r_ref_l, r_cand)
         _all_reduce(col, world, group)
-        tot = ops.prdc_reduce(col, rany, rmin, r_ref_l)        # [n_prec, n_rec(local), sum_cnt, n_cov(local)]
+        tot = ops.prdc_reduce(col, rany, rcov)                 # [n_prec, n_rec(local), sum_cnt, n_cov(local)]
         rows = torch.stack((tot[1], tot[3]))                   # (no host-side index list: that would be a blocking H2D copy)
         _all_reduce(rows, world, group)
         prdc_pending = (tot, rows, k)

@@ -286,8 +286,9 @@ def knn_lists_finish(lists, x_full, k):
     return out
 
 
-def prdc_counts(ref, cand, r_ref, r_cand):
-    """col_count i32[Nc], row_any u8[Nr], row_min f32[Nr] (prdc.py:34-48)."""
+def prdc_counts(ref, cand, r_ref, r_cand, want_min=False):
+    """col_count i32[Nc], row_any u8[Nr], row_cover u8[Nr] (prdc.py:34-48); with want_min=True also the row
+    minimum f32[Nr] (not needed by any metric; costs extra)."""
     lib = _lib.load()
     ref, cand = as_matrix(ref, "reference"), as_matrix(cand, "candidate")
     _require_cuda(r_ref, "r_ref")
@@ -300,28 +301,28 @@ def prdc_counts(ref, cand, r_ref, r_cand):
         raise ValueError("radius / embedding shapes do not match")
     col = torch.empty(nc, dtype=torch.int32, device=ref.device)
     rany = torch.empty(nr, dtype=torch.uint8, device=ref.device)
-    rmin = torch.empty(nr, dtype=torch.float32, device=ref.device)
+    rcov = torch.empty(nr, dtype=torch.uint8, device=ref.device)
+    rmin = torch.empty(nr, dtype=torch.float32, device=ref.device) if want_min else None
     nb = lib.am_prdc_workspace_bytes(nr, nc, d)
     ws = _workspace(nb, ref.device)
     _call(lib, "am_prdc_counts_f32", _ptr(ref), nr, _ld(ref), _ptr(cand), nc, _ld(cand), d, _ptr(r_ref),
-                                      _ptr(r_cand), _ptr(col), _ptr(rany), _ptr(rmin), _ptr(ws), nb, _stream())
-    return col, rany, rmin
+                                      _ptr(r_cand), _ptr(col), _ptr(rany), _ptr(rcov),
+                                      _ptr(rmin) if want_min else ctypes.c_void_p(None), _ptr(ws), nb, _stream())
+    return (col, rany, rcov, rmin) if want_min else (col, rany, rcov)
 
 
-def prdc_reduce(col, rany, rmin, r_ref):
+def prdc_reduce(col, rany, rcov):
     """Four integer totals as a device int64[4]:
-    (#cols with count>0, #rows with any, sum of counts, #rows with row_min < r_ref)."""
+    (#cols with count>0, #rows with any, sum of counts, #rows covered)."""
     lib = _lib.load()
-    for t, name in ((col, "col_count"), (rany, "row_any"), (rmin, "row_min"), (r_ref, "r_ref")):
+    for t, name in ((col, "col_count"), (rany, "row_any"), (rcov, "row_cover")):
         _require_cuda(t, name)
     # the C ABI takes raw pointers: hand it exactly the element types it reads
     col = col.to(torch.int32).contiguous()
     rany = rany.to(torch.uint8).contiguous()
-    rmin = rmin.to(torch.float32).contiguous()
-    r_ref = r_ref.to(torch.float32).contiguous()
-    if rmin.numel() != rany.numel() or r_ref.numel() != rany.numel():
-        raise ValueError("row_any / row_min / r_ref lengths differ")
+    rcov = rcov.to(torch.uint8).contiguous()
+    if rcov.numel() != rany.numel():
+        raise ValueError("row_any / row_cover lengths differ")
     out = torch.empty(4, dtype=torch.int64, device=col.device)
-    _call(lib, "am_prdc_reduce", _ptr(col), col.numel(), _ptr(rany), _ptr(rmin), _ptr(r_ref), rany.numel(),
-                                  _ptr(out), _stream())
+    _call(lib, "am_prdc_reduce", _ptr(col), col.numel(), _ptr(rany), _ptr(rcov), rany.numel(), _ptr(out), _stream())
     return out

@@ -158,21 +158,27 @@ int am_knn_lists_finish_f32(const float* lists, int nparts, const float* X, int6
 /* ---------------------------------------------------------------------------
  * A10  hypersphere membership counts            reference: prdc.py:34-48
  *   With d(i,j) the distance between reference row i and candidate row j:
- *   out_col_count[j] = #{ i : d(i,j) < r_ref[i] }      (precision, density)
- *   out_row_any[i]   = any_j d(i,j) < r_cand[j]        (recall)
- *   out_row_min[i]   = min_j d(i,j)                    (coverage)
- *   Outputs are OVERWRITTEN.  am_prdc_reduce turns them into the four integer
- *   totals { #cols with count>0, #rows with any, sum of counts, #rows with
- *   row_min < r_ref } (device int64[4]); the caller divides in f64.
+ *   out_col_count[j] = #{ i : d(i,j) < r_ref[i] }             (precision, density)
+ *   out_row_any[i]   = any_j d(i,j) < r_cand[j]               (recall)
+ *   out_row_cover[i] = any_j d(i,j) < r_ref[i]                (coverage: min_j d(i,j) < r_ref[i], prdc.py:45-47)
+ *   out_row_min[i]   = min_j d(i,j)                           OPTIONAL (may be NULL): not needed by any metric
+ *   Outputs are OVERWRITTEN.  am_prdc_reduce turns the first three into the four integer totals
+ *   { #cols with count>0, #rows with any, sum of counts, #rows covered } (device int64[4]); the caller
+ *   divides in f64.
+ *   Large problems run as a bf16-MFMA FILTER pass that queues every pair whose membership its error bound
+ *   cannot decide, followed by an f32 evaluation of exactly those pairs with the arithmetic of the exact
+ *   kernel (csrc/pairwise_fast.h): the outputs are bit-identical to the exact kernel's, which remains the
+ *   path for small problems and the automatic fallback.  Asking for out_row_min adds the candidates of the
+ *   row minimum to the queue (slower).
  * ------------------------------------------------------------------------- */
 size_t am_prdc_workspace_bytes(int64_t Nr, int64_t Nc, int D);
 int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr,
                        const float* C, int64_t Nc, int64_t ldc, int D,
                        const float* r_ref, const float* r_cand,
-                       int32_t* out_col_count, uint8_t* out_row_any, float* out_row_min,
+                       int32_t* out_col_count, uint8_t* out_row_any, uint8_t* out_row_cover, float* out_row_min,
                        void* ws, size_t ws_bytes, am_stream_t stream);
 int am_prdc_reduce(const int32_t* col_count, int64_t Nc,
-                   const uint8_t* row_any, const float* row_min, const float* r_ref, int64_t Nr,
+                   const uint8_t* row_any, const uint8_t* row_cover, int64_t Nr,
                    int64_t* out4, am_stream_t stream);
 
 /* ---- optional kernel clock (benchmark support; bench.py's roofline) --------------------------------

@@ -40,9 +40,9 @@ def knn_radii(x, k, columns=None):
 
 def prdc_counts(ref, cand, r_ref, r_cand):
     d = torch.cdist(ref, cand)
-    return ((d < r_ref[:, None]).sum(0).to(torch.int32), (d < r_cand[None, :]).any(1).to(torch.uint8), d.min(1)[0])
+    return ((d < r_ref[:, None]).sum(0).to(torch.int32), (d < r_cand[None, :]).any(1).to(torch.uint8),
+            (d.min(1)[0] < r_ref).to(torch.uint8))
 
 
-def prdc_reduce(col, rany, rmin, r_ref):
-    return torch.tensor([int((col > 0).sum()), int(rany.sum()), int(col.sum()), int((rmin < r_ref).sum())],
-                        dtype=torch.int64)
+def prdc_reduce(col, rany, rcov):
+    return torch.tensor([int((col > 0).sum()), int(rany.sum()), int(col.sum()), int(rcov.sum())], dtype=torch.int64)

@@ -52,13 +52,16 @@ def test_prdc_bit_exact_and_golden(am, golden, name):
     res = am.prdc(a, b, k)
     _, aux = exact.prdc(ref, cand, k)
     ops = am.hip_ops
-    col, rany, rmin = ops.prdc_counts(a.embeddings, b.embeddings, a.get_radii(k), b.get_radii(k))
+    col, rany, rcov, rmin = ops.prdc_counts(a.embeddings, b.embeddings, a.get_radii(k), b.get_radii(k), want_min=True)
+    col3, rany3, rcov3 = ops.prdc_counts(a.embeddings, b.embeddings, a.get_radii(k), b.get_radii(k))
+    assert torch.equal(col, col3) and torch.equal(rany, rany3) and torch.equal(rcov, rcov3)   # with / without the optional minimum
     # bit-exact against the C model of the device arithmetic
     assert np.array_equal(a.get_radii(k).cpu().numpy().view(np.uint32), aux["r_ref"].view(np.uint32))
     assert np.array_equal(b.get_radii(k).cpu().numpy().view(np.uint32), aux["r_cand"].view(np.uint32))
     assert np.array_equal(col.cpu().numpy(), aux["col_count"])
     assert np.array_equal(rany.cpu().numpy(), aux["row_any"])
     assert np.array_equal(rmin.cpu().numpy().view(np.uint32), aux["row_min"].view(np.uint32))
+    assert np.array_equal(rcov.cpu().numpy().astype(bool), aux["row_min"] < aux["r_ref"])
     # against the reference's own outputs
     np.testing.assert_allclose(a.get_radii(k).cpu().numpy(), g[f"{name}/r_ref"], rtol=3e-5, atol=1e-6)
     flips = int(np.abs(col.cpu().numpy().astype(np.int64) - g[f"{name}/col_count"]).sum())
@@ -301,19 +304,21 @@ def test_knn_symmetric_fallbacks_agree():
 
 
 def test_cross_kernel_schedules_agree():
-    """The membership-count kernel under its three schedules - plain pointer staging (variant 0), the production
+    """The exact membership-count kernel under its three schedules - plain pointer staging (variant 0), the
     register-staged early-commit pipeline (35) and the LDS-direct pipeline (99, buffer_load ... lds with
-    XOR-swizzled rows) - produces identical counts, row flags and row minima."""
+    XOR-swizzled rows) - and the filter-and-verify path produce identical counts, row flags and row minima."""
     import os
     import re
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    base = dict(os.environ, AB_ROWS="5000", AB_DIM="160")
+    base = dict(os.environ, AB_ROWS="5000", AB_DIM="160", AB_WANT_MIN="1")
     outs = []
-    for variant in ("0", "35", "99"):
+    # the fourth run is the production path at this size: the bf16 filter + exact verification (pairwise_fast.h)
+    for extra in ({"AM_ENGINE_VARIANT": "0", "AM_PRDC_FAST": "0"}, {"AM_ENGINE_VARIANT": "35", "AM_PRDC_FAST": "0"},
+                  {"AM_ENGINE_VARIANT": "99", "AM_PRDC_FAST": "0"}, {}):
         res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_cross.py")],
-                             env=dict(base, AM_ENGINE_VARIANT=variant), capture_output=True, text=True, timeout=600)
+                             env=dict(base, **extra), capture_output=True, text=True, timeout=600)
         m = re.search(r"sha1 ([0-9a-f]+)", res.stdout)
         assert m, res.stdout + res.stderr
         outs.append(m.group(1))
@@ -366,11 +371,14 @@ def test_knn_and_prdc_on_clustered_data_bit_exact(am):
     ex, ey = exact.knn_radii(x, k), exact.knn_radii(y, k)
     assert np.array_equal(rx.cpu().numpy().view(np.uint32), ex.view(np.uint32))
     assert np.array_equal(ry.cpu().numpy().view(np.uint32), ey.view(np.uint32))
-    col, rany, rmin = am.hip_ops.prdc_counts(dev(x), dev(y), rx, ry)
+    col, rany, rcov, rmin = am.hip_ops.prdc_counts(dev(x), dev(y), rx, ry, want_min=True)
     ecol, eany, emin = exact.prdc_counts(x, y, ex, ey)
     assert np.array_equal(col.cpu().numpy(), ecol)
     assert np.array_equal(rany.cpu().numpy(), eany)
     assert np.array_equal(rmin.cpu().numpy().view(np.uint32), emin.view(np.uint32))
+    assert np.array_equal(rcov.cpu().numpy().astype(bool), emin < ex)
+    col3, rany3, rcov3 = am.hip_ops.prdc_counts(dev(x), dev(y), rx, ry)
+    assert torch.equal(col, col3) and torch.equal(rany, rany3) and torch.equal(rcov, rcov3)
 
 
 # ----------------------------------------------------------------- scale and odd shapes

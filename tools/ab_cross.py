@@ -15,15 +15,17 @@ gen = torch.Generator(device="cuda").manual_seed(0)
 x = torch.randn(n, d, generator=gen, device="cuda")
 y = torch.randn(n, d, generator=gen, device="cuda") * 1.05 + 0.05
 rx, ry = ops.knn_radii(x, 5), ops.knn_radii(y, 5)
-ops.prdc_counts(x, y, rx, ry)
+want_min = os.environ.get("AB_WANT_MIN", "0") == "1"
+ops.prdc_counts(x, y, rx, ry, want_min)
 torch.cuda.synchronize()
 ts = []
 for _ in range(3):
     t0 = time.perf_counter()
-    col, rany, rmin = ops.prdc_counts(x, y, rx, ry)
+    outs = ops.prdc_counts(x, y, rx, ry, want_min)
     torch.cuda.synchronize()
     ts.append(time.perf_counter() - t0)
+col, rany = outs[0], outs[1]
 import hashlib  # noqa: E402
-digest = hashlib.sha1(col.cpu().numpy().tobytes() + rany.cpu().numpy().tobytes() + rmin.cpu().numpy().tobytes()).hexdigest()[:12]
-print(f"variant={os.environ.get('AM_ENGINE_VARIANT', 'default')} sha1 {digest} cross order={os.environ.get('AM_CROSS_ORDER', '0')} wg_target={os.environ.get('AM_WG_TARGET', '8192')} N={n} D={d}: "
+digest = hashlib.sha1(b"".join(o.cpu().numpy().tobytes() for o in outs)).hexdigest()[:12]
+print(f"want_min={int(want_min)} variant={os.environ.get('AM_ENGINE_VARIANT', 'default')} sha1 {digest} cross order={os.environ.get('AM_CROSS_ORDER', '0')} wg_target={os.environ.get('AM_WG_TARGET', '8192')} N={n} D={d}: "
       f"best {min(ts) * 1e3:.2f} ms {2 * n * n * d / min(ts) / 1e12:.1f} TF  sum {int(col.sum())} {int(rany.sum())}", flush=True)

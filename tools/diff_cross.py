@@ -25,9 +25,11 @@ elif kind == "dup":
 elif kind == "self":
     y = x.clone()
 rx, ry = ops.knn_radii(x, k), ops.knn_radii(y, k)
-col, rany, rmin = ops.prdc_counts(x, y, rx, ry)
+col, rany, rcov, rmin = ops.prdc_counts(x, y, rx, ry, True)
+col2, rany2, rcov2 = ops.prdc_counts(x, y, rx, ry)
 torch.cuda.synchronize()
-np.savez(sys.argv[1], col=col.cpu().numpy(), rany=rany.cpu().numpy(), rmin=rmin.cpu().numpy(), rx=rx.cpu().numpy(), ry=ry.cpu().numpy())
+np.savez(sys.argv[1], col=col.cpu().numpy(), rany=rany.cpu().numpy(), rcov=rcov.cpu().numpy(), rmin=rmin.cpu().numpy(),
+         col2=col2.cpu().numpy(), rany2=rany2.cpu().numpy(), rcov2=rcov2.cpu().numpy())
 ''' % ROOT
 
 out = {}
@@ -41,10 +43,14 @@ for fast in ("0", "1"):
     out[fast] = np.load(fp)
 a, b = out["0"], out["1"]
 bad = 0
-for key in ("col", "rany", "rmin"):
+for key in ("col", "rany", "rcov", "rmin", "col2", "rany2", "rcov2"):
     diff = np.flatnonzero(a[key] != b[key])
     bad += len(diff)
     print(f"{key}: {len(diff)} differences", diff[:8], a[key][diff[:8]], b[key][diff[:8]])
+for k3 in ("col", "rany", "rcov"):                     # with / without the optional row minimum: same flags and counts
+    if not np.array_equal(a[k3], a[k3 + "2"]) or not np.array_equal(b[k3], b[k3 + "2"]):
+        bad += 1
+        print("want_min on/off differ in", k3)
 print("sums exact", int(a["col"].sum()), int(a["rany"].sum()), "fast", int(b["col"].sum()), int(b["rany"].sum()))
 print("IDENTICAL" if bad == 0 else "MISMATCH")
 sys.exit(0 if bad == 0 else 1)

@@ -42,8 +42,8 @@ def t_prdc():
         R, C = torch.as_tensor(ref).to(dev), torch.as_tensor(cand).to(dev)
         rr = ops.knn_radii(R, k)
         rc = ops.knn_radii(C, k)
-        col, rany, rmin = ops.prdc_counts(R, C, rr, rc)
-        tot = ops.prdc_reduce(col, rany, rmin, rr).cpu().numpy()
+        col, rany, rcov, rmin = ops.prdc_counts(R, C, rr, rc, want_min=True)
+        tot = ops.prdc_reduce(col, rany, rcov).cpu().numpy()
         _, aux = exact.prdc(ref, cand, k)
         rr_, rc_ = rr.cpu().numpy(), rc.cpu().numpy()
         print(f"{name:26s} radii bitdiff ref {int((rr_.view(np.uint32) != aux['r_ref'].view(np.uint32)).sum())}"
