@@ -30,7 +30,7 @@ SIGNATURES = {
     "am_kd_rbf_workspace_bytes": (c_size_t, [c_int, c_int]),
     "am_kd_rbf_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, _P, _P, c_int, c_int, c_double, _P, _P,
                               c_size_t, _P]),
-    "am_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "am_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
     "am_knn_radii_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, c_int, _P, _P, c_size_t, _P]),
     "am_knn_sym_eligible": (c_int, [c_int64, c_int, c_int]),
     "am_knn_list_width": (c_int, [c_int]),

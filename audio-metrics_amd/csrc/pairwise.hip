@@ -18,6 +18,26 @@ namespace am {
 
 constexpr int EV_DEFAULT = EV_RSRC | EV_FRAGDB | EV_EARLY;   // the production schedule of the tile engine
 
+// Scaled f16 copies of the filter passes (pairwise_fast.h): a matrix whose largest |element| has the f32 bit pattern
+// `maxabs_bits` is multiplied by 2^half_scale_exp so that the largest element lands in [2^13, 2^14) - far from
+// f16 overflow (65504), and small elements far from f16's subnormal range.  Powers of two: the scaling is exact.
+__device__ __forceinline__ int half_scale_exp(unsigned maxabs_bits) {
+    if (maxabs_bits == 0u) return 0;
+    const int e = (int)((maxabs_bits >> 23) & 255u) - 127;          // floor(log2(max |x|)) for a normal maximum
+    const int ex = 13 - e;
+    return ex < -60 ? -60 : (ex > 60 ? 60 : ex);
+}
+__device__ __forceinline__ bool half_scale_ok(unsigned maxabs_bits) {   // finite, and the exponent was not clamped
+    if (maxabs_bits == 0u) return true;
+    const int e = (int)((maxabs_bits >> 23) & 255u) - 127;
+    return e != 128 && e != -127 && 13 - e >= -60 && 13 - e <= 60;
+}
+// the factor that turns the dot product of two scaled copies into -2 <x, y>:  -2 * 2^-(ex + ey)   (exact)
+__device__ __forceinline__ float half_unscale(unsigned maxabs_bits_x, unsigned maxabs_bits_y) {
+    const int s = half_scale_exp(maxabs_bits_x) + half_scale_exp(maxabs_bits_y);
+    return -2.f * __uint_as_float((unsigned)(127 - s) << 23);
+}
+
 // ------------------------------------------------------------------ row norms
 // |x|^2 in f32 with a fixed order (mirrored by oracle/exact_c): lane l of the
 // row's wave fmaf-accumulates elements 4*(64t+l)+c (t = 0,1,..; c = 0..3), then
@@ -113,6 +133,7 @@ struct KnnEpilogue {
     float xn[2];
     float best[2][KCAP];
     float aux_reg;
+    float dscale = -2.f;        // -2 for f32 operands; -2 / (operand scales) for the scaled f16 filter pre-pass
     const LaneInfo& L;
 
     __device__ __forceinline__ KnnEpilogue(const LaneInfo& l) : L(l) {}
@@ -138,13 +159,13 @@ struct KnnEpilogue {
                 float tmin = INFINITY;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg)
-                    tmin = fminf(tmin, fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]));
+                    tmin = fminf(tmin, fmaf(dscale, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]));
                 tmin = fmaxf(tmin, 0.f);
                 // common case after warm-up: no lane of the wave improves its list with this 32x32 tile
                 if (__any(tmin < best[nt][KCAP - 1])) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const float d2 = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
+                        const float d2 = fmaxf(fmaf(dscale, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
                         if (__any(d2 < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], d2);
                     }
                 }
@@ -158,7 +179,7 @@ template <int KCAP, int V, bool KTAIL>
 __global__ void __launch_bounds__(ENGINE_THREADS, 2)
 knn_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ldx, const float* __restrict__ xnorm,
                    const float* __restrict__ Y, int64_t M, int64_t ldy, const float* __restrict__ ynorm,
-                   int D, int nchunks, int qstride, float* __restrict__ partial) {
+                   int D, int nchunks, int qstride, float* __restrict__ partial, const unsigned* __restrict__ half_scale) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
     // qstride > 1: only every qstride-th column tile is visited (cheap upper bounds for the symmetric kernel)
@@ -170,6 +191,7 @@ knn_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ldx, const fl
     epi.nq = M;
     epi.qtile0 = w.qtile0;
     epi.aux = lds + ENGINE_LDS_FLOATS;
+    if constexpr ((V & EV_F16) != 0) epi.dscale = half_unscale(half_scale[2], half_scale[3]);   // scaled f16 operands
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int64_t i = w.prow0 + L.wn * 64 + nt * 32 + L.r;
@@ -340,15 +362,15 @@ struct KnnSymEpilogue {
     }
 };
 
-template <int KCAP, bool KTAIL>
-__global__ void __launch_bounds__(ENGINE_THREADS, 2)
-knn_sym_kernel(const float* __restrict__ X, int64_t N, int64_t ld, const float* __restrict__ xnorm, float* thr, int D,
-               int win_tiles, int nwin, int per_win, int k1, float* __restrict__ partial, float* __restrict__ cand,
-               int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, int qcap, int* __restrict__ wgq_count, int ablate,
-               int part, int nparts) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const LaneInfo L;
-    const int64_t T = (N + TB - 1) / TB;
+// Work item of the symmetric sweep (shared by the exact kernel and the f16 filter kernel of pairwise_fast.h).
+struct SymWork {
+    int W;              // column-tile window
+    int64_t pb;         // row block
+    int64_t qa;         // first Q tile of this block inside the window
+    int ntiles;         // 0: nothing of this window belongs to this block / this rank
+};
+
+__device__ __forceinline__ SymWork sym_work(int64_t T, int win_tiles, int nwin, int per_win, int part, int nparts) {
     // Work item = (column-tile WINDOW, row block) over the CYCLIC HALF-RANGE pairing: block pb owns the tile
     // pairs (pb, q) with (q - pb) mod T in 0 .. T/2.  All workgroups in flight stream the same window of Q
     // tiles (L2 / Infinity-Cache reuse) with different row blocks.  Windows are swept in DESCENDING order: the
@@ -388,10 +410,30 @@ knn_sym_kernel(const float* __restrict__ X, int64_t N, int64_t ld, const float* 
     // multi-GPU: rank `part` of `nparts` owns the CONTIGUOUS range of row blocks with floor(pb*nparts/T) == part
     // (see am_knn_sym_part_f32).  Not pb mod nparts: consecutive blockIdx map to consecutive pb, and ownership
     // by residue would put every owned workgroup of a window on the same XCD (blockIdx % 8).
-    if (ntiles == 0 || (int)(pb * nparts / T) != part) {   // nothing of this window belongs to this block
+    SymWork w;
+    w.W = W;
+    w.pb = pb;
+    w.qa = qa;
+    w.ntiles = (ntiles == 0 || (int)(pb * nparts / T) != part) ? 0 : ntiles;
+    return w;
+}
+
+template <int KCAP, bool KTAIL>
+__global__ void __launch_bounds__(ENGINE_THREADS, 2)
+knn_sym_kernel(const float* __restrict__ X, int64_t N, int64_t ld, const float* __restrict__ xnorm, float* thr, int D,
+               int win_tiles, int nwin, int per_win, int k1, float* __restrict__ partial, float* __restrict__ cand,
+               int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, int qcap, int* __restrict__ wgq_count, int ablate,
+               int part, int nparts) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LaneInfo L;
+    const int64_t T = (N + TB - 1) / TB;
+    const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
+    if (sw.ntiles == 0) {                              // nothing of this window belongs to this block
         if (L.tid == 0) wgq_count[blockIdx.x] = 0;
         return;
     }
+    const int W = sw.W, ntiles = sw.ntiles;
+    const int64_t pb = sw.pb, qa = sw.qa;
     const int chunk = W;                               // partial-list slot
 
     KnnSymEpilogue<KCAP> epi(L);
@@ -819,7 +861,8 @@ static int launch_norms(const float* X, int64_t N, int64_t ld, int D, float* out
 
 template <int KCAP, int V, bool KTAIL>
 static int launch_knn_vt(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
-                         const float* yn, int D, int nchunks, int qstride, float* partial, hipStream_t st) {
+                         const float* yn, int D, int nchunks, int qstride, float* partial, hipStream_t st,
+                         const unsigned* half_scale = nullptr) {
     static bool attr_done = false;
     if (!attr_done) {
         AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_partial_kernel<KCAP, V, KTAIL>),
@@ -829,7 +872,7 @@ static int launch_knn_vt(const float* X, int64_t N, int64_t ldx, const float* xn
     const int64_t blocks = ceil_div(N, TB) * nchunks;
     if (qstride == 1) clock_begin(AM_KERNEL_KNN, st);         // main pass only; qstride > 1 is the sampled pre-pass
     hipLaunchKernelGGL((knn_partial_kernel<KCAP, V, KTAIL>), dim3((unsigned)blocks), dim3(ENGINE_THREADS),
-                       PAIRWISE_LDS_BYTES, st, X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial);
+                       PAIRWISE_LDS_BYTES, st, X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, half_scale);
     if (qstride == 1) clock_end(AM_KERNEL_KNN, st);
     AM_LAUNCH_CHECK();
     return AM_OK;
@@ -981,6 +1024,8 @@ struct KnnBuffers {
     uint2* wgq;
 };
 
+#include "pairwise_fast.h"      // f16 filter + exact verification forms of the two PRDC kernels
+
 static size_t carve_knn(Carver& c, int64_t N, int64_t M, const KnnPlan& p, KnnBuffers& b) {
     b.xn = c.take<float>(N);
     b.yn = c.take<float>(M);
@@ -1003,13 +1048,18 @@ static size_t carve_knn(Carver& c, int64_t N, int64_t M, const KnnPlan& p, KnnBu
     return c.off;
 }
 
-extern "C" size_t am_knn_workspace_bytes(int64_t N, int64_t M, int k) {
-    if (N < 1 || M < 1 || k < 1 || k > AM_MAX_K) return 0;
+extern "C" size_t am_knn_workspace_bytes(int64_t N, int64_t M, int D, int k) {
+    if (N < 1 || M < 1 || D < 1 || k < 1 || k > AM_MAX_K) return 0;
     // sized for the symmetric path whenever the shapes allow it (the caller may pass Y == X)
-    const KnnPlan p = plan_knn(N, M, 1 << 20, k, N == M);   // D unknown here: assume the wide case
+    const KnnPlan p = plan_knn(N, M, D, k, N == M);
     Carver c(nullptr, 0);
     KnnBuffers b;
-    return carve_knn(c, N, M, p, b);
+    carve_knn(c, N, M, p, b);
+    if (p.sym && knn_fast_enabled(N, D)) {               // f16 copy + norm / element maxima of the filter path
+        c.take<uint16_t>((size_t)N * half_ld(D));
+        c.take<unsigned>(4);
+    }
+    return c.off;
 }
 
 template <int KCAP>
@@ -1110,15 +1160,31 @@ extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const fl
     Carver c(ws, ws_bytes);
     KnnBuffers b;
     carve_knn(c, N, M, p, b);
+    bool fast = p.sym && knn_fast_enabled(N, D);
+    uint16_t* xb = nullptr;
+    unsigned* maxn = nullptr;
+    if (fast) {
+        xb = c.take<uint16_t>((size_t)N * half_ld(D));
+        maxn = c.take<unsigned>(4);
+    }
     if (!c.ok() && p.sym) {                        // a caller that sized the workspace for Y != X: general path
         p = plan_knn(N, M, D, k, false);
         c = Carver(ws, ws_bytes);
         carve_knn(c, N, M, p, b);
+        fast = false;
     }
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
     if ((rc = launch_norms(X, N, ldx, D, b.xn, st)) != AM_OK) return rc;
     if (!self && (rc = launch_norms(Y, M, ldy, D, b.yn, st)) != AM_OK) return rc;
     const int k1 = k + 1;
+    if (fast) {                                    // f16 filter sweep + exact verification (pairwise_fast.h), same bits
+        switch (p.kcap) {
+            case 6:  return run_knn_fast<6>(X, N, ldx, D, k1, p, b, xb, maxn, out_r, st);
+            case 11: return run_knn_fast<11>(X, N, ldx, D, k1, p, b, xb, maxn, out_r, st);
+            case 16: return run_knn_fast<16>(X, N, ldx, D, k1, p, b, xb, maxn, out_r, st);
+            default: return run_knn_fast<32>(X, N, ldx, D, k1, p, b, xb, maxn, out_r, st);
+        }
+    }
     switch (p.kcap) {
         case 6:  return run_knn<6>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
         case 11: return run_knn<11>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
@@ -1235,8 +1301,6 @@ extern "C" int am_knn_lists_finish_f32(const float* lists, int nparts, const flo
     }
 }
 
-#include "pairwise_fast.h"      // bf16 filter + exact verification form of the membership counts
-
 extern "C" size_t am_prdc_workspace_bytes(int64_t Nr, int64_t Nc, int D) {
     if (Nr < 1 || Nc < 1 || D < 1) return 0;
     Carver c(nullptr, 0);
@@ -1284,7 +1348,7 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
     AM_HIP_TRY(hipMemsetAsync(out_col_count, 0, (size_t)Nc * sizeof(int32_t), st));
     const int* run_flag = nullptr;
     if (fast) {
-        // bf16 filter pass + exact verification of the queued pairs (pairwise_fast.h): same outputs, bit for bit.
+        // f16 filter pass + exact verification of the queued pairs (pairwise_fast.h): same outputs, bit for bit.
         // The exact kernel is still launched behind it, but its workgroups return at once unless the filter path
         // raised its device-side fail flag (both queues overflowed).
         if ((rc = run_cross_fast(R, Nr, ldr, rn, rt, C, Nc, ldc, cn, ct, D, fplan, fbuf, out_col_count, rmin, rany, rcov,

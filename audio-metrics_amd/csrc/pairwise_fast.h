@@ -3,57 +3,69 @@
 // The exact kernels of pairwise.hip spend all their time in f32 MFMAs (157 TF peak, 96 % of the sustained rate
 // reached).  Almost none of the N x M distances they compute matter: a pair is relevant only if its squared
 // distance lies below a row or column threshold (a k-NN bound, a hypersphere radius, the running row minimum).
-// The kernels here find the relevant pairs with a 16x cheaper bf16 MFMA pass and then evaluate exactly those
+// The kernels here find the relevant pairs with a 16x cheaper f16 MFMA pass and then evaluate exactly those
 // pairs with the f32 arithmetic of the exact engine, so the results are BIT-IDENTICAL to pairwise.hip's:
 //
-//   1. X, Y are rounded to bf16 once (round-to-nearest-even).  For finite normal inputs
-//      |bf16(v) - v| <= 2^-8 |v|, hence for the bf16 dot product accumulated in f32
-//          |dot'(x,y) - <x,y>| <= (2^-7 + 2^-16) sum_k |x_k y_k| + (f32 accumulation, < 2^-14 |x||y|)
-//                              <= (2^-7 + 2^-13) |x| |y|                                   (Cauchy-Schwarz)
-//      and the approximate squared distance a = fma(-2, dot', |x|^2 + |y|^2) (same f32 norms and the same
-//      rounding of their sum as the exact value t) satisfies
-//          |a - t| <= 2 |dot' - dot_f32chain| + ulps <= FAST_C (|x|^2 + |y|^2) =: eps(x, y),
-//      FAST_C = 2^-7 + 2^-10 + 2^-12 (the 2^-10 + 2^-12 slack covers the f32 chain's own error, the error of the
-//      f32 norms and the rounding of the thresholds below, each < 2^-13 relative).
+//   1. X, Y are copied once to f16 (round-to-nearest-even) after an exact power-of-two scaling that puts each
+//      matrix's largest |element| M into [2^13, 2^14) (half_scale_exp).  A scaled element v becomes v^ with
+//      |v^ - v| <= 2^-11 |v| + eta, eta = 2^-14 (the smallest normal f16: covers subnormal operands being
+//      flushed by the matrix core).  For the f16 dot product accumulated in f32 and scaled back,
+//          |dot' - <x,y>| <= (2^-10 + 2^-21) sum_k |x_k y_k| + eta 2^-13 (|x|_1 M_y + |y|_1 M_x) (1 + 2^-11) + D eta^2 2^-26 M_x M_y
+//                             + (f32 accumulation, < 2^-14 |x||y|)
+//                         <= (2^-10 + 2^-13 + 2^-26 sqrt(D)) (|x|^2 + |y|^2 + M_x^2 + M_y^2) / 2
+//      (Cauchy-Schwarz, |x|_1 <= sqrt(D) |x|, 2ab <= a^2 + b^2), and M_x^2 <= max_i |x_i|^2.  The approximate
+//      squared distance a = fma(-2 / (scales), dot'_scaled, |x|^2 + |y|^2) (same f32 norms and the same
+//      rounding of their sum as the exact value t) therefore satisfies, for D <= 2^20,
+//          |a - t| <= FAST_C (|x|^2 + max_j |y_j|^2)  resp.  FAST_C (max_i |x_i|^2 + |y|^2),
+//      FAST_C = 2^-10 + 2^-12: twice the constant above (the 2^-12 slack also covers the f32 chain's own error,
+//      the error of the f32 norms and the rounding of the thresholds below, each < 2^-13 relative).
 //   2. A pair is QUEUED when a <= threshold + eps, which every pair with t <(=) threshold satisfies.
-//   3. Queued pairs are filed under their row, their exact t is computed with the engine's fmaf order
-//      (exact_pair_d2, the chain oracle/exact_c reproduces), and the reductions of the exact kernels are applied
-//      to those values.  Rows whose queue or candidate buffer overflowed are recomputed exactly against every
-//      column (fix-up kernels), and their queued entries are ignored.
-//
-// Inputs are assumed finite and below bf16's overflow threshold (3.4e38); f32 denormals are outside the bound
-// above only by absolute amounts below 2^-133 |y| and are ignored.
+//   3. Queued pairs are grouped by row, their exact t is computed with the engine's fmaf order
+//      (exact_pair_dot, the chain oracle/exact_c reproduces), and the reductions of the exact kernels are applied
+//      to those values.  Queue overflow falls back to the exact computation (per row for the k-NN radii, for the
+//      whole call for the membership counts), as does a matrix whose M is not a finite number within 2^+-60.
 #pragma once
 
 namespace am {
 
-constexpr int EV_FAST = EV_DEFAULT | EV_BF16;
-constexpr float FAST_C = 0.0078125f + 0.0009765625f + 0.000244140625f;       // 2^-7 + 2^-10 + 2^-12
-constexpr int FAST_LDB_ALIGN = 64;                                            // bf16 row stride: whole 128-B slabs
+constexpr int EV_FAST = EV_DEFAULT | EV_F16;
+constexpr float FAST_C = 0.0009765625f + 0.000244140625f;                     // 2^-10 + 2^-12
+constexpr int FAST_LDH_ALIGN = 64;                                            // f16 row stride: whole 128-B slabs
 
-static inline int64_t bf16_ld(int D) { return (int64_t)(D + FAST_LDB_ALIGN - 1) / FAST_LDB_ALIGN * FAST_LDB_ALIGN; }
+static inline int64_t half_ld(int D) { return (int64_t)(D + FAST_LDH_ALIGN - 1) / FAST_LDH_ALIGN * FAST_LDH_ALIGN; }
 
-// ---- f32 -> bf16 copy (RNE), zero-padded to ldb columns; one thread per 8 elements
-__device__ __forceinline__ unsigned bf16_rne(float v) {
-    unsigned u = __float_as_uint(v);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+// largest |element| of a matrix through its bit pattern (sign cleared; NaN/inf sort above every finite value)
+__global__ void __launch_bounds__(256) maxabs_bits_kernel(const float* __restrict__ X, int64_t N, int64_t ld, int D,
+                                                          unsigned* __restrict__ out) {
+    const int64_t dq = (D + 3) / 4;
+    unsigned m = 0u;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < N * dq; idx += (int64_t)gridDim.x * 256) {
+        const f32x4 v = load_k4(X + (idx / dq) * ld, (int)(idx % dq) * 4, D);
+        m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+        m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
 }
 
-__global__ void __launch_bounds__(256) to_bf16_kernel(const float* __restrict__ X, int64_t N, int64_t ld, int D, int64_t ldb,
-                                                      uint16_t* __restrict__ Xb) {
-    const int64_t per_row = ldb / 8;
+// ---- scaled f32 -> f16 copy (RNE), zero-padded to ldh columns; one thread per 8 elements
+__global__ void __launch_bounds__(256) to_half_kernel(const float* __restrict__ X, int64_t N, int64_t ld, int D, int64_t ldh,
+                                                      const unsigned* __restrict__ maxabs_bits, uint16_t* __restrict__ Xh) {
+    const int64_t per_row = ldh / 8;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = idx / per_row;
     if (row >= N) return;
+    const float sc = __uint_as_float((unsigned)(127 + half_scale_exp(*maxabs_bits)) << 23);
     const int c = (int)(idx % per_row) * 8;
     const f32x4 a = load_k4(X + row * ld, c, D), b = load_k4(X + row * ld, c + 4, D);
+    auto h = [&](float v) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(v * sc)); };
     uint4 o;
-    o.x = bf16_rne(a.x) | (bf16_rne(a.y) << 16);
-    o.y = bf16_rne(a.z) | (bf16_rne(a.w) << 16);
-    o.z = bf16_rne(b.x) | (bf16_rne(b.y) << 16);
-    o.w = bf16_rne(b.z) | (bf16_rne(b.w) << 16);
-    *reinterpret_cast<uint4*>(Xb + row * ldb + c) = o;
+    o.x = h(a.x) | (h(a.y) << 16);
+    o.y = h(a.z) | (h(a.w) << 16);
+    o.z = h(b.x) | (h(b.y) << 16);
+    o.w = h(b.z) | (h(b.w) << 16);
+    *reinterpret_cast<uint4*>(Xh + row * ldh + c) = o;
 }
 
 // max of non-negative floats (squared norms) through their bit patterns
@@ -66,10 +78,15 @@ __global__ void __launch_bounds__(256) max_bits_kernel(const float* __restrict__
     if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
 }
 
-static int launch_to_bf16(const float* X, int64_t N, int64_t ld, int D, uint16_t* Xb, hipStream_t st) {
-    const int64_t ldb = bf16_ld(D);
-    const int64_t threads = N * (ldb / 8);
-    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, X, N, ld, D, ldb, Xb);
+// stats[which] (0/1: largest squared norm, 2/3: largest |element|) of one matrix, then its scaled f16 copy
+static int launch_to_half(const float* X, int64_t N, int64_t ld, int D, const float* norms, unsigned* stats, int which,
+                          uint16_t* Xh, hipStream_t st) {
+    const int64_t ldh = half_ld(D);
+    hipLaunchKernelGGL(max_bits_kernel, dim3(256), dim3(256), 0, st, norms, N, stats + which);
+    hipLaunchKernelGGL(maxabs_bits_kernel, dim3(1024), dim3(256), 0, st, X, N, ld, D, stats + 2 + which);
+    const int64_t threads = N * (ldh / 8);
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, X, N, ld, D, ldh,
+                       stats + 2 + which, Xh);
     AM_LAUNCH_CHECK();
     return AM_OK;
 }
@@ -123,6 +140,7 @@ struct CrossFastEpilogue {
     int ovcap;
     int* fail;
     int dbg;
+    float dsc;                  // -2 / (operand scales)
     int64_t prow[2];
     float xn[2], thi[2], tlo[2], e2[2], m[2];
     bool rowok[2], anyf[2], covf[2];
@@ -181,7 +199,7 @@ struct CrossFastEpilogue {
                 float tmin = INFINITY, marg = INFINITY;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const float u = fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
+                    const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
                     tmin = fminf(tmin, u);
                     marg = fminf(marg, u - th[reg >> 2][reg & 3]);          // +inf - (-inf) = +inf past nq
                 }
@@ -194,7 +212,7 @@ struct CrossFastEpilogue {
                         const float* alo = a + 2 * TB + mt * 32;
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
-                            const float u = fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
+                            const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
                             const int64_t j = jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3);
                             const bool sure = rowok[nt] && u < tlo[nt];
                             const unsigned long long mask = __ballot(sure);
@@ -230,7 +248,7 @@ struct CrossFastShim {            // picks the epilogue body at compile time
     }
 };
 
-// Rb / Cb: bf16 copies viewed as f32 words (ld and Dh in words, Dh % 32 == 0).
+// Rb / Cb: f16 copies viewed as f32 words (ld and Dh in words, Dh % 32 == 0).
 template <bool PRE, bool WANT_MIN>
 __global__ void __launch_bounds__(ENGINE_THREADS, 2)
 cross_fast_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const float* __restrict__ rnorm,
@@ -262,6 +280,8 @@ cross_fast_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const f
     epi.ovcap = ovcap;
     epi.fail = fail;
     epi.dbg = dbg;
+    epi.dsc = half_unscale(maxn[2], maxn[3]);
+    if (blockIdx.x == 0 && L.tid == 0 && !(half_scale_ok(maxn[2]) && half_scale_ok(maxn[3]))) *fail = 1;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int64_t i = w.prow0 + L.wn * 64 + nt * 32 + L.r;
@@ -471,8 +491,8 @@ struct CrossFastBuffers {
 
 static CrossFastBuffers carve_cross_fast(Carver& c, int64_t Nr, int64_t Nc, int D, const CrossFastPlan& p) {
     CrossFastBuffers b;
-    b.rb = c.take<uint16_t>((size_t)Nr * bf16_ld(D));
-    b.cb = c.take<uint16_t>((size_t)Nc * bf16_ld(D));
+    b.rb = c.take<uint16_t>((size_t)Nr * half_ld(D));
+    b.cb = c.take<uint16_t>((size_t)Nc * half_ld(D));
     b.maxn = c.take<unsigned>(4);
     b.rmin_approx = c.take<unsigned>(Nr);
     b.wgq = c.take<uint2>((size_t)p.blocks * p.qcap);
@@ -497,15 +517,13 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
                           int64_t ldc, const float* cn, const float* ct, int D, const CrossFastPlan& p, const CrossFastBuffers& b,
                           int32_t* col_count, unsigned* rmin, unsigned* rany, unsigned* rcov, bool want_min, hipStream_t st) {
     int rc;
-    if ((rc = launch_to_bf16(R, Nr, ldr, D, b.rb, st)) != AM_OK) return rc;
-    if ((rc = launch_to_bf16(C, Nc, ldc, D, b.cb, st)) != AM_OK) return rc;
     AM_HIP_TRY(hipMemsetAsync(b.maxn, 0, 4 * sizeof(unsigned), st));
     AM_HIP_TRY(hipMemsetAsync(b.ov_count, 0, 4 * sizeof(int), st));
-    hipLaunchKernelGGL(max_bits_kernel, dim3(256), dim3(256), 0, st, rn, Nr, b.maxn);
-    hipLaunchKernelGGL(max_bits_kernel, dim3(256), dim3(256), 0, st, cn, Nc, b.maxn + 1);
+    if ((rc = launch_to_half(R, Nr, ldr, D, rn, b.maxn, 0, b.rb, st)) != AM_OK) return rc;
+    if ((rc = launch_to_half(C, Nc, ldc, D, cn, b.maxn, 1, b.cb, st)) != AM_OK) return rc;
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, b.rmin_approx, Nr, 0x7f800000u);
     AM_LAUNCH_CHECK();
-    const int64_t ldb = bf16_ld(D);
+    const int64_t ldb = half_ld(D);
     const int Dh = (int)(ldb / 2);
     const float* Rb = reinterpret_cast<const float*>(b.rb);
     const float* Cb = reinterpret_cast<const float*>(b.cb);
@@ -559,6 +577,372 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
         for (int v : wc) { tot += v; full += (v >= p.qcap); wmax = std::max(wmax, v); }
         fprintf(stderr, "[cross_fast] blocks=%lld nchunks=%d queued=%lld (max/wg %d, full regions %lld) overflow queue=%d fail=%d\n",
                 (long long)p.blocks, p.nchunks, tot, wmax, full, ovc[0], ovc[1]);
+    }
+    return AM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-NN radii of a set against itself, filter pass: the symmetric sweep of knn_sym_kernel on the f16 copy.
+// thr[i] is an upper bound of (true (k+1)-th smallest t of row i) + E_i, E_i = FAST_C (|x_i|^2 + max_j |x_j|^2):
+// every pair with t_ij <= the row's final value has a_ij <= thr[i], in whichever direction it is met.
+//   own rows (lane-local):  queue (i, j) when a <= min(thr[i] at workgroup start, kthA + 2 E_i), kthA = the
+//                           (k+1)-th smallest max(a, 0) this lane has seen (true values of those columns are
+//                           <= max(a, 0) + E_i, so kthA + E_i bounds the row's final value from above);
+//   mirrored (Q rows):      queue (j, i) when a <= thr[j].
+// The per-lane lists are merged per row and window, published (kthA + 2 E_i, cumulative over the windows done)
+// exactly like the exact kernel's, but they only steer the filter: the radii come from the exact values of the
+// queued pairs (knn_fast_verify_kernel -> knn_sym_scatter_kernel -> knn_fast_select_kernel).
+// Queue entry: (target row, other row | FAST_INBLOCK if the TARGET is the row of this workgroup's block).
+constexpr unsigned FAST_INBLOCK = 0x80000000u;
+
+template <int KCAP>
+struct KnnFastEpilogue {
+    const float* qnorm;
+    const float* thr;
+    int64_t n, pblock;
+    float* aux;                 // LDS [2][2][128] : |x_j|^2 and thr[j] of the tile
+    uint2* wgq;
+    int* qn;
+    int qcap;
+    int* cnt;
+    int cap;
+    float dsc;                  // -2 / (operand scale)^2
+    int64_t prow[2];
+    float xn[2], flt[2], e2[2];
+    bool rowok[2];
+    float best[2][KCAP];        // ascending; the first KCAP - (k+1) slots are -inf pads, so best[KCAP-1] is the (k+1)-th smallest
+    float aux_n, aux_t;
+    const LaneInfo& L;
+
+    __device__ __forceinline__ KnnFastEpilogue(const LaneInfo& l) : L(l) {}
+    __device__ __forceinline__ void push(int64_t target, unsigned other) {
+        const int slot = atomicAdd(qn, 1);
+        if (slot < qcap) wgq[slot] = make_uint2((unsigned)target, other);
+        else atomicAdd(cnt + target, cap + 1);              // region full: the row goes to the exact fix-up kernel
+    }
+    __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
+        if (L.tid < TB) {
+            const int64_t j = qtile * TB + L.tid;
+            aux_n = j < n ? qnorm[j] : INFINITY;
+            aux_t = j < n ? __hip_atomic_load(thr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+        }
+    }
+    __device__ __forceinline__ void aux_commit(int t) {
+        if (L.tid < TB) {
+            aux[(t & 1) * 2 * TB + L.tid] = aux_n;
+            aux[(t & 1) * 2 * TB + TB + L.tid] = aux_t;
+        }
+    }
+    __device__ __forceinline__ void finish(int t, int64_t qtile, f32x16 (&acc)[2][2]) {
+        const float* a = aux + (t & 1) * 2 * TB + L.wm * 64 + L.h * 4;
+        const bool mirror = qtile != pblock;                // the diagonal tile holds both directions itself
+        const int64_t jbase = qtile * TB + L.wm * 64 + L.h * 4;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 yn[4], tq[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
+                tq[g4] = *reinterpret_cast<const f32x4*>(a + TB + mt * 32 + g4 * 8);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float tmin = INFINITY, marg = INFINITY;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
+                    tmin = fminf(tmin, u);
+                    marg = fminf(marg, u - tq[reg >> 2][reg & 3]);
+                }
+                float pl = fminf(flt[nt], best[nt][KCAP - 1] + e2[nt]);
+                if (__any(rowok[nt] && (tmin <= pl || (mirror && marg <= 0.f)))) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
+                        const int64_t j = jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3);
+                        const bool own = rowok[nt] && u <= pl;
+                        if (own) push(prow[nt], (unsigned)j | FAST_INBLOCK);
+                        const float v = own ? fmaxf(u, 0.f) : INFINITY;
+                        if (__any(v < best[nt][KCAP - 1])) {
+                            list_insert<KCAP>(best[nt], v);
+                            pl = fminf(flt[nt], best[nt][KCAP - 1] + e2[nt]);
+                        }
+                        if (mirror && rowok[nt] && u <= tq[reg >> 2][reg & 3]) push(j, (unsigned)prow[nt]);
+                    }
+                }
+            }
+        }
+    }
+};
+
+// Xb: f16 copy viewed as f32 words (ldh, Dh in words).  Same grid and work mapping as knn_sym_kernel.
+template <int KCAP>
+__global__ void __launch_bounds__(ENGINE_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
+knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float* __restrict__ xnorm, float* thr, int Dh,
+                int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
+                int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, int qcap, int* __restrict__ wgq_count) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LaneInfo L;
+    const int64_t T = (N + TB - 1) / TB;
+    const SymWork sw = sym_work(T, win_tiles, nwin, per_win, 0, 1);
+    if (sw.ntiles == 0) {
+        if (L.tid == 0) wgq_count[blockIdx.x] = 0;
+        return;
+    }
+    const float nmax = __uint_as_float(maxn[0]);
+    KnnFastEpilogue<KCAP> epi(L);
+    epi.qnorm = xnorm;
+    epi.thr = thr;
+    epi.n = N;
+    epi.pblock = sw.pb;
+    epi.aux = lds + ENGINE_LDS_FLOATS;
+    epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
+    epi.qn = reinterpret_cast<int*>(lds + ENGINE_LDS_FLOATS + 4 * TB);
+    epi.qcap = qcap;
+    epi.cnt = cnt;
+    epi.cap = cap;
+    epi.dsc = half_unscale(maxn[2], maxn[2]);
+    if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int64_t i = sw.pb * TB + L.wn * 64 + nt * 32 + L.r;
+        epi.prow[nt] = i;
+        epi.rowok[nt] = i < N;
+        epi.xn[nt] = i < N ? xnorm[i] : 0.f;
+        epi.e2[nt] = 2.f * FAST_C * ((i < N ? xnorm[i] : 0.f) + nmax);
+        epi.flt[nt] = i < N ? __hip_atomic_load(thr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = s < KCAP - k1 ? -INFINITY : INFINITY;
+    }
+    dense_pipeline_early<EV_FAST, false>(Xb, N, ldh, LinearTiles{sw.qa}, Xb, N, ldh, sw.pb * TB, sw.ntiles, Dh, lds, L, epi);
+    float* mg = lds;                                   // [128][4][KCAP]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float* dst = mg + ((L.wn * 64 + nt * 32 + L.r) * 4 + (L.wm * 2 + L.h)) * KCAP;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
+    }
+    __syncthreads();
+    if (L.tid == 0) wgq_count[blockIdx.x] = min(*epi.qn, qcap);
+    if (L.tid < TB) {
+        const int64_t i = sw.pb * TB + L.tid;
+        if (i < N) {
+            const float* src = mg + L.tid * 4 * KCAP;
+            float m[KCAP];                             // same padding: m[KCAP-1] = (k+1)-th smallest of the finite entries
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) m[s] = src[s];
+            for (int s = KCAP; s < 4 * KCAP; ++s)
+                if (src[s] > -INFINITY) list_insert<KCAP>(m, src[s]);
+            float* out = partial + ((int64_t)sw.W * N + i) * KCAP;
+            // write-through stores / agent-scope loads: other XCDs read these lists while the kernel runs
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) __hip_atomic_store(out + s, m[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int w2 = sw.W + 1; w2 < nwin; ++w2) {      // cumulative over the windows already swept (distinct columns)
+                const float* src2 = partial + ((int64_t)w2 * N + i) * KCAP;
+                for (int s = 0; s < KCAP; ++s) {
+                    const float v = __hip_atomic_load(src2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v > -INFINITY) list_insert<KCAP>(m, v);
+                }
+            }
+            const float kthv = m[KCAP - 1];
+            const float bound = kthv + 2.f * FAST_C * (xnorm[i] + nmax);     // >= 0, so its bit pattern orders like the value
+            atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
+        }
+    }
+}
+
+// pre-pass result (approximate (k+1)-th smallest over the column sample) -> filter bound
+__global__ void __launch_bounds__(256) knn_fast_bound_kernel(float* __restrict__ thr, const float* __restrict__ xnorm, int64_t n,
+                                                             const unsigned* __restrict__ maxn) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) thr[i] = thr[i] + 2.f * FAST_C * (xnorm[i] + __uint_as_float(maxn[0]));     // +inf stays +inf
+}
+
+// Exact value of every queued pair of one region, written back as (target row, bits of t).  The entries are
+// bucketed by the row that belongs to this workgroup's block (target or other): that row goes to LDS once and
+// every lane evaluates one partner row with the exact engine's fmaf chain (t(i,j) == t(j,i) bit for bit).
+__global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __restrict__ X, int64_t N, int64_t ld,
+                                                              const float* __restrict__ xnorm, int D, int win_tiles, int nwin,
+                                                              int per_win, uint2* __restrict__ wgq, int qcap,
+                                                              const int* __restrict__ wgq_count) {
+    extern __shared__ __attribute__((aligned(16))) float vlds[];       // [4][dp] rows, then 2 x qcap sorted words
+    __shared__ int bucket[TB], start[TB];
+    const int n = wgq_count[blockIdx.x];
+    if (n == 0) return;
+    const int dp = (D + 7) / 8 * 8;
+    unsigned* s_target = reinterpret_cast<unsigned*>(vlds + 4 * dp);
+    unsigned* s_other = s_target + qcap;
+    uint2* q = wgq + (int64_t)blockIdx.x * qcap;
+    const int64_t T = (N + TB - 1) / TB;
+    const int64_t prow0 = sym_work(T, win_tiles, nwin, per_win, 0, 1).pb * TB;
+    if (threadIdx.x < TB) bucket[threadIdx.x] = 0;
+    __syncthreads();
+    constexpr int PER = 8;                                             // qcap <= 256 * PER
+    int pos[PER];
+    uint2 ent[PER];
+#pragma unroll
+    for (int s = 0; s < PER; ++s) {
+        const int e = threadIdx.x + s * 256;
+        pos[s] = 0;
+        if (e < n) {
+            ent[s] = q[e];
+            const int64_t inblock = (ent[s].y & FAST_INBLOCK) ? ent[s].x : (ent[s].y & ~FAST_INBLOCK);
+            pos[s] = atomicAdd(&bucket[(int)(inblock - prow0)], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                                            // exclusive scan of the 128 bucket sizes
+        const int a0 = bucket[2 * threadIdx.x], a1 = bucket[2 * threadIdx.x + 1];
+        int v = a0 + a1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(v, off);
+            if ((int)threadIdx.x >= off) v += o;
+        }
+        start[2 * threadIdx.x] = v - a0 - a1;
+        start[2 * threadIdx.x + 1] = v - a1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < PER; ++s) {
+        const int e = threadIdx.x + s * 256;
+        if (e < n) {
+            const int64_t inblock = (ent[s].y & FAST_INBLOCK) ? ent[s].x : (ent[s].y & ~FAST_INBLOCK);
+            const int dst = start[(int)(inblock - prow0)] + pos[s];
+            s_target[dst] = ent[s].x;
+            s_other[dst] = ent[s].y;
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* xs = vlds + wave * dp;
+    for (int lr = wave; lr < TB; lr += 4) {
+        const int c = bucket[lr];
+        if (c == 0) continue;
+        const int64_t i = prow0 + lr;
+        for (int k = lane; k < dp; k += 64) xs[k] = k < D ? X[i * ld + k] : 0.f;
+        __builtin_amdgcn_wave_barrier();
+        const float xi = xnorm[i];
+        for (int e0 = 0; e0 < c; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < c) {
+                const int at = start[lr] + e;
+                const unsigned tg = s_target[at], ot = s_other[at];
+                const int64_t partner = (ot & FAST_INBLOCK) ? (int64_t)(ot & ~FAST_INBLOCK) : (int64_t)tg;
+                const float t = fmaxf(fmaf(-2.f, exact_pair_dot(xs, X + partner * ld, D), xi + xnorm[partner]), 0.f);
+                q[at] = make_uint2(tg, __float_as_uint(t));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// radius[i] = sqrt_rn( (k+1)-th smallest exact value filed under row i ); overflowed rows -> exact fix-up
+template <int KCAP>
+__global__ void knn_fast_select_kernel(const float* __restrict__ cand, const int* __restrict__ cnt, int cap, int64_t N, int k1,
+                                       const unsigned* __restrict__ maxn, float* __restrict__ radii, int* __restrict__ ov_list,
+                                       int* __restrict__ ov_count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int c = cnt[i];
+    if (c > cap || c < k1 || !half_scale_ok(maxn[2])) {                           // c < k1 cannot happen (the true top k+1 are always queued); be safe
+        ov_list[atomicAdd(ov_count, 1)] = (int)i;
+        return;
+    }
+    float m[KCAP];
+#pragma unroll
+    for (int s = 0; s < KCAP; ++s) m[s] = INFINITY;
+    const float* src = cand + i * cap;
+    for (int s = 0; s < c; ++s) {
+        const float v = src[s];
+        if (v < m[KCAP - 1]) list_insert<KCAP>(m, v);
+    }
+    float r2 = m[0];
+#pragma unroll
+    for (int s = 1; s < KCAP; ++s)
+        if (s == k1 - 1) r2 = m[s];
+    radii[i] = sqrt_rn(r2);
+}
+
+static bool knn_fast_enabled(int64_t N, int D) {
+    static const int on = env_int("AM_KNN_FAST", 1);
+    static const int min_rows = env_int("AM_KNN_FAST_MIN_ROWS", 32768);   // below: the exact symmetric kernel is faster (measured)
+    const size_t verify_lds = (size_t)(4 * ((D + 7) / 8 * 8) + 2 * 2048) * sizeof(float);
+    return on != 0 && N >= min_rows && D >= 32 && verify_lds <= 60 * 1024;
+}
+
+// X: N x D f32 (exact verification), xb: workspace for the f16 copy; plan / buffers of the symmetric path.
+template <int KCAP>
+static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, const KnnPlan& p, const KnnBuffers& b,
+                        uint16_t* xb, unsigned* maxn, float* out_r, hipStream_t st) {
+    int rc;
+    const int64_t ldh = half_ld(D) / 2;                              // row stride of the f16 copy in f32 words
+    const int Dh = (int)ldh;
+    const float* Xb = reinterpret_cast<const float*>(xb);
+    AM_HIP_TRY(hipMemsetAsync(maxn, 0, 4 * sizeof(unsigned), st));
+    if ((rc = launch_to_half(X, N, ld, D, b.xn, maxn, 0, xb, st)) != AM_OK) return rc;
+    AM_HIP_TRY(hipMemcpyAsync(maxn + 3, maxn + 2, sizeof(unsigned), hipMemcpyDeviceToDevice, st));   // both operands are X
+    // 1) filter bounds for the rows of the top windows from a sampled f16 pass of the general kernel
+    // (every row, unlike the exact kernel: here a row's OWN entries are queued too, so it needs a bound from the start)
+    const int64_t row_lo = 0;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st,
+                       reinterpret_cast<unsigned*>(b.thr), N, 0x7f800000u);
+    AM_LAUNCH_CHECK();
+    if (row_lo < N) {
+        const int64_t nr = N - row_lo;
+        if ((rc = launch_knn_vt<KCAP, EV_FAST, false>(Xb + row_lo * ldh, nr, ldh, b.xn + row_lo, Xb, N, ldh, b.xn, Dh, p.pre_chunks,
+                                                      p.pre_stride, b.partial, st, maxn)) != AM_OK)
+            return rc;
+        hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(nr, 256)), dim3(256), 0, st, b.partial, nr, p.pre_chunks,
+                           k1, 1, b.thr + row_lo);
+        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(nr, 256)), dim3(256), 0, st, b.thr + row_lo,
+                           b.xn + row_lo, nr, maxn);
+        AM_LAUNCH_CHECK();
+    }
+    AM_HIP_TRY(hipMemsetAsync(b.cnt, 0, (size_t)(N + 1) * sizeof(int), st));
+    // 2) symmetric filter sweep
+    const unsigned nwg = (unsigned)p.nwin * (unsigned)p.per_win;
+    const int64_t nlist = (int64_t)p.nwin * N * KCAP;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)ceil_div(nlist, 256)), dim3(256), 0, st,
+                       reinterpret_cast<unsigned*>(b.partial), nlist, 0x7f800000u);
+    AM_LAUNCH_CHECK();
+    static bool attr_done = false;
+    if (!attr_done) {
+        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_fast_kernel<KCAP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIRWISE_LDS_BYTES + 16));
+        attr_done = true;
+    }
+    const int qcap = std::min(p.qcap, 2048);                            // knn_fast_verify_kernel: <= 256 * 8
+    clock_begin(AM_KERNEL_KNN, st);
+    hipLaunchKernelGGL(knn_fast_kernel<KCAP>, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st, Xb, N, ldh, b.xn, b.thr,
+                       Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, qcap, b.wgq_count);
+    clock_end(AM_KERNEL_KNN, st);
+    AM_LAUNCH_CHECK();
+    // 3) exact values of the queued pairs, 4) filed under their rows, 5) selection, 6) exact fix-up of overflowed rows
+    const size_t verify_lds = (size_t)(4 * ((D + 7) / 8 * 8) + 2 * qcap) * sizeof(float);
+    hipLaunchKernelGGL(knn_fast_verify_kernel, dim3(nwg), dim3(256), verify_lds, st, X, N, ld, b.xn, D, p.win_tiles, p.nwin,
+                       p.per_win, b.wgq, qcap, b.wgq_count);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_sym_scatter_kernel, dim3(nwg), dim3(256), 0, st, b.wgq, qcap, b.wgq_count, b.cand, b.cnt, p.cap);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_fast_select_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.cand, b.cnt, p.cap, N, k1,
+                       maxn, out_r, b.ov_list, b.ov_count);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
+                       b.xn, D, k1, b.ov_list, b.ov_count, out_r);
+    AM_LAUNCH_CHECK();
+    static const int debug = env_int("AM_FAST_DEBUG", 0);
+    if (debug) {                                       // development aid: synchronises
+        AM_HIP_TRY(hipStreamSynchronize(st));
+        std::vector<int> wc(nwg), cn(N + 1);
+        AM_HIP_TRY(hipMemcpy(wc.data(), b.wgq_count, nwg * sizeof(int), hipMemcpyDeviceToHost));
+        AM_HIP_TRY(hipMemcpy(cn.data(), b.cnt, (N + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        long long tot = 0, full = 0, ctot = 0;
+        int wmax = 0, cmax = 0;
+        for (int v : wc) { tot += v; full += (v >= qcap); wmax = std::max(wmax, v); }
+        for (int64_t i = 0; i < N; ++i) { ctot += std::min(cn[i], p.cap); cmax = std::max(cmax, cn[i]); }
+        fprintf(stderr, "[knn_fast] wgs=%u nwin=%d qcap=%d queued=%lld (max/wg %d, full regions %lld) filed=%lld max/row=%d "
+                        "rows to fix-up=%d\n", nwg, p.nwin, qcap, tot, wmax, full, ctot, cmax, cn[N]);
     }
     return AM_OK;
 }

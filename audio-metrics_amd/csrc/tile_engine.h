@@ -282,7 +282,7 @@ __device__ __forceinline__ void dense_pipeline(const float* __restrict__ Q, int6
 
 constexpr int EV_EARLY = 32;     // loads issued two stages ahead, LDS writes placed inside the MFMA stream
 constexpr int EV_LDS = 64;       // operands go global -> LDS directly (buffer_load ... lds); needs D % 32 == 0
-constexpr int EV_BF16 = 128;     // operands are bf16 pairs viewed as f32 words (filter passes only)
+constexpr int EV_F16 = 128;      // operands are f16 pairs viewed as f32 words (filter passes only)
 
 // LDS image of the LDS-direct variant: unpadded 128-B rows (a wave's buffer_load_dwordx4 ... lds writes 64 x 16 B
 // contiguously = 8 whole rows), 16-B chunks XOR-swizzled by (row & 7) so the MFMA fragment reads stay conflict-free.
@@ -310,18 +310,18 @@ __device__ __forceinline__ FragSet read_frags(const float* __restrict__ q, const
     return f;
 }
 
-// bf16 operands (EV_BF16): the same 16-B fragment is eight bf16 inner elements, consumed by ONE
-// v_mfma_f32_32x32x16_bf16 (lane half h supplies k = 8h .. 8h+7 of the 16-wide step), so a 128-B slab row is 64
+// f16 operands (EV_F16): the same 16-B fragment is eight half-precision inner elements, consumed by ONE
+// v_mfma_f32_32x32x16_f16 (lane half h supplies k = 8h .. 8h+7 of the 16-wide step), so a 128-B slab row is 64
 // inner elements and a stage issues 16 MFMAs instead of 64.  Used only by the filter passes of pairwise_fast.h,
 // whose results are re-verified in f32; the accumulation order inside the instruction is irrelevant there.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void mfma_chunk_bf16(const FragSet& f, f32x16 (&acc)[2][2]) {
-    const bf16x8 qa = __builtin_bit_cast(bf16x8, f.qa), qb = __builtin_bit_cast(bf16x8, f.qb);
-    const bf16x8 pa = __builtin_bit_cast(bf16x8, f.pa), pb = __builtin_bit_cast(bf16x8, f.pb);
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, pa, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, pb, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qb, pa, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qb, pb, acc[1][1], 0, 0, 0);
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mfma_chunk_f16(const FragSet& f, f32x16 (&acc)[2][2]) {
+    const f16x8 qa = __builtin_bit_cast(f16x8, f.qa), qb = __builtin_bit_cast(f16x8, f.qb);
+    const f16x8 pa = __builtin_bit_cast(f16x8, f.pa), pb = __builtin_bit_cast(f16x8, f.pb);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, pa, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, pb, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qb, pa, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qb, pb, acc[1][1], 0, 0, 0);
 }
 
 __device__ __forceinline__ void mfma_chunk(const FragSet& f, f32x16 (&acc)[2][2]) {
@@ -568,7 +568,7 @@ __device__ __forceinline__ void addr_pipeline_early(const QAddrFn& qaddr, const 
         const float* sq = lds + (g & 1) * STAGE_FLOATS + (L.wm * 64 + L.r) * LDK + L.h * 4;
         const float* sp = lds + (g & 1) * STAGE_FLOATS + TILE_FLOATS + (L.wn * 64 + L.r) * LDK + L.h * 4;
         auto mm = [&](const FragSet& f) {
-            if constexpr ((V & EV_BF16) != 0) mfma_chunk_bf16(f, acc);
+            if constexpr ((V & EV_F16) != 0) mfma_chunk_f16(f, acc);
             else mfma_chunk(f, acc);
         };
         FragSet f0 = read_frags(sq, sp, 0);

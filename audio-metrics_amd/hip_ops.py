@@ -232,7 +232,7 @@ def knn_radii(x, k, columns=None):
     if y.shape[1] != d:
         raise ValueError("feature dimensions differ")
     out = torch.empty(n, dtype=torch.float32, device=x.device)
-    nb = lib.am_knn_workspace_bytes(n, y.shape[0], int(k))
+    nb = lib.am_knn_workspace_bytes(n, y.shape[0], d, int(k))
     ws = _workspace(nb, x.device)
     _call(lib, "am_knn_radii_f32", _ptr(x), n, _ld(x), _ptr(y), y.shape[0], _ld(y), d, int(k), _ptr(out),
                                     _ptr(ws), nb, _stream())

@@ -127,7 +127,7 @@ int am_kd_rbf_f32(const float* X, int64_t N1, int64_t ldx,
  *   Distances follow torch.cdist's matmul form  sqrt(max(|x|^2+|y|^2-2x.y, 0))
  *   in f32; no N x M matrix is materialised.  1 <= k <= AM_MAX_K, k+1 <= M.
  * ------------------------------------------------------------------------- */
-size_t am_knn_workspace_bytes(int64_t N, int64_t M, int k);
+size_t am_knn_workspace_bytes(int64_t N, int64_t M, int D, int k);
 int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx,
                      const float* Y, int64_t M, int64_t ldy, int D, int k,
                      float* out_r, void* ws, size_t ws_bytes, am_stream_t stream);

@@ -39,8 +39,8 @@ def test_host_side_entry_points():
     for t in [(1.0, 2.0, 3.0), (5.0, 1.0, 3.0), (-1.0, -1.0, -1.0), (2.0, 2.0, 0.0), (0.3, 0.9, 0.1)]:
         assert lib.am_apa_f64(*t) == oracle.apa_from_distances(*t)
     # workspace queries are pure host functions
-    assert lib.am_knn_workspace_bytes(100000, 100000, 5) > 0
-    assert lib.am_knn_workspace_bytes(10, 10, 99) == 0
+    assert lib.am_knn_workspace_bytes(100000, 100000, 512, 5) > 0
+    assert lib.am_knn_workspace_bytes(10, 10, 16, 99) == 0
     assert lib.am_stats_workspace_bytes(100000, 512) > 0
     assert lib.am_frechet_workspace_bytes(512) >= 6 * 512 * 512 * 8
     assert lib.am_kd_workspace_bytes(100, 1000) > 0

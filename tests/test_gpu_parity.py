@@ -285,7 +285,8 @@ def test_knn_symmetric_path_bit_exact(am):
 
 def test_knn_symmetric_fallbacks_agree():
     """General kernel, symmetric kernel, symmetric kernel with a 2-slot candidate buffer (every row overflows
-    -> exact fix-up kernel) and with a 16-entry workgroup queue (direct per-row pushes) give identical bits.
+    -> exact fix-up kernel) and with a 16-entry workgroup queue (direct per-row pushes), and the f16 filter path
+    (plain, with overflowing candidate buffers, with overflowing queue regions) give identical bits.
     The knobs are process-wide environment variables, hence subprocesses."""
     import os
     import re
@@ -294,7 +295,9 @@ def test_knn_symmetric_fallbacks_agree():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = dict(os.environ, AB_ROWS="9000", AB_DIM="160", AB_K="5", AB_REPS="1")
     outs = []
-    for extra in ({"AM_KNN_SYM_MIN_ROWS": "100000000"}, {}, {"AM_KNN_SYM_CAP": "2"}, {"AM_KNN_SYM_QCAP": "16"}):
+    fast = {"AM_KNN_FAST_MIN_ROWS": "1000"}           # the f16 filter + exact verification path (pairwise_fast.h)
+    for extra in ({"AM_KNN_SYM_MIN_ROWS": "100000000"}, {}, {"AM_KNN_SYM_CAP": "2"}, {"AM_KNN_SYM_QCAP": "16"},
+                  fast, dict(fast, AM_KNN_SYM_CAP="2"), dict(fast, AM_KNN_SYM_QCAP="16")):
         res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_knn.py")], env=dict(base, **extra),
                              capture_output=True, text=True, timeout=600)
         m = re.search(r"radii sha1 ([0-9a-f]+)", res.stdout)
@@ -323,6 +326,26 @@ def test_cross_kernel_schedules_agree():
         assert m, res.stdout + res.stderr
         outs.append(m.group(1))
     assert len(set(outs)) == 1, outs
+
+
+@pytest.mark.parametrize("rows,dim,k", [(40000, 128, 5), (33000, 200, 10)])
+def test_knn_filter_path_bit_identical_at_production_sizes(rows, dim, k):
+    """At >= 32768 rows am_knn_radii_f32 runs the f16 filter sweep + exact verification; its radii equal the exact
+    symmetric kernel's bit for bit."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ, AB_ROWS=str(rows), AB_DIM=str(dim), AB_K=str(k), AB_REPS="1")
+    outs = []
+    for extra in ({"AM_KNN_FAST": "0"}, {}):
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_knn.py")], env=dict(base, **extra),
+                             capture_output=True, text=True, timeout=600)
+        m = re.search(r"radii sha1 ([0-9a-f]+)", res.stdout)
+        assert m, res.stdout + res.stderr
+        outs.append(m.group(1))
+    assert outs[0] == outs[1], outs
 
 
 # ----------------------------------------------------------------- PCA projection (n_pca)
