@@ -1011,10 +1011,10 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
     else p.pre_windows = std::min<int>(p.nwin, (int)ceil_div(512, p.per_win) + 2);
     p.nchunks = p.nwin;                               // partial-list slots
     // expected survivors per workgroup when only the sample bound is known:
-    //   pairs = 128 * win_tiles * 128, hit rate = (k+1) / (N / stride); keep 4x head-room
+    //   pairs = 128 * win_tiles * 128, hit rate = (k+1) / (N / stride); keep 8x head-room
     const double expect = 128.0 * 128.0 * p.win_tiles * (double)(k + 1) * stride / (double)N;
     static const int qcap_env = env_int("AM_KNN_SYM_QCAP", 0);
-    p.qcap = qcap_env > 0 ? qcap_env : (int)std::min(8192.0, std::max(256.0, 4.0 * expect));
+    p.qcap = qcap_env > 0 ? qcap_env : (int)std::min(8192.0, std::max(256.0, 8.0 * expect));   // (the f16 filter path queues both directions)
     return p;
 }
 

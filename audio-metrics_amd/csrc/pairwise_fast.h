@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __res
     const int64_t prow0 = sym_work(T, win_tiles, nwin, per_win, 0, 1).pb * TB;
     if (threadIdx.x < TB) bucket[threadIdx.x] = 0;
     __syncthreads();
-    constexpr int PER = 8;                                             // qcap <= 256 * PER
+    constexpr int PER = 16;                                            // qcap <= 256 * PER
     int pos[PER];
     uint2 ent[PER];
 #pragma unroll
@@ -867,7 +867,7 @@ __global__ void knn_fast_select_kernel(const float* __restrict__ cand, const int
 static bool knn_fast_enabled(int64_t N, int D) {
     static const int on = env_int("AM_KNN_FAST", 1);
     static const int min_rows = env_int("AM_KNN_FAST_MIN_ROWS", 32768);   // below: the exact symmetric kernel is faster (measured)
-    const size_t verify_lds = (size_t)(4 * ((D + 7) / 8 * 8) + 2 * 2048) * sizeof(float);
+    const size_t verify_lds = (size_t)(4 * ((D + 7) / 8 * 8) + 2 * 4096) * sizeof(float);
     return on != 0 && N >= min_rows && D >= 32 && verify_lds <= 60 * 1024;
 }
 
@@ -912,7 +912,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIRWISE_LDS_BYTES + 16));
         attr_done = true;
     }
-    const int qcap = std::min(p.qcap, 2048);                            // knn_fast_verify_kernel: <= 256 * 8
+    const int qcap = std::min(p.qcap, 4096);                            // knn_fast_verify_kernel: <= 256 * 16
     clock_begin(AM_KERNEL_KNN, st);
     hipLaunchKernelGGL(knn_fast_kernel<KCAP>, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st, Xb, N, ldh, b.xn, b.thr,
                        Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, qcap, b.wgq_count);
@@ -941,6 +941,14 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
         int wmax = 0, cmax = 0;
         for (int v : wc) { tot += v; full += (v >= qcap); wmax = std::max(wmax, v); }
         for (int64_t i = 0; i < N; ++i) { ctot += std::min(cn[i], p.cap); cmax = std::max(cmax, cn[i]); }
+        {
+            int shown = 0;
+            for (int64_t i = 0; i < N && shown < 24; ++i)
+                if (cn[i] > p.cap) { fprintf(stderr, " row %lld cnt %d;", (long long)i, cn[i]); ++shown; }
+            for (unsigned g = 0, sh = 0; g < nwg && sh < 8; ++g)
+                if (wc[g] >= qcap) { fprintf(stderr, " fullwg %u (win %d, e %u);", g, p.nwin - 1 - (int)(g / p.per_win), g % p.per_win); ++sh; }
+            fprintf(stderr, "\n");
+        }
         fprintf(stderr, "[knn_fast] wgs=%u nwin=%d qcap=%d queued=%lld (max/wg %d, full regions %lld) filed=%lld max/row=%d "
                         "rows to fix-up=%d\n", nwg, p.nwin, qcap, tot, wmax, full, ctot, cmax, cn[N]);
     }
