@@ -44,6 +44,8 @@ SIGNATURES = {
     "am_prdc_reduce": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P]),
     "am_kernel_clock_enable": (c_int, [c_int]),
     "am_kernel_clock_read": (c_int, [c_int, _P, _P]),
+    "am_knn_path": (c_int, [c_int64, c_int64, c_int, c_int, c_int]),
+    "am_prdc_path": (c_int, [c_int64, c_int64, c_int]),
 }
 
 

@@ -19,7 +19,7 @@ void set_error(const char* fmt, ...) {
 
 // ---- kernel clock ---------------------------------------------------------------------------------
 namespace {
-constexpr int N_CLOCKED = 2;
+constexpr int N_CLOCKED = 4;
 std::atomic<int> g_clock_on{0};
 std::mutex g_clock_mu;
 struct ClockRecord {

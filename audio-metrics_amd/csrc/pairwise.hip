@@ -1055,10 +1055,7 @@ extern "C" size_t am_knn_workspace_bytes(int64_t N, int64_t M, int D, int k) {
     Carver c(nullptr, 0);
     KnnBuffers b;
     carve_knn(c, N, M, p, b);
-    if (p.sym && knn_fast_enabled(N, D)) {               // f16 copy + norm / element maxima of the filter path
-        c.take<uint16_t>((size_t)N * half_ld(D));
-        c.take<unsigned>(4);
-    }
+    if (p.sym && knn_fast_enabled(N, D)) carve_knn_fast(c, N, D, p);      // the filter path's own buffers
     return c.off;
 }
 
@@ -1090,9 +1087,9 @@ static int run_knn(const float* X, int64_t N, int64_t ldx, const float* Y, int64
         std::vector<int> cnt(N + 1);
         const size_t nwg = (size_t)p.nwin * p.per_win;
         std::vector<int> wq(nwg);
-        hipStreamSynchronize(st);
-        hipMemcpy(cnt.data(), b.cnt, (N + 1) * sizeof(int), hipMemcpyDeviceToHost);
-        hipMemcpy(wq.data(), b.wgq_count, nwg * sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(cnt.data(), b.cnt, (N + 1) * sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(wq.data(), b.wgq_count, nwg * sizeof(int), hipMemcpyDeviceToHost);
         long long tot = 0, mx = 0, wtot = 0, wmx = 0, wfull = 0;
         for (int64_t i = 0; i < N; ++i) { tot += cnt[i]; mx = std::max<long long>(mx, cnt[i]); }
         for (size_t i = 0; i < nwg; ++i) { wtot += wq[i]; wmx = std::max<long long>(wmx, wq[i]); wfull += wq[i] >= p.qcap; }
@@ -1106,11 +1103,11 @@ static int run_knn(const float* X, int64_t N, int64_t ldx, const float* Y, int64
             }
             fprintf(stderr, "\n");
             std::vector<float> th(N), rr(N);
-            hipMemcpy(th.data(), b.thr, N * sizeof(float), hipMemcpyDeviceToHost);
-            hipMemcpy(rr.data(), out_r, N * sizeof(float), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(th.data(), b.thr, N * sizeof(float), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(rr.data(), out_r, N * sizeof(float), hipMemcpyDeviceToHost);
             {
                 std::vector<float> pl((size_t)p.nwin * N * p.kcap);
-                hipMemcpy(pl.data(), b.partial, pl.size() * sizeof(float), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(pl.data(), b.partial, pl.size() * sizeof(float), hipMemcpyDeviceToHost);
                 double acc2 = 0; long long finite = 0;
                 for (int64_t i = 0; i < N; ++i) {
                     std::vector<float> all;
@@ -1161,12 +1158,8 @@ extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const fl
     KnnBuffers b;
     carve_knn(c, N, M, p, b);
     bool fast = p.sym && knn_fast_enabled(N, D);
-    uint16_t* xb = nullptr;
-    unsigned* maxn = nullptr;
-    if (fast) {
-        xb = c.take<uint16_t>((size_t)N * half_ld(D));
-        maxn = c.take<unsigned>(4);
-    }
+    KnnFastBuffers fb{};
+    if (fast) fb = carve_knn_fast(c, N, D, p);
     if (!c.ok() && p.sym) {                        // a caller that sized the workspace for Y != X: general path
         p = plan_knn(N, M, D, k, false);
         c = Carver(ws, ws_bytes);
@@ -1179,10 +1172,10 @@ extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const fl
     const int k1 = k + 1;
     if (fast) {                                    // f16 filter sweep + exact verification (pairwise_fast.h), same bits
         switch (p.kcap) {
-            case 6:  return run_knn_fast<6>(X, N, ldx, D, k1, p, b, xb, maxn, out_r, st);
-            case 11: return run_knn_fast<11>(X, N, ldx, D, k1, p, b, xb, maxn, out_r, st);
-            case 16: return run_knn_fast<16>(X, N, ldx, D, k1, p, b, xb, maxn, out_r, st);
-            default: return run_knn_fast<32>(X, N, ldx, D, k1, p, b, xb, maxn, out_r, st);
+            case 6:  return run_knn_fast<6>(X, N, ldx, D, k1, p, b, fb, out_r, st);
+            case 11: return run_knn_fast<11>(X, N, ldx, D, k1, p, b, fb, out_r, st);
+            case 16: return run_knn_fast<16>(X, N, ldx, D, k1, p, b, fb, out_r, st);
+            default: return run_knn_fast<32>(X, N, ldx, D, k1, p, b, fb, out_r, st);
         }
     }
     switch (p.kcap) {
@@ -1191,6 +1184,17 @@ extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const fl
         case 16: return run_knn<16>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
         default: return run_knn<32>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
     }
+}
+
+// which form am_knn_radii_f32 / am_prdc_counts_f32 take for a shape: 0 exact general, 1 exact symmetric, 2 f16 filter + verify
+extern "C" int am_knn_path(int64_t N, int64_t M, int D, int k, int self) {
+    if (N < 1 || M < 1 || D < 1 || k < 1 || k > AM_MAX_K) return -1;
+    const KnnPlan p = plan_knn(N, M, D, k, self != 0 && N == M);
+    return !p.sym ? 0 : (knn_fast_enabled(N, D) ? 2 : 1);
+}
+extern "C" int am_prdc_path(int64_t Nr, int64_t Nc, int D) {
+    if (Nr < 1 || Nc < 1 || D < 1) return -1;
+    return cross_fast_enabled(Nr, Nc, D) ? 2 : 0;
 }
 
 // ---- partitioned symmetric k-NN (multi-GPU; every rank holds the full set) --------------------------

@@ -557,8 +557,10 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
     AM_LAUNCH_CHECK();
     unsigned* rmin_or_null = want_min ? rmin : nullptr;
     const size_t verify_lds = (size_t)(4 * ((D + 7) / 8 * 8) + p.qcap) * sizeof(float);
+    clock_begin(AM_KERNEL_PRDC_VERIFY, st);
     hipLaunchKernelGGL(cross_verify_kernel, dim3((unsigned)p.blocks), dim3(256), verify_lds, st, R, Nr, ldr, rn, rt, C, ldc, cn, ct,
                        D, p.nchunks, b.wgq, p.qcap, b.wgq_count, col_count, rmin_or_null, rany, rcov);
+    clock_end(AM_KERNEL_PRDC_VERIFY, st);
     AM_LAUNCH_CHECK();
     hipLaunchKernelGGL(cross_verify_overflow_kernel, dim3(1024), dim3(256), 0, st, R, ldr, rn, rt, C, ldc, cn, ct, D, b.ovq,
                        b.ov_count, p.ovcap, fail, col_count, rmin_or_null, rany, rcov);
@@ -591,9 +593,10 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
 //   mirrored (Q rows):      queue (j, i) when a <= thr[j].
 // The per-lane lists are merged per row and window, published (kthA + 2 E_i, cumulative over the windows done)
 // exactly like the exact kernel's, but they only steer the filter: the radii come from the exact values of the
-// queued pairs (knn_fast_verify_kernel -> knn_sym_scatter_kernel -> knn_fast_select_kernel).
-// Queue entry: (target row, other row | FAST_INBLOCK if the TARGET is the row of this workgroup's block).
-constexpr unsigned FAST_INBLOCK = 0x80000000u;
+// queued pairs (knn_fast_scatter_kernel -> knn_fast_prune_kernel -> knn_fast_verify_kernel -> knn_fast_select_kernel).
+// Queue entry: (row a | FAST_BOTH, row b): the exact value t(a, b) is filed under row a, and under row b as well when
+// FAST_BOTH is set (a pair that passes the own-row test of a and the mirrored test of b is evaluated once).
+constexpr unsigned FAST_BOTH = 0x80000000u;
 
 template <int KCAP>
 struct KnnFastEpilogue {
@@ -602,6 +605,7 @@ struct KnnFastEpilogue {
     int64_t n, pblock;
     float* aux;                 // LDS [2][2][128] : |x_j|^2 and thr[j] of the tile
     uint2* wgq;
+    float* wgv;                 // approximate value of each queued pair (pruning, knn_fast_prune_kernel)
     int* qn;
     int qcap;
     int* cnt;
@@ -615,10 +619,15 @@ struct KnnFastEpilogue {
     const LaneInfo& L;
 
     __device__ __forceinline__ KnnFastEpilogue(const LaneInfo& l) : L(l) {}
-    __device__ __forceinline__ void push(int64_t target, unsigned other) {
+    __device__ __forceinline__ void push(int64_t a, int64_t b, bool both, float val) {
         const int slot = atomicAdd(qn, 1);
-        if (slot < qcap) wgq[slot] = make_uint2((unsigned)target, other);
-        else atomicAdd(cnt + target, cap + 1);              // region full: the row goes to the exact fix-up kernel
+        if (slot < qcap) {
+            wgq[slot] = make_uint2((unsigned)a | (both ? FAST_BOTH : 0u), (unsigned)b);
+            wgv[slot] = val;
+        } else {                                            // region full: the row(s) go to the exact fix-up kernel
+            atomicAdd(cnt + a, cap + 1);
+            if (both) atomicAdd(cnt + b, cap + 1);
+        }
     }
     __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
         if (L.tid < TB) {
@@ -661,13 +670,14 @@ struct KnnFastEpilogue {
                         const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
                         const int64_t j = jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3);
                         const bool own = rowok[nt] && u <= pl;
-                        if (own) push(prow[nt], (unsigned)j | FAST_INBLOCK);
+                        const bool mir = mirror && rowok[nt] && u <= tq[reg >> 2][reg & 3];
+                        if (own) push(prow[nt], j, mir, u);
+                        else if (mir) push(j, prow[nt], false, u);
                         const float v = own ? fmaxf(u, 0.f) : INFINITY;
                         if (__any(v < best[nt][KCAP - 1])) {
                             list_insert<KCAP>(best[nt], v);
                             pl = fminf(flt[nt], best[nt][KCAP - 1] + e2[nt]);
                         }
-                        if (mirror && rowok[nt] && u <= tq[reg >> 2][reg & 3]) push(j, (unsigned)prow[nt]);
                     }
                 }
             }
@@ -680,11 +690,12 @@ template <int KCAP>
 __global__ void __launch_bounds__(ENGINE_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
 knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float* __restrict__ xnorm, float* thr, int Dh,
                 int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
-                int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, int qcap, int* __restrict__ wgq_count) {
+                int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
+                int* __restrict__ wgq_count, int part, int nparts) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
     const int64_t T = (N + TB - 1) / TB;
-    const SymWork sw = sym_work(T, win_tiles, nwin, per_win, 0, 1);
+    const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
     if (sw.ntiles == 0) {
         if (L.tid == 0) wgq_count[blockIdx.x] = 0;
         return;
@@ -697,6 +708,7 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     epi.pblock = sw.pb;
     epi.aux = lds + ENGINE_LDS_FLOATS;
     epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
+    epi.wgv = wgv + (int64_t)blockIdx.x * qcap;
     epi.qn = reinterpret_cast<int*>(lds + ENGINE_LDS_FLOATS + 4 * TB);
     epi.qcap = qcap;
     epi.cnt = cnt;
@@ -758,95 +770,140 @@ __global__ void __launch_bounds__(256) knn_fast_bound_kernel(float* __restrict__
     if (i < n) thr[i] = thr[i] + 2.f * FAST_C * (xnorm[i] + __uint_as_float(maxn[0]));     // +inf stays +inf
 }
 
-// Exact value of every queued pair of one region, written back as (target row, bits of t).  The entries are
-// bucketed by the row that belongs to this workgroup's block (target or other): that row goes to LDS once and
-// every lane evaluates one partner row with the exact engine's fmaf chain (t(i,j) == t(j,i) bit for bit).
-__global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __restrict__ X, int64_t N, int64_t ld,
-                                                              const float* __restrict__ xnorm, int D, int win_tiles, int nwin,
-                                                              int per_win, uint2* __restrict__ wgq, int qcap,
-                                                              const int* __restrict__ wgq_count) {
-    extern __shared__ __attribute__((aligned(16))) float vlds[];       // [4][dp] rows, then 2 x qcap sorted words
-    __shared__ int bucket[TB], start[TB];
-    const int n = wgq_count[blockIdx.x];
-    if (n == 0) return;
-    const int dp = (D + 7) / 8 * 8;
-    unsigned* s_target = reinterpret_cast<unsigned*>(vlds + 4 * dp);
-    unsigned* s_other = s_target + qcap;
-    uint2* q = wgq + (int64_t)blockIdx.x * qcap;
-    const int64_t T = (N + TB - 1) / TB;
-    const int64_t prow0 = sym_work(T, win_tiles, nwin, per_win, 0, 1).pb * TB;
-    if (threadIdx.x < TB) bucket[threadIdx.x] = 0;
-    __syncthreads();
-    constexpr int PER = 16;                                            // qcap <= 256 * PER
-    int pos[PER];
-    uint2 ent[PER];
-#pragma unroll
-    for (int s = 0; s < PER; ++s) {
-        const int e = threadIdx.x + s * 256;
-        pos[s] = 0;
-        if (e < n) {
-            ent[s] = q[e];
-            const int64_t inblock = (ent[s].y & FAST_INBLOCK) ? ent[s].x : (ent[s].y & ~FAST_INBLOCK);
-            pos[s] = atomicAdd(&bucket[(int)(inblock - prow0)], 1);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {                                            // exclusive scan of the 128 bucket sizes
-        const int a0 = bucket[2 * threadIdx.x], a1 = bucket[2 * threadIdx.x + 1];
-        int v = a0 + a1;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(v, off);
-            if ((int)threadIdx.x >= off) v += o;
-        }
-        start[2 * threadIdx.x] = v - a0 - a1;
-        start[2 * threadIdx.x + 1] = v - a1;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < PER; ++s) {
-        const int e = threadIdx.x + s * 256;
-        if (e < n) {
-            const int64_t inblock = (ent[s].y & FAST_INBLOCK) ? ent[s].x : (ent[s].y & ~FAST_INBLOCK);
-            const int dst = start[(int)(inblock - prow0)] + pos[s];
-            s_target[dst] = ent[s].x;
-            s_other[dst] = ent[s].y;
-        }
-    }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* xs = vlds + wave * dp;
-    for (int lr = wave; lr < TB; lr += 4) {
-        const int c = bucket[lr];
-        if (c == 0) continue;
-        const int64_t i = prow0 + lr;
-        for (int k = lane; k < dp; k += 64) xs[k] = k < D ? X[i * ld + k] : 0.f;
-        __builtin_amdgcn_wave_barrier();
-        const float xi = xnorm[i];
-        for (int e0 = 0; e0 < c; e0 += 64) {
-            const int e = e0 + lane;
-            if (e < c) {
-                const int at = start[lr] + e;
-                const unsigned tg = s_target[at], ot = s_other[at];
-                const int64_t partner = (ot & FAST_INBLOCK) ? (int64_t)(ot & ~FAST_INBLOCK) : (int64_t)tg;
-                const float t = fmaxf(fmaf(-2.f, exact_pair_dot(xs, X + partner * ld, D), xi + xnorm[partner]), 0.f);
-                q[at] = make_uint2(tg, __float_as_uint(t));
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+// After the sweep: (1) the APPROXIMATE values of the queued pairs are filed under their rows
+// (knn_fast_scatter_kernel); (2) per row, kq = the (k+1)-th smallest max(a, 0) among ITS filed entries bounds the
+// row's final value: the k+1 entries behind it have true values <= kq + E_i, so every pair the row needs has
+// a <= kq + 2 E_i - entries above that are dropped, the survivors go to one global pair list
+// (knn_fast_prune_kernel; the bounds during the sweep come from a column sample and from half-finished lists, so
+// ~4/5 of the queue is dropped here); (3) the exact value of each surviving pair is computed with the exact
+// engine's fmaf chain and filed under its row (knn_fast_verify_kernel); (4) selection, (5) exact fix-up of rows
+// whose buffers overflowed anywhere on the way (count marker > cap).
+__device__ __forceinline__ void knn_file_approx(float* __restrict__ fval, unsigned* __restrict__ fidx, int* __restrict__ cnt,
+                                                int cap, int64_t row, float v, unsigned partner) {
+    const int slot = atomicAdd(cnt + row, 1);
+    if (slot < cap) {
+        fval[row * (int64_t)cap + slot] = v;
+        fidx[row * (int64_t)cap + slot] = partner;
     }
 }
 
-// radius[i] = sqrt_rn( (k+1)-th smallest exact value filed under row i ); overflowed rows -> exact fix-up
+__global__ void __launch_bounds__(256) knn_fast_scatter_kernel(const uint2* __restrict__ wgq, const float* __restrict__ wgv,
+                                                               int qcap, const int* __restrict__ wgq_count,
+                                                               float* __restrict__ fval, unsigned* __restrict__ fidx,
+                                                               int* __restrict__ cnt, int cap) {
+    const int n = wgq_count[blockIdx.x];
+    const uint2* q = wgq + (int64_t)blockIdx.x * qcap;
+    const float* v = wgv + (int64_t)blockIdx.x * qcap;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const uint2 p = q[e];
+        const unsigned a = p.x & ~FAST_BOTH;
+        knn_file_approx(fval, fidx, cnt, cap, a, v[e], p.y);
+        if (p.x & FAST_BOTH) knn_file_approx(fval, fidx, cnt, cap, p.y, v[e], a);
+    }
+}
+
+// one thread per row; survivors are appended to pairs[] (one atomicAdd per wave)
+template <int KCAP>
+__global__ void __launch_bounds__(256) knn_fast_prune_kernel(const float* __restrict__ fval, const unsigned* __restrict__ fidx,
+                                                             const int* __restrict__ cnt, int cap, int64_t N, int k1,
+                                                             const float* __restrict__ xnorm, const unsigned* __restrict__ maxn,
+                                                             uint2* __restrict__ pairs, int pair_cap, int* __restrict__ pair_count,
+                                                             int* __restrict__ cnt2) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = i < N ? cnt[i] : 0;
+    const bool bad = i < N && (c > cap || c < k1);       // overflow on the way here (c < k1 cannot happen: the true top k+1 are always queued)
+    const float* fv = fval + i * (int64_t)cap;
+    int ns = 0;
+    float thr = -INFINITY;
+    if (i < N && !bad) {
+        float m[KCAP];
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) m[s] = INFINITY;
+        for (int s = 0; s < c; ++s) {
+            const float v = fmaxf(fv[s], 0.f);
+            if (v < m[KCAP - 1]) list_insert<KCAP>(m, v);
+        }
+        float kq = m[0];
+#pragma unroll
+        for (int s = 1; s < KCAP; ++s)
+            if (s == k1 - 1) kq = m[s];
+        thr = kq + 2.f * FAST_C * (xnorm[i] + __uint_as_float(maxn[0]));
+        for (int s = 0; s < c; ++s) ns += fv[s] <= thr;
+    }
+    int incl = ns;                                        // wave-inclusive prefix sum of the survivor counts
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    const int total = __shfl(incl, 63);
+    int base = 0;
+    if (lane == 63 && total > 0) base = atomicAdd(pair_count, total);
+    base = __shfl(base, 63);
+    if (i >= N) return;
+    if (bad || base + total > pair_cap) {                 // (pair list full: cannot happen, it is as large as the queue regions together)
+        cnt2[i] = cap + 1;                                // -> exact fix-up
+        return;
+    }
+    int at = base + incl - ns;
+    const unsigned* fi = fidx + i * (int64_t)cap;
+    for (int s = 0; s < c; ++s)
+        if (fv[s] <= thr) pairs[at++] = make_uint2((unsigned)i, fi[s]);
+}
+
+// One pair per lane, two pairs per thread interleaved for ILP; each lane walks its two rows with the exact engine's
+// fmaf chain (t(a,b) == t(b,a) bit for bit: products commute and the inner order is the same).  Consecutive pairs
+// share their first row (the list is written row by row), so those reads coalesce; the partner rows come from L2 /
+// Infinity Cache.
+__device__ __forceinline__ void knn_file(float* __restrict__ cand, int* __restrict__ cnt, int cap, int64_t row, float t) {
+    const int slot = atomicAdd(cnt + row, 1);
+    if (slot < cap) cand[row * (int64_t)cap + slot] = t;
+}
+
+__global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __restrict__ X, int64_t ld,
+                                                              const float* __restrict__ xnorm, int D,
+                                                              const uint2* __restrict__ pairs, const int* __restrict__ pair_count,
+                                                              int pair_cap, float* __restrict__ cand, int* __restrict__ cnt2,
+                                                              int cap) {
+    const int n = min(*pair_count, pair_cap);
+    const int dp = (D + 7) / 8 * 8;
+    for (int64_t e0 = (int64_t)blockIdx.x * 512 + threadIdx.x; e0 < n; e0 += (int64_t)gridDim.x * 512) {
+        const int64_t e1 = e0 + 256;
+        const bool two = e1 < n;
+        const uint2 p0 = pairs[e0], p1 = two ? pairs[e1] : p0;
+        const float *xa0 = X + (int64_t)p0.x * ld, *xb0 = X + (int64_t)p0.y * ld;
+        const float *xa1 = X + (int64_t)p1.x * ld, *xb1 = X + (int64_t)p1.y * ld;
+        float acc0 = 0.f, acc1 = 0.f;
+        for (int c = 0; c < dp; c += 8) {
+            const f32x4 u0 = load_k4(xa0, c, D), u1 = load_k4(xa0, c + 4, D), v0 = load_k4(xb0, c, D), v1 = load_k4(xb0, c + 4, D);
+            const f32x4 w0 = load_k4(xa1, c, D), w1 = load_k4(xa1, c + 4, D), z0 = load_k4(xb1, c, D), z1 = load_k4(xb1, c + 4, D);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc0 = fmaf(v0[s], u0[s], acc0);
+                acc1 = fmaf(z0[s], w0[s], acc1);
+                acc0 = fmaf(v1[s], u1[s], acc0);
+                acc1 = fmaf(z1[s], w1[s], acc1);
+            }
+        }
+        knn_file(cand, cnt2, cap, p0.x, fmaxf(fmaf(-2.f, acc0, xnorm[p0.x] + xnorm[p0.y]), 0.f));
+        if (two) knn_file(cand, cnt2, cap, p1.x, fmaxf(fmaf(-2.f, acc1, xnorm[p1.x] + xnorm[p1.y]), 0.f));
+    }
+}
+
+// radius[i] = sqrt_rn( (k+1)-th smallest exact value filed under row i ); overflowed rows -> exact fix-up.
+// Partitioned form (out_lists != nullptr): this rank's KCAP smallest exact values of the row (+inf padded), or a NaN
+// in slot 0 when the row overflowed here (am_knn_lists_finish_f32 then recomputes it exactly).
 template <int KCAP>
 __global__ void knn_fast_select_kernel(const float* __restrict__ cand, const int* __restrict__ cnt, int cap, int64_t N, int k1,
                                        const unsigned* __restrict__ maxn, float* __restrict__ radii, int* __restrict__ ov_list,
-                                       int* __restrict__ ov_count) {
+                                       int* __restrict__ ov_count, float* __restrict__ out_lists) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int c = cnt[i];
-    if (c > cap || c < k1 || !half_scale_ok(maxn[2])) {                           // c < k1 cannot happen (the true top k+1 are always queued); be safe
-        ov_list[atomicAdd(ov_count, 1)] = (int)i;
+    if (c > cap || (out_lists == nullptr && c < k1) || !half_scale_ok(maxn[2])) {
+        if (out_lists != nullptr) out_lists[i * KCAP] = NAN;
+        else ov_list[atomicAdd(ov_count, 1)] = (int)i;
         return;
     }
     float m[KCAP];
@@ -856,6 +913,11 @@ __global__ void knn_fast_select_kernel(const float* __restrict__ cand, const int
     for (int s = 0; s < c; ++s) {
         const float v = src[s];
         if (v < m[KCAP - 1]) list_insert<KCAP>(m, v);
+    }
+    if (out_lists != nullptr) {
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) out_lists[i * KCAP + s] = m[s];
+        return;
     }
     float r2 = m[0];
 #pragma unroll
@@ -867,39 +929,57 @@ __global__ void knn_fast_select_kernel(const float* __restrict__ cand, const int
 static bool knn_fast_enabled(int64_t N, int D) {
     static const int on = env_int("AM_KNN_FAST", 1);
     static const int min_rows = env_int("AM_KNN_FAST_MIN_ROWS", 32768);   // below: the exact symmetric kernel is faster (measured)
-    const size_t verify_lds = (size_t)(4 * ((D + 7) / 8 * 8) + 2 * 4096) * sizeof(float);
-    return on != 0 && N >= min_rows && D >= 32 && verify_lds <= 60 * 1024;
+    return on != 0 && N >= min_rows && D >= 32 && N < ((int64_t)1 << 31);
 }
 
-// X: N x D f32 (exact verification), xb: workspace for the f16 copy; plan / buffers of the symmetric path.
+struct KnnFastBuffers {           // on top of the symmetric path's KnnBuffers
+    uint16_t* xb;                 // scaled f16 copy
+    unsigned* maxn;               // [4] largest squared norm / largest |element|
+    float* wgv;                   // approximate values of the queue entries
+    unsigned* fidx;               // partner of each filed entry
+    int *cnt2, *pair_count;
+};
+
+static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan& p) {
+    KnnFastBuffers f;
+    f.xb = c.take<uint16_t>((size_t)N * half_ld(D));
+    f.maxn = c.take<unsigned>(4);
+    f.wgv = c.take<float>((size_t)p.nwin * p.per_win * p.qcap);
+    f.fidx = c.take<unsigned>((size_t)N * p.cap);
+    f.cnt2 = c.take<int>(N + 1);                  // [N] = pair counter
+    f.pair_count = f.cnt2 ? f.cnt2 + N : nullptr;
+    return f;
+}
+
+// X: N x D f32 (exact verification); plan / buffers of the symmetric path + the filter path's own.
+// thr_in != nullptr: filter bounds already computed (partitioned form: am_knn_bounds_f32 of every rank, all-gathered);
+// out_lists != nullptr: partitioned form, emit per-row lists instead of radii.
 template <int KCAP>
 static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, const KnnPlan& p, const KnnBuffers& b,
-                        uint16_t* xb, unsigned* maxn, float* out_r, hipStream_t st) {
+                        const KnnFastBuffers& f, float* out_r, hipStream_t st, int part = 0, int nparts = 1,
+                        float* thr_in = nullptr, float* out_lists = nullptr) {
     int rc;
     const int64_t ldh = half_ld(D) / 2;                              // row stride of the f16 copy in f32 words
     const int Dh = (int)ldh;
-    const float* Xb = reinterpret_cast<const float*>(xb);
+    const float* Xb = reinterpret_cast<const float*>(f.xb);
+    unsigned* maxn = f.maxn;
+    float* thr = thr_in != nullptr ? thr_in : b.thr;
     AM_HIP_TRY(hipMemsetAsync(maxn, 0, 4 * sizeof(unsigned), st));
-    if ((rc = launch_to_half(X, N, ld, D, b.xn, maxn, 0, xb, st)) != AM_OK) return rc;
+    if ((rc = launch_to_half(X, N, ld, D, b.xn, maxn, 0, f.xb, st)) != AM_OK) return rc;
     AM_HIP_TRY(hipMemcpyAsync(maxn + 3, maxn + 2, sizeof(unsigned), hipMemcpyDeviceToDevice, st));   // both operands are X
-    // 1) filter bounds for the rows of the top windows from a sampled f16 pass of the general kernel
-    // (every row, unlike the exact kernel: here a row's OWN entries are queued too, so it needs a bound from the start)
-    const int64_t row_lo = 0;
-    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st,
-                       reinterpret_cast<unsigned*>(b.thr), N, 0x7f800000u);
-    AM_LAUNCH_CHECK();
-    if (row_lo < N) {
-        const int64_t nr = N - row_lo;
-        if ((rc = launch_knn_vt<KCAP, EV_FAST, false>(Xb + row_lo * ldh, nr, ldh, b.xn + row_lo, Xb, N, ldh, b.xn, Dh, p.pre_chunks,
-                                                      p.pre_stride, b.partial, st, maxn)) != AM_OK)
+    // 1) filter bounds for every row from a sampled f16 pass of the general kernel (here a row's OWN entries are
+    //    queued too, so - unlike in the exact symmetric kernel - every row needs a bound from the start)
+    if (thr_in == nullptr) {
+        if ((rc = launch_knn_vt<KCAP, EV_FAST, false>(Xb, N, ldh, b.xn, Xb, N, ldh, b.xn, Dh, p.pre_chunks, p.pre_stride, b.partial,
+                                                      st, maxn)) != AM_OK)
             return rc;
-        hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(nr, 256)), dim3(256), 0, st, b.partial, nr, p.pre_chunks,
-                           k1, 1, b.thr + row_lo);
-        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(nr, 256)), dim3(256), 0, st, b.thr + row_lo,
-                           b.xn + row_lo, nr, maxn);
+        hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.partial, N, p.pre_chunks,
+                           k1, 1, thr);
+        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, thr, b.xn, N, maxn);
         AM_LAUNCH_CHECK();
     }
     AM_HIP_TRY(hipMemsetAsync(b.cnt, 0, (size_t)(N + 1) * sizeof(int), st));
+    AM_HIP_TRY(hipMemsetAsync(f.cnt2, 0, (size_t)(N + 1) * sizeof(int), st));
     // 2) symmetric filter sweep
     const unsigned nwg = (unsigned)p.nwin * (unsigned)p.per_win;
     const int64_t nlist = (int64_t)p.nwin * N * KCAP;
@@ -912,45 +992,49 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIRWISE_LDS_BYTES + 16));
         attr_done = true;
     }
-    const int qcap = std::min(p.qcap, 4096);                            // knn_fast_verify_kernel: <= 256 * 16
+    const int qcap = p.qcap;
     clock_begin(AM_KERNEL_KNN, st);
-    hipLaunchKernelGGL(knn_fast_kernel<KCAP>, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st, Xb, N, ldh, b.xn, b.thr,
-                       Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, qcap, b.wgq_count);
+    hipLaunchKernelGGL(knn_fast_kernel<KCAP>, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st, Xb, N, ldh, b.xn, thr,
+                       Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, f.wgv, qcap, b.wgq_count,
+                       part, nparts);
     clock_end(AM_KERNEL_KNN, st);
     AM_LAUNCH_CHECK();
-    // 3) exact values of the queued pairs, 4) filed under their rows, 5) selection, 6) exact fix-up of overflowed rows
-    const size_t verify_lds = (size_t)(4 * ((D + 7) / 8 * 8) + 2 * qcap) * sizeof(float);
-    hipLaunchKernelGGL(knn_fast_verify_kernel, dim3(nwg), dim3(256), verify_lds, st, X, N, ld, b.xn, D, p.win_tiles, p.nwin,
-                       p.per_win, b.wgq, qcap, b.wgq_count);
+    // 3) approximate values filed by row, 4) pruned against the row's own (k+1)-th smallest, 5) exact values of the
+    //    survivors, 6) selection, 7) exact fix-up of overflowed rows
+    hipLaunchKernelGGL(knn_fast_scatter_kernel, dim3(nwg), dim3(256), 0, st, b.wgq, f.wgv, qcap, b.wgq_count, b.cand, f.fidx, b.cnt,
+                       p.cap);
     AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_sym_scatter_kernel, dim3(nwg), dim3(256), 0, st, b.wgq, qcap, b.wgq_count, b.cand, b.cnt, p.cap);
+    const int64_t pair_cap64 = std::min<int64_t>((int64_t)nwg * qcap, (int64_t)1 << 30);
+    const int pair_cap = (int)pair_cap64;
+    hipLaunchKernelGGL(knn_fast_prune_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.cand, f.fidx, b.cnt, p.cap,
+                       N, k1, b.xn, maxn, b.wgq, pair_cap, f.pair_count, f.cnt2);
     AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_fast_select_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.cand, b.cnt, p.cap, N, k1,
-                       maxn, out_r, b.ov_list, b.ov_count);
+    clock_begin(AM_KERNEL_KNN_VERIFY, st);
+    hipLaunchKernelGGL(knn_fast_verify_kernel, dim3(4096), dim3(256), 0, st, X, ld, b.xn, D, b.wgq, f.pair_count, pair_cap, b.cand,
+                       f.cnt2, p.cap);
+    clock_end(AM_KERNEL_KNN_VERIFY, st);
     AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
-                       b.xn, D, k1, b.ov_list, b.ov_count, out_r);
+    hipLaunchKernelGGL(knn_fast_select_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.cand, f.cnt2, p.cap, N, k1,
+                       maxn, out_r, b.ov_list, b.ov_count, out_lists);
     AM_LAUNCH_CHECK();
+    if (out_lists == nullptr) {
+        hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
+                           b.xn, D, k1, b.ov_list, b.ov_count, out_r);
+        AM_LAUNCH_CHECK();
+    }
     static const int debug = env_int("AM_FAST_DEBUG", 0);
     if (debug) {                                       // development aid: synchronises
         AM_HIP_TRY(hipStreamSynchronize(st));
-        std::vector<int> wc(nwg), cn(N + 1);
+        std::vector<int> wc(nwg), cn(N + 1), c2(N + 1);
         AM_HIP_TRY(hipMemcpy(wc.data(), b.wgq_count, nwg * sizeof(int), hipMemcpyDeviceToHost));
         AM_HIP_TRY(hipMemcpy(cn.data(), b.cnt, (N + 1) * sizeof(int), hipMemcpyDeviceToHost));
-        long long tot = 0, full = 0, ctot = 0;
+        AM_HIP_TRY(hipMemcpy(c2.data(), f.cnt2, (N + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        long long tot = 0, full = 0, ctot = 0, bad = 0;
         int wmax = 0, cmax = 0;
         for (int v : wc) { tot += v; full += (v >= qcap); wmax = std::max(wmax, v); }
-        for (int64_t i = 0; i < N; ++i) { ctot += std::min(cn[i], p.cap); cmax = std::max(cmax, cn[i]); }
-        {
-            int shown = 0;
-            for (int64_t i = 0; i < N && shown < 24; ++i)
-                if (cn[i] > p.cap) { fprintf(stderr, " row %lld cnt %d;", (long long)i, cn[i]); ++shown; }
-            for (unsigned g = 0, sh = 0; g < nwg && sh < 8; ++g)
-                if (wc[g] >= qcap) { fprintf(stderr, " fullwg %u (win %d, e %u);", g, p.nwin - 1 - (int)(g / p.per_win), g % p.per_win); ++sh; }
-            fprintf(stderr, "\n");
-        }
+        for (int64_t i = 0; i < N; ++i) { ctot += std::min(cn[i], p.cap); cmax = std::max(cmax, cn[i]); bad += c2[i] > p.cap; }
         fprintf(stderr, "[knn_fast] wgs=%u nwin=%d qcap=%d queued=%lld (max/wg %d, full regions %lld) filed=%lld max/row=%d "
-                        "rows to fix-up=%d\n", nwg, p.nwin, qcap, tot, wmax, full, ctot, cmax, cn[N]);
+                        "pairs verified=%d rows to fix-up=%lld\n", nwg, p.nwin, qcap, tot, wmax, full, ctot, cmax, c2[N], bad);
     }
     return AM_OK;
 }

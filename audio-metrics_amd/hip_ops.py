@@ -48,7 +48,7 @@ class KernelTimer:
         return out
 
 
-KERNEL_KNN, KERNEL_PRDC_CROSS = 0, 1        # enum am_clocked_kernel
+KERNEL_KNN, KERNEL_PRDC_CROSS, KERNEL_KNN_VERIFY, KERNEL_PRDC_VERIFY = 0, 1, 2, 3        # enum am_clocked_kernel
 
 
 def kernel_clock_enable(on=True):
@@ -240,6 +240,16 @@ def knn_radii(x, k, columns=None):
 
 
 # ---- partitioned symmetric k-NN (multi-GPU, every rank holds the full set) ----
+def knn_path(n, m, d, k, self_distance=True):
+    """0 exact general kernel, 1 exact symmetric kernel, 2 f16 filter + exact verification."""
+    return int(_lib.load().am_knn_path(int(n), int(m), int(d), int(k), 1 if self_distance else 0))
+
+
+def prdc_path(n_ref, n_cand, d):
+    """0 exact kernel, 2 f16 filter + exact verification."""
+    return int(_lib.load().am_prdc_path(int(n_ref), int(n_cand), int(d)))
+
+
 def knn_sym_eligible(n, d, k):
     return bool(_lib.load().am_knn_sym_eligible(int(n), int(d), int(k)))
 

@@ -185,14 +185,20 @@ int am_prdc_reduce(const int32_t* col_count, int64_t Nc,
  * When enabled, the library brackets every launch of the two tile kernels with a hipEvent pair recorded on
  * the caller's stream, so a benchmark can report the duration of exactly that kernel (the figure
  * `rocprofv3 --kernel-trace --stats` prints for it) rather than of the whole entry point.
- *   AM_KERNEL_KNN         knn_sym_kernel, or knn_partial_kernel's main pass when the general form runs
- *                         (the sampled pre-pass of the symmetric form is not counted)
- *   AM_KERNEL_PRDC_CROSS  prdc_cross_kernel
+ *   AM_KERNEL_KNN          the k-NN tile kernel: knn_fast_kernel (f16 filter sweep) where the filter path runs,
+ *                          else knn_sym_kernel, else knn_partial_kernel's main pass (sampled pre-passes not counted)
+ *   AM_KERNEL_PRDC_CROSS   the membership tile kernel: cross_fast_kernel (f16 filter) or prdc_cross_kernel
+ *   AM_KERNEL_KNN_VERIFY   knn_fast_verify_kernel (exact f32 values of the queued pairs)
+ *   AM_KERNEL_PRDC_VERIFY  cross_verify_kernel
  * am_kernel_clock_read waits for the recorded launches, returns their count and summed duration in
- * milliseconds, and resets that kernel's record.  Disabled by default; no cost when disabled. */
-enum am_clocked_kernel { AM_KERNEL_KNN = 0, AM_KERNEL_PRDC_CROSS = 1 };
+ * milliseconds, and resets that kernel's record.  Disabled by default; no cost when disabled.
+ * am_knn_path / am_prdc_path tell which form the library picks for a shape (0 = exact general kernel,
+ * 1 = exact symmetric kernel (k-NN only), 2 = f16 filter + exact verification). */
+enum am_clocked_kernel { AM_KERNEL_KNN = 0, AM_KERNEL_PRDC_CROSS = 1, AM_KERNEL_KNN_VERIFY = 2, AM_KERNEL_PRDC_VERIFY = 3 };
 int am_kernel_clock_enable(int on);
 int am_kernel_clock_read(int kernel, int64_t* launches, double* total_ms);
+int am_knn_path(int64_t N, int64_t M, int D, int k, int self);
+int am_prdc_path(int64_t Nr, int64_t Nc, int D);
 
 #ifdef __cplusplus
 }
