@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <vector>
 #include <cmath>
+#include <type_traits>
 
 namespace am {
 
@@ -1205,12 +1206,14 @@ extern "C" int am_knn_sym_eligible(int64_t N, int D, int k) {
 
 extern "C" int am_knn_list_width(int k) { return (k < 1 || k > AM_MAX_K) ? 0 : kcap_for(k + 1); }
 
-extern "C" size_t am_knn_part_workspace_bytes(int64_t N, int k) {
-    if (N < 1 || k < 1 || k > AM_MAX_K) return 0;
-    const KnnPlan p = plan_knn(N, N, 1 << 20, k, true);
+extern "C" size_t am_knn_part_workspace_bytes(int64_t N, int D, int k) {
+    if (N < 1 || D < 1 || k < 1 || k > AM_MAX_K) return 0;
+    const KnnPlan p = plan_knn(N, N, D, k, true);
     Carver c(nullptr, 0);
     KnnBuffers b;
-    return carve_knn(c, N, N, p, b);
+    carve_knn(c, N, N, p, b);
+    if (p.sym && knn_fast_enabled(N, D)) carve_knn_fast(c, N, D, p);
+    return c.off;
 }
 
 extern "C" int am_knn_bounds_f32(const float* X, int64_t N, int64_t ld, int D, int k, int64_t row0, int64_t nrows,
@@ -1228,8 +1231,37 @@ extern "C" int am_knn_bounds_f32(const float* X, int64_t N, int64_t ld, int D, i
     Carver c(ws, ws_bytes);
     float* xn = c.take<float>(N);
     float* partial = c.take<float>((size_t)p.pre_chunks * nrows * p.kcap);
+    const bool fast = knn_fast_enabled(N, D);
+    uint16_t* xb = fast ? c.take<uint16_t>((size_t)N * half_ld(D)) : nullptr;
+    unsigned* maxn = fast ? c.take<unsigned>(4) : nullptr;
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
     if ((rc = launch_norms(X, N, ld, D, xn, st)) != AM_OK) return rc;
+    if (fast) {
+        // f16 sample pass (pairwise_fast.h): kthA + E_i bounds the (k+1)-th smallest true value of the sample, hence of the row
+        AM_HIP_TRY(hipMemsetAsync(maxn, 0, 4 * sizeof(unsigned), st));
+        if ((rc = launch_to_half(X, N, ld, D, xn, maxn, 0, xb, st)) != AM_OK) return rc;
+        AM_HIP_TRY(hipMemcpyAsync(maxn + 3, maxn + 2, sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+        const int64_t ldh = half_ld(D) / 2;
+        const float* Xb = reinterpret_cast<const float*>(xb);
+        auto go = [&](auto kcap_tag) -> int {
+            constexpr int KC = decltype(kcap_tag)::value;
+            int r2 = launch_knn_vt<KC, EV_FAST, false>(Xb + row0 * ldh, nrows, ldh, xn + row0, Xb, N, ldh, xn, (int)ldh, p.pre_chunks,
+                                                       p.pre_stride, partial, st, maxn);
+            if (r2 != AM_OK) return r2;
+            hipLaunchKernelGGL(knn_merge_kernel<KC>, dim3((unsigned)ceil_div(nrows, 256)), dim3(256), 0, st, partial, nrows,
+                               p.pre_chunks, k + 1, 1, out_bound_sq);
+            hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(nrows, 256)), dim3(256), 0, st, out_bound_sq,
+                               out_bound_sq, xn + row0, nrows, maxn, 1.f);
+            AM_LAUNCH_CHECK();
+            return AM_OK;
+        };
+        switch (p.kcap) {
+            case 6:  return go(std::integral_constant<int, 6>{});
+            case 11: return go(std::integral_constant<int, 11>{});
+            case 16: return go(std::integral_constant<int, 16>{});
+            default: return go(std::integral_constant<int, 32>{});
+        }
+    }
     const float* Xr = X + row0 * ld;
     switch (p.kcap) {
         case 6:  return launch_knn<6>(Xr, nrows, ld, xn + row0, X, N, ld, xn, D, k + 1, p.pre_chunks, p.pre_stride, true, partial, out_bound_sq, st);
@@ -1262,8 +1294,19 @@ extern "C" int am_knn_sym_part_f32(const float* X, int64_t N, int64_t ld, int D,
     Carver c(ws, ws_bytes);
     KnnBuffers b;
     carve_knn(c, N, N, p, b);
+    const bool fast = knn_fast_enabled(N, D);
+    KnnFastBuffers fb{};
+    if (fast) fb = carve_knn_fast(c, N, D, p);
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
     if ((rc = launch_norms(X, N, ld, D, b.xn, st)) != AM_OK) return rc;
+    if (fast) {                                    // f16 filter sweep of this rank's row blocks + exact verification
+        switch (p.kcap) {
+            case 6:  return run_knn_fast<6>(X, N, ld, D, k + 1, p, b, fb, nullptr, st, part, nparts, bounds_sq, out_lists);
+            case 11: return run_knn_fast<11>(X, N, ld, D, k + 1, p, b, fb, nullptr, st, part, nparts, bounds_sq, out_lists);
+            case 16: return run_knn_fast<16>(X, N, ld, D, k + 1, p, b, fb, nullptr, st, part, nparts, bounds_sq, out_lists);
+            default: return run_knn_fast<32>(X, N, ld, D, k + 1, p, b, fb, nullptr, st, part, nparts, bounds_sq, out_lists);
+        }
+    }
     switch (p.kcap) {
         case 6:  return run_knn_part<6>(X, N, ld, D, k + 1, part, nparts, bounds_sq, out_lists, p, b, st);
         case 11: return run_knn_part<11>(X, N, ld, D, k + 1, part, nparts, bounds_sq, out_lists, p, b, st);

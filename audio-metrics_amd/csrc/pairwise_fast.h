@@ -764,10 +764,11 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
 }
 
 // pre-pass result (approximate (k+1)-th smallest over the column sample) -> filter bound
-__global__ void __launch_bounds__(256) knn_fast_bound_kernel(float* __restrict__ thr, const float* __restrict__ xnorm, int64_t n,
-                                                             const unsigned* __restrict__ maxn) {
+__global__ void __launch_bounds__(256) knn_fast_bound_kernel(const float* __restrict__ in, float* __restrict__ thr,
+                                                             const float* __restrict__ xnorm, int64_t n,
+                                                             const unsigned* __restrict__ maxn, float factor) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) thr[i] = thr[i] + 2.f * FAST_C * (xnorm[i] + __uint_as_float(maxn[0]));     // +inf stays +inf
+    if (i < n) thr[i] = in[i] + factor * FAST_C * (xnorm[i] + __uint_as_float(maxn[0]));     // +inf stays +inf
 }
 
 // After the sweep: (1) the APPROXIMATE values of the queued pairs are filed under their rows
@@ -808,11 +809,13 @@ __global__ void __launch_bounds__(256) knn_fast_prune_kernel(const float* __rest
                                                              const int* __restrict__ cnt, int cap, int64_t N, int k1,
                                                              const float* __restrict__ xnorm, const unsigned* __restrict__ maxn,
                                                              uint2* __restrict__ pairs, int pair_cap, int* __restrict__ pair_count,
-                                                             int* __restrict__ cnt2) {
+                                                             int* __restrict__ cnt2, int partitioned) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int c = i < N ? cnt[i] : 0;
-    const bool bad = i < N && (c > cap || c < k1);       // overflow on the way here (c < k1 cannot happen: the true top k+1 are always queued)
+    // overflow on the way here; c < k1 cannot happen on one GPU (the true top k+1 are always queued) - in the
+    // partitioned form a rank may hold fewer than k+1 entries of a row, which then all survive (kq = +inf)
+    const bool bad = i < N && (c > cap || (c < k1 && !partitioned));
     const float* fv = fval + i * (int64_t)cap;
     int ns = 0;
     float thr = -INFINITY;
@@ -952,30 +955,34 @@ static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan&
 }
 
 // X: N x D f32 (exact verification); plan / buffers of the symmetric path + the filter path's own.
-// thr_in != nullptr: filter bounds already computed (partitioned form: am_knn_bounds_f32 of every rank, all-gathered);
+// bounds_in != nullptr: upper bounds B_i of the rows' final values already computed (partitioned form:
+// am_knn_bounds_f32 of every rank, all-gathered) -> filter bound B_i + E_i;
 // out_lists != nullptr: partitioned form, emit per-row lists instead of radii.
 template <int KCAP>
 static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, const KnnPlan& p, const KnnBuffers& b,
                         const KnnFastBuffers& f, float* out_r, hipStream_t st, int part = 0, int nparts = 1,
-                        float* thr_in = nullptr, float* out_lists = nullptr) {
+                        const float* bounds_in = nullptr, float* out_lists = nullptr) {
     int rc;
     const int64_t ldh = half_ld(D) / 2;                              // row stride of the f16 copy in f32 words
     const int Dh = (int)ldh;
     const float* Xb = reinterpret_cast<const float*>(f.xb);
     unsigned* maxn = f.maxn;
-    float* thr = thr_in != nullptr ? thr_in : b.thr;
+    float* thr = b.thr;
     AM_HIP_TRY(hipMemsetAsync(maxn, 0, 4 * sizeof(unsigned), st));
     if ((rc = launch_to_half(X, N, ld, D, b.xn, maxn, 0, f.xb, st)) != AM_OK) return rc;
     AM_HIP_TRY(hipMemcpyAsync(maxn + 3, maxn + 2, sizeof(unsigned), hipMemcpyDeviceToDevice, st));   // both operands are X
     // 1) filter bounds for every row from a sampled f16 pass of the general kernel (here a row's OWN entries are
     //    queued too, so - unlike in the exact symmetric kernel - every row needs a bound from the start)
-    if (thr_in == nullptr) {
+    if (bounds_in != nullptr) {
+        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, bounds_in, thr, b.xn, N, maxn, 1.f);
+        AM_LAUNCH_CHECK();
+    } else {
         if ((rc = launch_knn_vt<KCAP, EV_FAST, false>(Xb, N, ldh, b.xn, Xb, N, ldh, b.xn, Dh, p.pre_chunks, p.pre_stride, b.partial,
                                                       st, maxn)) != AM_OK)
             return rc;
         hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.partial, N, p.pre_chunks,
                            k1, 1, thr);
-        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, thr, b.xn, N, maxn);
+        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, thr, thr, b.xn, N, maxn, 2.f);
         AM_LAUNCH_CHECK();
     }
     AM_HIP_TRY(hipMemsetAsync(b.cnt, 0, (size_t)(N + 1) * sizeof(int), st));
@@ -1007,7 +1014,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     const int64_t pair_cap64 = std::min<int64_t>((int64_t)nwg * qcap, (int64_t)1 << 30);
     const int pair_cap = (int)pair_cap64;
     hipLaunchKernelGGL(knn_fast_prune_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.cand, f.fidx, b.cnt, p.cap,
-                       N, k1, b.xn, maxn, b.wgq, pair_cap, f.pair_count, f.cnt2);
+                       N, k1, b.xn, maxn, b.wgq, pair_cap, f.pair_count, f.cnt2, out_lists != nullptr ? 1 : 0);
     AM_LAUNCH_CHECK();
     clock_begin(AM_KERNEL_KNN_VERIFY, st);
     hipLaunchKernelGGL(knn_fast_verify_kernel, dim3(4096), dim3(256), 0, st, X, ld, b.xn, D, b.wgq, f.pair_count, pair_cap, b.cand,

@@ -260,7 +260,7 @@ def knn_bounds(x_full, k, row0, nrows):
     x = as_matrix(x_full)
     n, d = x.shape
     out = torch.empty(int(nrows), dtype=torch.float32, device=x.device)
-    nb = lib.am_knn_part_workspace_bytes(n, int(k))
+    nb = lib.am_knn_part_workspace_bytes(n, d, int(k))
     ws = _workspace(nb, x.device)
     _call(lib, "am_knn_bounds_f32", _ptr(x), n, _ld(x), d, int(k), int(row0), int(nrows), _ptr(out), _ptr(ws), nb, _stream())
     return out
@@ -274,7 +274,7 @@ def knn_sym_part(x_full, k, part, nparts, bounds_sq):
     width = lib.am_knn_list_width(int(k))
     bounds_sq = bounds_sq.to(torch.float32).contiguous().clone()
     out = torch.empty((n, width), dtype=torch.float32, device=x.device)
-    nb = lib.am_knn_part_workspace_bytes(n, int(k))
+    nb = lib.am_knn_part_workspace_bytes(n, d, int(k))
     ws = _workspace(nb, x.device)
     _call(lib, "am_knn_sym_part_f32", _ptr(x), n, _ld(x), d, int(k), int(part), int(nparts), _ptr(bounds_sq), _ptr(out),
           _ptr(ws), nb, _stream())

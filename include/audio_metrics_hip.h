@@ -141,13 +141,16 @@ int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx,
  *                           from a column sample; ranks split the rows and all-gather the result
  *   am_knn_sym_part_f32     this rank's share: out_lists[N][am_knn_list_width(k)] = its smallest entries per row
  *                           (+inf padded; a NaN in slot 0 flags a row whose candidate buffer overflowed);
- *                           bounds_sq[N] is read and tightened in place
+ *                           bounds_sq[N] is read (the exact form also tightens it in place)
  *   am_knn_lists_finish_f32 lists[nparts][N][width] (all-gathered) -> out_r[N]; flagged rows are recomputed exactly
+ * Shapes that take the f16 filter + exact verification form in am_knn_radii_f32 take it here too (csrc/pairwise_fast.h):
+ * the bounds come from an f16 sample pass, each rank sweeps its row blocks on the f16 copy and evaluates its surviving
+ * pairs exactly; out_lists then holds the rank's smallest EXACT values per row.
  * The result is bit-identical to am_knn_radii_f32(X, X).
  * ------------------------------------------------------------------------- */
 int am_knn_sym_eligible(int64_t N, int D, int k);
 int am_knn_list_width(int k);
-size_t am_knn_part_workspace_bytes(int64_t N, int k);
+size_t am_knn_part_workspace_bytes(int64_t N, int D, int k);
 int am_knn_bounds_f32(const float* X, int64_t N, int64_t ld, int D, int k, int64_t row0, int64_t nrows,
                       float* out_bound_sq, void* ws, size_t ws_bytes, am_stream_t stream);
 int am_knn_sym_part_f32(const float* X, int64_t N, int64_t ld, int D, int k, int part, int nparts,

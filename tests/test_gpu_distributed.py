@@ -79,15 +79,18 @@ def test_sharded_evaluate_with_hip_kernels(n_ref, n_cand):
     assert abs(am.frechet_distance(a, b) - single["fad"]) <= 1e-5 * abs(single["fad"])
 
 
-@pytest.mark.parametrize("nparts,k", [(2, 5), (3, 10), (8, 5)])
-def test_partitioned_symmetric_knn_bit_identical(nparts, k):
+@pytest.mark.parametrize("nparts,k,rows,path", [(2, 5, 9100, 1), (3, 10, 9100, 1), (8, 5, 9100, 1),
+                                                (2, 5, 33100, 2), (5, 10, 33100, 2)])
+def test_partitioned_symmetric_knn_bit_identical(nparts, k, rows, path):
     """The multi-GPU form of the symmetric k-NN, emulated on one GPU: every part computed in turn, lists
-    stacked as the all-gather would, then merged - bit-identical to the single-GPU result."""
+    stacked as the all-gather would, then merged - bit-identical to the single-GPU result.  9100 rows take the
+    exact symmetric kernel (path 1), 33100 rows the f16 filter sweep + exact verification (path 2)."""
     import numpy as np
     from audio_metrics_amd import hip_ops as ops
-    x = torch.as_tensor(gi.randn(97, 9100, 136)).to("cuda:0")
+    x = torch.as_tensor(gi.randn(97, rows, 136)).to("cuda:0")
     n = x.shape[0]
     assert ops.knn_sym_eligible(n, x.shape[1], k)
+    assert ops.knn_path(n, n, x.shape[1], k) == path
     want = ops.knn_radii(x, k).cpu().numpy()
     bounds = torch.cat([ops.knn_bounds(x, k, lo, hi - lo) for lo, hi in
                         [(n * p // nparts, n * (p + 1) // nparts) for p in range(nparts)]])
