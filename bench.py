@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 METRIC = "evaluate() embeddings/sec (FAD+KD+PRDC), 2×100k CLAP-512 sets, 1/2/4/8 GPUs"
 F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+F16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: bf16/f16 dense peak (v_mfma_f32_32x32x16_f16)
 
 
 def cpu_baseline(ref, cand, k, sample_rows=8000):
@@ -145,7 +146,8 @@ def main():
     # C-ABI entry point from the host side; the library's kernel clock brackets the two tile kernels themselves
     # (the durations `rocprofv3 --kernel-trace --stats` reports for them).
     ops.kernel_clock_enable(True)
-    ops.kernel_clock_read(ops.KERNEL_KNN), ops.kernel_clock_read(ops.KERNEL_PRDC_CROSS)      # drop warm-up launches
+    for kid in (ops.KERNEL_KNN, ops.KERNEL_PRDC_CROSS, ops.KERNEL_KNN_VERIFY, ops.KERNEL_PRDC_VERIFY):
+        ops.kernel_clock_read(kid)                                                           # drop warm-up launches
     with ops.KernelTimer() as timer:
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -153,8 +155,9 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
     kern = timer.summary()
-    knn_launches, knn_total_ms = ops.kernel_clock_read(ops.KERNEL_KNN)
-    cross_launches, cross_total_ms = ops.kernel_clock_read(ops.KERNEL_PRDC_CROSS)
+    clocks = {name: ops.kernel_clock_read(kid) for name, kid in
+              (("knn", ops.KERNEL_KNN), ("cross", ops.KERNEL_PRDC_CROSS), ("knn_verify", ops.KERNEL_KNN_VERIFY),
+               ("cross_verify", ops.KERNEL_PRDC_VERIFY))}
     ops.kernel_clock_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -162,31 +165,68 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        # Dominant kernel: the k-NN tile kernel.  One GPU: am_knn_radii_f32 (symmetric or general form inside);
-        # several GPUs and an eligible shape: the partitioned symmetric form, am_knn_sym_part_f32.
+        rows_local = hi - lo
+        # Which form of the two PRDC tile kernels ran (am_knn_path / am_prdc_path: 0 exact general, 1 exact symmetric,
+        # 2 f16 filter sweep + exact f32 verification of the undecided pairs).
         part_form = "am_knn_sym_part_f32" in kern
         knn_entry = "am_knn_sym_part_f32" if part_form else "am_knn_radii_f32"
-        calls, ms = kern[knn_entry]
-        entry_ms = ms / calls                                 # whole entry point: pre-pass + tile kernel + scatter/merge
-        knn_ms = knn_total_ms / knn_launches if knn_launches else entry_ms        # the tile kernel alone
+        knn_path = ops.knn_path(n, n, d, k) if (world == 1 or part_form) else 0
+        cross_path = ops.prdc_path(rows_local, n, d)
+        knn_kernel = {0: "knn_partial_kernel", 1: "knn_sym_kernel", 2: "knn_fast_kernel"}[knn_path]
+        cross_kernel = {0: "prdc_cross_kernel", 2: "cross_fast_kernel"}[cross_path]
+        peak_of = {0: F32_MFMA_PEAK_TFLOPS, 1: F32_MFMA_PEAK_TFLOPS, 2: F16_MFMA_PEAK_TFLOPS}
+        mfma_of = {0: "v_mfma_f32_32x32x2_f32", 1: "v_mfma_f32_32x32x2_f32", 2: "v_mfma_f32_32x32x16_f16"}
+
+        def per_launch(name, entry):
+            launches, total = clocks[name]
+            if launches:
+                return total / launches, launches / args.steps
+            calls, ms = kern[entry]
+            return ms / calls, calls / args.steps
+
+        knn_ms, knn_lps = per_launch("knn", knn_entry)
+        cross_ms, cross_lps = per_launch("cross", "am_prdc_counts_f32")
+        kcalls, kms = kern[knn_entry]
         ccalls, cms = kern["am_prdc_counts_f32"]
-        cross_ms = cross_total_ms / cross_launches if cross_launches else cms / ccalls
-        rows_local = hi - lo
-        flop_per_launch = 2.0 * rows_local * n * d            # algorithmic: one dot product per (row, column) of this rank's share
-        achieved = flop_per_launch / (entry_ms * 1e-3) / 1e12  # conservative: charged with the entry point's other kernels too
-        # The self-distance matrix is bitwise symmetric; the symmetric kernel multiplies only a cyclic half of the
-        # tile pairs (+ a sampled pre-pass for bounds), so its ALGORITHMIC rate can exceed the MFMA peak.
+        # ALGORITHMIC work of one launch (one dot product per (row, column) pair, no symmetry credit):
+        # 2 * rows_of_this_rank * N * D flop.  The symmetric forms (paths 1, 2) multiply a cyclic half of the tile
+        # pairs - self distances are bitwise symmetric - so they EXECUTE about half of it.
         t_tiles = (n + 127) // 128
-        sym = part_form or (world == 1 and n >= 8192 and d >= 128)
-        # cyclic half of the tile pairs; one GPU adds the sampling pre-pass (1/16 of the column tiles for the rows of
-        # the top windows), the partitioned form runs its pre-pass in a separate entry point (am_knn_bounds_f32)
-        exec_frac_of_alg = ((t_tiles // 2 + 1) / t_tiles) if sym else 1.0     # tile pairs the clocked kernel multiplies
-        traffic = None
-        try:                                                # PMC-derived bytes per launch, recorded from profiles/
+        flop_alg = 2.0 * rows_local * n * d
+        knn_exec = ((t_tiles // 2 + 1) / t_tiles) if knn_path in (1, 2) else 1.0
+        try:                                                # PMC-derived HBM-side bytes per launch, recorded from profiles/
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                traffic = json.load(f).get("knn_kernel_bytes_per_launch")
+                traffic_table = json.load(f).get("bytes_per_launch", {})
         except OSError:
-            pass
+            traffic_table = {}
+
+        def roof(kernel, path, ms, lps, exec_frac, entry, entry_ms):
+            peak = peak_of[path]
+            achieved = flop_alg / (ms * 1e-3) / 1e12
+            return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "traffic": traffic_table.get(kernel) if world == 1 else None,
+                    "kernel": kernel, "mfma": mfma_of[path], "entry_point": entry, "launch_ms": ms, "launches_per_step": lps,
+                    "entry_ms": entry_ms, "flop_per_launch": flop_alg, "executed_flop_per_launch": flop_alg * exec_frac,
+                    "executed_frac": flop_alg * exec_frac / (ms * 1e-3) / 1e12 / peak}
+
+        knn_roof = roof(knn_kernel, knn_path, knn_ms, knn_lps, knn_exec, knn_entry, kms / kcalls)
+        cross_roof = roof(cross_kernel, cross_path, cross_ms, cross_lps, 1.0, "am_prdc_counts_f32", cms / ccalls)
+        # dominant kernel = the one with the larger share of the step
+        main, other = (knn_roof, cross_roof) if knn_ms * knn_lps >= cross_ms * cross_lps else (cross_roof, knn_roof)
+        main["note"] = (
+            "achieved = algorithmic flops 2*rows*N*D of one launch / launch_ms (hipEvents around the kernel inside the "
+            "library, on its stream; compare rocprofv3's average for it); peak = dense MFMA peak of the instruction the "
+            "kernel issues.  Path 2 kernels are FILTERS: they evaluate every pair on the f16 matrix cores with a proven "
+            "error bound and queue the few pairs the bound cannot decide; those are re-evaluated with the exact f32 fmaf "
+            "chain (verify kernels, listed under other_kernels), so the outputs are bit-identical to the exact f32 "
+            "kernels'.  executed_frac = executed flops / launch_ms / peak is the MFMA-pipe utilisation (the symmetric "
+            "sweep executes ~half of the algorithmic pairs).")
+        verify = {}
+        for name, label in (("knn_verify", "knn_fast_verify_kernel"), ("cross_verify", "cross_verify_kernel")):
+            launches, total = clocks[name]
+            if launches:
+                verify[label] = {"launch_ms": total / launches, "launches_per_step": launches / args.steps,
+                                 "bound": "hbm/L2 gather: two 4*D-byte rows per surviving pair, one fmaf chain per lane"}
         out = {
             "metric": METRIC,
             "value": args.steps * 2 * n / elapsed,
@@ -203,26 +243,14 @@ def main():
             "config": {"workload": f"FAD+KD+PRDC(k={k}) cold evaluate() of 2x{n} CLAP-{d} f32 embedding sets resident in HBM "
                                    "(BASELINE.json configs[2])",
                        "n_ref": n, "n_cand": n, "dim": d, "nearest_k": k, "kd_subsets": 100, "kd_subset_size": 1000,
-                       "sharding": f"rows/{world}"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": ("knn_sym_kernel" if sym else "knn_partial_kernel") + f" ({knn_entry}, 2 launches/step)",
-                         "launch_ms": knn_ms, "entry_ms": entry_ms, "launches_per_step": knn_launches / args.steps,
-                         "flop_per_launch": flop_per_launch,
-                         "executed_flop_per_launch": flop_per_launch * exec_frac_of_alg,
-                         "executed_frac": flop_per_launch * exec_frac_of_alg / (knn_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                         "note": ("launch_ms = the tile kernel alone (hipEvents inside the library; compare rocprofv3's "
-                                  "average for it); achieved = algorithmic flops 2*N*N*D (no symmetry credit) / entry_ms, "
-                                  "the whole entry point incl. its sampled pre-pass and merge kernels; the tile kernel "
-                                  f"executes {exec_frac_of_alg:.3f} of those flops (bitwise-symmetric self distances), so "
-                                  "frac may exceed 1; executed_frac = executed flops / launch_ms / peak is the MFMA-pipe "
-                                  "utilisation")},
+                       "sharding": f"rows/{world}",
+                       "arithmetic": "results are the exact f32 values (bit-identical to the f32-MFMA kernels); the PRDC tile "
+                                     "kernels pre-filter on f16 MFMA with f32 accumulation where am_knn_path/am_prdc_path = 2"},
+            "roofline": main,
+            "other_tile_kernel": other,
+            "other_kernels": verify,
             "kernels_ms_per_call": {name: tot / c for name, (c, tot) in sorted(kern.items())},
             "kernels_calls_per_step": {name: c / args.steps for name, (c, tot) in sorted(kern.items())},
-            "cross_kernel": {"kernel": "prdc_cross_kernel (am_prdc_counts_f32, 1 launch/step)", "launch_ms": cross_ms,
-                             "bound": "mfma", "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "achieved": 2.0 * rows_local * n * d / (cross_ms * 1e-3) / 1e12,
-                             "frac": 2.0 * rows_local * n * d / (cross_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS},
             "result": result,
         }
         if world == 1:
