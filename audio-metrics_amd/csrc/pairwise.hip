@@ -115,6 +115,39 @@ __device__ __forceinline__ WorkItem work_item(int64_t q_tiles, int nchunks, int 
     return w;
 }
 
+// XCD-grouped form of the same (row block, column chunk) grid for the f16 filter kernels, whose operand traffic is
+// 16x the exact kernels' per unit of time and therefore has to come from L2: block b runs on XCD b % 8
+// (MI355X_MICROARCH.md, workgroup dispatch), and the ~64 workgroups resident on one XCD should share few row blocks
+// and few column chunks.  The b / 8-th work item of an XCD is item (b / 8) % 64 of that XCD's (b / 8) / 64-th GROUP of
+// grp_rows row blocks x (64 / grp_rows) chunks: a group keeps grp_rows x 128 P rows (f16: 128 KB per block) resident
+// in the 4 MB L2 while its chunks stream past, and each Q tile is fetched once per group instead of once per
+// workgroup.  Grid: cross_grouped_blocks().  Items past the grid's edge come back with ntiles = 0.
+static inline int64_t cross_grouped_blocks(int64_t row_blocks, int nchunks, int grp_rows) {
+    const int grp_chunks = 64 / grp_rows;
+    const int64_t groups = ceil_div(row_blocks, grp_rows) * ceil_div(nchunks, grp_chunks);
+    return ceil_div(groups, 8) * 8 * 64;
+}
+__device__ __forceinline__ WorkItem work_item_grouped(int64_t q_tiles, int nchunks, int64_t row_blocks, int grp_rows) {
+    const int grp_chunks = 64 / grp_rows;
+    const int64_t cgroups = (nchunks + grp_chunks - 1) / grp_chunks;
+    const int xcd = blockIdx.x & 7;
+    const int64_t seq = blockIdx.x >> 3;
+    const int64_t g = (seq >> 6) * 8 + xcd;
+    const int within = (int)(seq & 63);
+    const int64_t rb = (g / cgroups) * grp_rows + within / grp_chunks;
+    const int chunk = (int)((g % cgroups) * grp_chunks + within % grp_chunks);
+    WorkItem w;
+    w.prow0 = rb * TB;
+    if (rb >= row_blocks || chunk >= nchunks) {
+        w.qtile0 = 0;
+        w.ntiles = 0;
+        return w;
+    }
+    w.qtile0 = q_tiles * chunk / nchunks;
+    w.ntiles = (int)(q_tiles * (chunk + 1) / nchunks - w.qtile0);
+    return w;
+}
+
 // the generic (gather) pipeline numbers tiles locally; shift them to absolute Q tile indices
 template <class Epi>
 struct OffsetEpilogue {
@@ -1251,7 +1284,7 @@ extern "C" int am_knn_bounds_f32(const float* X, int64_t N, int64_t ld, int D, i
             hipLaunchKernelGGL(knn_merge_kernel<KC>, dim3((unsigned)ceil_div(nrows, 256)), dim3(256), 0, st, partial, nrows,
                                p.pre_chunks, k + 1, 1, out_bound_sq);
             hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(nrows, 256)), dim3(256), 0, st, out_bound_sq,
-                               out_bound_sq, xn + row0, nrows, maxn, 1.f);
+                               out_bound_sq, xn + row0, nrows, maxn, fast_c(D));
             AM_LAUNCH_CHECK();
             return AM_OK;
         };

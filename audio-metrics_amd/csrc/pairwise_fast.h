@@ -7,29 +7,35 @@
 // pairs with the f32 arithmetic of the exact engine, so the results are BIT-IDENTICAL to pairwise.hip's:
 //
 //   1. X, Y are copied once to f16 (round-to-nearest-even) after an exact power-of-two scaling that puts each
-//      matrix's largest |element| M into [2^13, 2^14) (half_scale_exp).  A scaled element v becomes v^ with
-//      |v^ - v| <= 2^-11 |v| + eta, eta = 2^-14 (the smallest normal f16: covers subnormal operands being
-//      flushed by the matrix core).  For the f16 dot product accumulated in f32 and scaled back,
-//          |dot' - <x,y>| <= (2^-10 + 2^-21) sum_k |x_k y_k| + eta 2^-13 (|x|_1 M_y + |y|_1 M_x) (1 + 2^-11) + D eta^2 2^-26 M_x M_y
-//                             + (f32 accumulation, < 2^-14 |x||y|)
-//                         <= (2^-10 + 2^-13 + 2^-26 sqrt(D)) (|x|^2 + |y|^2 + M_x^2 + M_y^2) / 2
-//      (Cauchy-Schwarz, |x|_1 <= sqrt(D) |x|, 2ab <= a^2 + b^2), and M_x^2 <= max_i |x_i|^2.  The approximate
-//      squared distance a = fma(-2 / (scales), dot'_scaled, |x|^2 + |y|^2) (same f32 norms and the same
-//      rounding of their sum as the exact value t) therefore satisfies, for D <= 2^20,
-//          |a - t| <= FAST_C (|x|^2 + max_j |y_j|^2)  resp.  FAST_C (max_i |x_i|^2 + |y|^2),
-//      FAST_C = 2^-10 + 2^-12: twice the constant above (the 2^-12 slack also covers the f32 chain's own error,
-//      the error of the f32 norms and the rounding of the thresholds below, each < 2^-13 relative).
+//      matrix's largest |element| M into [2^13, 2^14) (half_scale_exp).  A scaled element v becomes v^ = v (1 + d) + e
+//      with |d| <= 2^-11 and |e| <= eta = 2^-14 <= 2^-27 M (the smallest normal f16: covers subnormal operands being
+//      flushed by the matrix core).  f16 x f16 products are exact in f32, so the f16 dot product, scaled back, differs
+//      from <x, y> by at most
+//          (2^-10 + 2^-22) S + (1 + 2^-11) 2^-27 (M_y |x|_1 + M_x |y|_1) + D 2^-54 M_x M_y  +  D 2^-22 S ,
+//      S = sum_k |x_k y_k|; the last term is the accumulation inside the matrix core, priced at one rounding of
+//      relative size 2^-23 (truncation) per added term with a factor 2 to spare, whatever the order.  With
+//      S <= (|x|^2 + |y|^2) / 2, |x|_1 <= sqrt(D) |x|, 2ab <= a^2 + b^2 and M_x^2, M_y^2 <= G := the largest squared
+//      row norm of EITHER matrix, the approximate squared distance a = fma(-2 / (scales), dot', |x|^2 + |y|^2) (same
+//      f32 norms and the same rounding of their sum as the exact value t, whose own fmaf chain is off by at most
+//      D 2^-24 S) satisfies
+//          |a - t| <= fast_c(D) (|x|^2 + G),     fast_c(D) = 2^-10 + 2^-19 + 2^-25 sqrt(D) + D 2^-21 ,
+//      for D <= 4096 (wider inputs take the exact kernels); 2^-19 covers the roundings of a, t, the thresholds
+//      below and of the f32 norms the bound itself is computed from.  At D = 512 fast_c = 1.2224e-3.
 //   2. A pair is QUEUED when a <= threshold + eps, which every pair with t <(=) threshold satisfies.
-//   3. Queued pairs are grouped by row, their exact t is computed with the engine's fmaf order
-//      (exact_pair_dot, the chain oracle/exact_c reproduces), and the reductions of the exact kernels are applied
-//      to those values.  Queue overflow falls back to the exact computation (per row for the k-NN radii, for the
-//      whole call for the membership counts), as does a matrix whose M is not a finite number within 2^+-60.
+//   3. Queued pairs are evaluated with the engine's fmaf order (the chain oracle/exact_c reproduces), and the
+//      reductions of the exact kernels are applied to those values.  Queue overflow falls back to the exact
+//      computation (per row for the k-NN radii, for the whole call for the membership counts), as does a matrix
+//      whose M is not a finite number within 2^+-60.
 #pragma once
+#include "wide_engine.h"
 
 namespace am {
 
 constexpr int EV_FAST = EV_DEFAULT | EV_F16;
-constexpr float FAST_C = 0.0009765625f + 0.000244140625f;                     // 2^-10 + 2^-12
+constexpr int FAST_MAX_DIM = 4096;                                            // fast_c's derivation holds up to here
+static inline float fast_c(int D) {
+    return 0.0009765625f + 1.9073486328125e-06f + 2.98023223876953125e-08f * sqrtf((float)D) + (float)D * 4.76837158203125e-07f;
+}
 constexpr int FAST_LDH_ALIGN = 64;                                            // f16 row stride: whole 128-B slabs
 
 static inline int64_t half_ld(int D) { return (int64_t)(D + FAST_LDH_ALIGN - 1) / FAST_LDH_ALIGN * FAST_LDH_ALIGN; }
@@ -110,7 +116,7 @@ __device__ __forceinline__ float exact_pair_dot(const float* __restrict__ xs, co
 
 // ------------------------------------------------------------------------------------------------
 // Membership counts, filter pass.  P rows = reference rows i (lane-local), Q rows = candidate rows j.
-// With E_i = FAST_C (|r_i|^2 + max_j |c_j|^2) and E'_j = FAST_C (max_i |r_i|^2 + |c_j|^2)  (>= eps of every pair),
+// With G = the largest squared row norm of either set, E_i = fast_c (|r_i|^2 + G) and E'_j = fast_c (G + |c_j|^2)  (>= eps of every pair),
 // T_i = T(r_ref[i]), T'_j = T(r_cand[j]) the strict "<" thresholds of the exact kernel:
 //   column counts   a <  T_i - E_i   the pair is inside for certain: counted at once (as the exact kernel does)
 //                   a <= T_i + E_i   otherwise ambiguous: QUEUED
@@ -129,7 +135,8 @@ struct CrossFastEpilogue {
     const float* qnorm;
     const float* qthr;
     int64_t nq;
-    float rnmax_c;              // FAST_C * max_i |r_i|^2
+    float fc;                   // fast_c(D)
+    float rnmax_c;              // fast_c * G
     float* aux;                 // LDS [2][3][128] : |c_j|^2, T'_j + E'_j, T'_j - E'_j of the tile
     int32_t* col_count;
     uint2* wgq;                 // this workgroup's append region
@@ -162,7 +169,7 @@ struct CrossFastEpilogue {
         if (L.tid < TB) {
             const int64_t j = qtile * TB + L.tid;
             if (j < nq) {
-                const float e = fmaf(FAST_C, qnorm[j], rnmax_c);
+                const float e = fmaf(fc, qnorm[j], rnmax_c);
                 aux_n = qnorm[j];
                 aux_hi = qthr[j] + e;
                 aux_lo = qthr[j] - e;
@@ -256,20 +263,26 @@ cross_fast_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const f
                   const float* __restrict__ cnorm, const float* __restrict__ cthr, int Dh, int nchunks, int qstride,
                   const unsigned* __restrict__ maxn, unsigned* __restrict__ rmin_approx, unsigned* __restrict__ row_any,
                   unsigned* __restrict__ row_cover, int32_t* __restrict__ col_count, uint2* __restrict__ wgq, int qcap, int* __restrict__ wgq_count,
-                  uint2* __restrict__ ovq, int* __restrict__ ov_count, int ovcap, int* __restrict__ fail, int dbg) {
+                  uint2* __restrict__ ovq, int* __restrict__ ov_count, int ovcap, int* __restrict__ fail, int dbg, float fc,
+                  int grp_rows) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
     const int64_t q_tiles = ((Nc + TB - 1) / TB + qstride - 1) / qstride;
-    const WorkItem w = work_item(q_tiles, nchunks);
+    const WorkItem w = grp_rows > 0 ? work_item_grouped(q_tiles, nchunks, (Nr + TB - 1) / TB, grp_rows) : work_item(q_tiles, nchunks);
+    if (w.ntiles == 0) {                                   // padding item of the grouped grid
+        if (!PRE && L.tid == 0) wgq_count[blockIdx.x] = 0;
+        return;
+    }
     int* qn = reinterpret_cast<int*>(lds + ENGINE_LDS_FLOATS + FAST_AUX_FLOATS);
     if (L.tid == 0) *qn = 0;
 
-    const float rnmax = __uint_as_float(maxn[0]), cnmax = __uint_as_float(maxn[1]);
+    const float gmax = fmaxf(__uint_as_float(maxn[0]), __uint_as_float(maxn[1]));
     CrossFastEpilogue epi(L);
+    epi.fc = fc;
     epi.qnorm = cnorm;
     epi.qthr = cthr;
     epi.nq = Nc;
-    epi.rnmax_c = FAST_C * rnmax;
+    epi.rnmax_c = fc * gmax;
     epi.aux = lds + ENGINE_LDS_FLOATS;
     epi.col_count = col_count;
     epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
@@ -289,7 +302,7 @@ cross_fast_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const f
         epi.prow[nt] = i;
         epi.rowok[nt] = ok;
         epi.xn[nt] = ok ? rnorm[i] : 0.f;
-        const float e = FAST_C * ((ok ? rnorm[i] : 0.f) + cnmax);
+        const float e = fc * ((ok ? rnorm[i] : 0.f) + gmax);
         epi.thi[nt] = ok ? rthr[i] + e : -INFINITY;
         epi.tlo[nt] = ok ? rthr[i] - e : -INFINITY;
         epi.e2[nt] = 2.f * e;
@@ -330,6 +343,272 @@ __device__ __forceinline__ void cross_apply(float t, int64_t j, unsigned jflag, 
     }
 }
 
+// ---- the same filter on the 256 x 256 f16 engine (wide_engine.h): main pass only ---------------------------------
+constexpr int WIDE_AUX_WORDS = 6 * WTB;                                    // LDS [2][3][256]
+constexpr size_t WIDE_CROSS_LDS_BYTES = (WENGINE_LDS_WORDS + WIDE_AUX_WORDS) * sizeof(float) + 16;
+
+struct CrossWideEpilogue {
+    const float* qnorm;
+    const float* qthr;
+    int64_t nq;
+    float fc, rnmax_c;
+    float* aux;                 // LDS [2][3][256] : |c_j|^2, T'_j + E'_j, T'_j - E'_j of the tile
+    int32_t* col_count;
+    uint2* wgq;
+    int* qn;
+    int qcap;
+    uint2* ovq;
+    int* ov_count;
+    int ovcap;
+    int* fail;
+    int dbg;
+    float dsc;
+    int64_t prow[2];
+    float xn[2], thi[2], tlo[2], e2[2], m[2];
+    bool rowok[2], anyf[2], covf[2];
+    float aux_n, aux_hi, aux_lo;
+    const WLane& L;
+
+    __device__ __forceinline__ CrossWideEpilogue(const WLane& l) : L(l) {}
+    __device__ __forceinline__ void push(int64_t i, unsigned jflag) {
+        const int slot = atomicAdd(qn, 1);
+        if (slot < qcap) {
+            wgq[slot] = make_uint2((unsigned)i, jflag);
+        } else {
+            const int s2 = atomicAdd(ov_count, 1);
+            if (s2 < ovcap) ovq[s2] = make_uint2((unsigned)i, jflag);
+            else *fail = 1;
+        }
+    }
+    __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
+        if (L.tid < WTB) {
+            const int64_t j = qtile * WTB + L.tid;
+            if (j < nq) {
+                const float e = fmaf(fc, qnorm[j], rnmax_c);
+                aux_n = qnorm[j];
+                aux_hi = qthr[j] + e;
+                aux_lo = qthr[j] - e;
+            } else {
+                aux_n = INFINITY;
+                aux_hi = -INFINITY;
+                aux_lo = -INFINITY;
+            }
+        }
+    }
+    __device__ __forceinline__ void aux_commit(int t) {
+        if (L.tid < WTB) {
+            float* d = aux + (t & 1) * 3 * WTB + L.tid;
+            d[0] = aux_n;
+            d[WTB] = aux_hi;
+            d[2 * WTB] = aux_lo;
+        }
+    }
+    template <bool WANT_MIN>
+    __device__ __forceinline__ void finish_impl(int t, int64_t qtile, f32x16 (&acc)[4][2]) {
+        const float* a = aux + (t & 1) * 3 * WTB + L.wm * 128 + L.h * 4;
+        const int64_t jbase = qtile * WTB + L.wm * 128 + L.h * 4;
+        if (dbg & 8) return;                                   // timing experiment: MFMA pipeline only
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x4 yn[4], th[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
+                th[g4] = *reinterpret_cast<const f32x4*>(a + WTB + mt * 32 + g4 * 8);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float tmin = INFINITY, marg = INFINITY;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
+                    tmin = fminf(tmin, u);
+                    marg = fminf(marg, u - th[reg >> 2][reg & 3]);
+                }
+                if constexpr (WANT_MIN) m[nt] = fminf(m[nt], fmaxf(tmin, 0.f));
+                const float prow_thr = WANT_MIN ? fmaxf(thi[nt], m[nt] + e2[nt]) : thi[nt];
+                if (__any(rowok[nt] && (tmin <= prow_thr || (!anyf[nt] && marg <= 0.f)))) {
+                    const float* alo = a + 2 * WTB + mt * 32;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
+                        const int64_t j = jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3);
+                        const bool sure = rowok[nt] && u < tlo[nt];
+                        const unsigned long long mask = __ballot(sure);
+                        if (mask != 0ull && L.lane == 0) {               // lanes 0-31: column j, lanes 32-63: column j + 4
+                            const int lo = __popcll(mask & 0xffffffffull);
+                            const int hi = __popcll(mask >> 32);
+                            if (lo) atomicAdd(col_count + j - L.h * 4, lo);
+                            if (hi) atomicAdd(col_count + j - L.h * 4 + 4, hi);
+                        }
+                        covf[nt] = covf[nt] || sure;
+                        bool want = rowok[nt] && !sure && u <= thi[nt];
+                        if constexpr (WANT_MIN) want = want || (rowok[nt] && u <= m[nt] + e2[nt]);
+                        if (rowok[nt] && !anyf[nt] && u <= th[reg >> 2][reg & 3]) {
+                            if (u < alo[(reg >> 2) * 8 + (reg & 3)]) anyf[nt] = true;       // certain witness
+                            else want = true;                                             // ambiguous "any"
+                        }
+                        if (want) push(prow[nt], (unsigned)j | (sure ? FAST_COUNTED : 0u));
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <bool WANT_MIN>
+struct CrossWideShim {
+    CrossWideEpilogue& e;
+    __device__ __forceinline__ void aux_issue(int t, int64_t q) { e.aux_issue(t, q); }
+    __device__ __forceinline__ void aux_commit(int t) { e.aux_commit(t); }
+    __device__ __forceinline__ void finish(int t, int64_t q, f32x16 (&acc)[4][2]) { e.template finish_impl<WANT_MIN>(t, q, acc); }
+};
+
+struct WideTiles {
+    int64_t q0;
+    __device__ __forceinline__ int64_t operator()(int t) const { return q0 + t; }
+};
+
+// work item = (256-row block, column chunk), XCD-grouped: block b runs on XCD b % 8; the 32 workgroups resident on an
+// XCD (one per CU) form a group of grp_rows row blocks x 32 / grp_rows chunks, so a group keeps grp_rows P blocks
+// (256 KB each) in the 4 MB L2 and fetches each Q tile once.
+struct WideWork {
+    int64_t rb, qtile0;
+    int ntiles;
+};
+static inline int64_t wide_grouped_blocks(int64_t row_blocks, int nchunks, int grp_rows) {
+    const int grp_chunks = 32 / grp_rows;
+    const int64_t groups = ceil_div(row_blocks, grp_rows) * ceil_div(nchunks, grp_chunks);
+    return ceil_div(groups, 8) * 8 * 32;
+}
+__device__ __forceinline__ WideWork wide_work(int64_t q_tiles, int nchunks, int64_t row_blocks, int grp_rows) {
+    const int grp_chunks = 32 / grp_rows;
+    const int64_t cgroups = (nchunks + grp_chunks - 1) / grp_chunks;
+    const int xcd = blockIdx.x & 7;
+    const int64_t seq = blockIdx.x >> 3;
+    const int64_t g = (seq >> 5) * 8 + xcd;
+    const int within = (int)(seq & 31);
+    WideWork w;
+    w.rb = (g / cgroups) * grp_rows + within / grp_chunks;
+    const int chunk = (int)((g % cgroups) * grp_chunks + within % grp_chunks);
+    w.qtile0 = 0;
+    w.ntiles = 0;
+    if (w.rb < row_blocks && chunk < nchunks) {
+        w.qtile0 = q_tiles * chunk / nchunks;
+        w.ntiles = (int)(q_tiles * (chunk + 1) / nchunks - w.qtile0);
+    }
+    return w;
+}
+
+template <bool WANT_MIN>
+__global__ void __launch_bounds__(WTHREADS, 1)
+cross_wide_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const float* __restrict__ rnorm,
+                  const float* __restrict__ rthr, const float* __restrict__ Cb, int64_t Nc, int64_t ldc,
+                  const float* __restrict__ cnorm, const float* __restrict__ cthr, int Dh, int nchunks, int grp_rows,
+                  const unsigned* __restrict__ maxn, unsigned* __restrict__ rmin_approx, unsigned* __restrict__ row_any,
+                  unsigned* __restrict__ row_cover, int32_t* __restrict__ col_count, uint2* __restrict__ wgq, int qcap,
+                  int* __restrict__ wgq_count, uint2* __restrict__ ovq, int* __restrict__ ov_count, int ovcap,
+                  int* __restrict__ fail, int dbg, float fc) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const WLane L;
+    const WideWork w = wide_work((Nc + WTB - 1) / WTB, nchunks, (Nr + WTB - 1) / WTB, grp_rows);
+    if (w.ntiles == 0) {
+        if (L.tid == 0) wgq_count[blockIdx.x] = 0;
+        return;
+    }
+    int* qn = reinterpret_cast<int*>(lds + WENGINE_LDS_WORDS + WIDE_AUX_WORDS);
+    if (L.tid == 0) *qn = 0;
+    const float gmax = fmaxf(__uint_as_float(maxn[0]), __uint_as_float(maxn[1]));
+    CrossWideEpilogue epi(L);
+    epi.fc = fc;
+    epi.qnorm = cnorm;
+    epi.qthr = cthr;
+    epi.nq = Nc;
+    epi.rnmax_c = fc * gmax;
+    epi.aux = lds + WENGINE_LDS_WORDS;
+    epi.col_count = col_count;
+    epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
+    epi.qn = qn;
+    epi.qcap = qcap;
+    epi.ovq = ovq;
+    epi.ov_count = ov_count;
+    epi.ovcap = ovcap;
+    epi.fail = fail;
+    epi.dbg = dbg;
+    epi.dsc = half_unscale(maxn[2], maxn[3]);
+    if (blockIdx.x == 0 && L.tid == 0 && !(half_scale_ok(maxn[2]) && half_scale_ok(maxn[3]))) *fail = 1;
+    const int64_t prow0 = w.rb * WTB;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int64_t i = prow0 + L.wn * 64 + nt * 32 + L.r;
+        const bool ok = i < Nr;
+        epi.prow[nt] = i;
+        epi.rowok[nt] = ok;
+        epi.xn[nt] = ok ? rnorm[i] : 0.f;
+        const float e = fc * ((ok ? rnorm[i] : 0.f) + gmax);
+        epi.thi[nt] = ok ? rthr[i] + e : -INFINITY;
+        epi.tlo[nt] = ok ? rthr[i] - e : -INFINITY;
+        epi.e2[nt] = 2.f * e;
+        epi.m[nt] = (WANT_MIN && ok) ? __uint_as_float(rmin_approx[i]) : INFINITY;
+        epi.anyf[nt] = ok ? (row_any[i] != 0u) : true;
+        epi.covf[nt] = false;
+    }
+    CrossWideShim<WANT_MIN> shim{epi};
+    wide_pipeline(Cb, Nc, ldc, WideTiles{w.qtile0}, Rb, Nr, ldr, prow0, w.ntiles, Dh, lds, L, shim);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float mn = fminf(epi.m[nt], __shfl_xor(epi.m[nt], 32));
+        const int other = __shfl_xor((int)epi.anyf[nt], 32);
+        const int other_c = __shfl_xor((int)epi.covf[nt], 32);
+        const bool any = epi.anyf[nt] || other != 0;
+        const bool cov = epi.covf[nt] || other_c != 0;
+        if (L.h == 0 && epi.rowok[nt]) {
+            if constexpr (WANT_MIN) atomicMin(rmin_approx + epi.prow[nt], __float_as_uint(mn));
+            if (any) atomicOr(row_any + epi.prow[nt], 1u);
+            if (cov) atomicOr(row_cover + epi.prow[nt], 1u);
+        }
+    }
+    __syncthreads();
+    if (L.tid == 0) wgq_count[blockIdx.x] = *qn < qcap ? *qn : qcap;
+}
+
+// exact evaluation of the regions of cross_wide_kernel: one queued pair per thread, both rows from global memory
+__global__ void __launch_bounds__(256) cross_verify_regions_kernel(const float* __restrict__ R, int64_t ldr,
+                                                                   const float* __restrict__ rnorm, const float* __restrict__ rthr,
+                                                                   const float* __restrict__ C, int64_t ldc,
+                                                                   const float* __restrict__ cnorm, const float* __restrict__ cthr,
+                                                                   int D, const uint2* __restrict__ wgq, int qcap,
+                                                                   const int* __restrict__ wgq_count, int32_t* __restrict__ col_count,
+                                                                   unsigned* __restrict__ row_min_bits,
+                                                                   unsigned* __restrict__ row_any, unsigned* __restrict__ row_cover) {
+    const int n = wgq_count[blockIdx.x];
+    const uint2* q = wgq + (int64_t)blockIdx.x * qcap;
+    const int dp = (D + 7) / 8 * 8;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const uint2 v = q[e];
+        const int64_t i = v.x, j = v.y & ~FAST_COUNTED;
+        const float* x = R + i * ldr;
+        const float* y = C + j * ldc;
+        float acc = 0.f;
+        for (int c = 0; c < dp; c += 8) {
+            const f32x4 y0 = load_k4(y, c, D), y1 = load_k4(y, c + 4, D);
+            const f32x4 x0 = load_k4(x, c, D), x1 = load_k4(x, c + 4, D);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc = fmaf(y0[s], x0[s], acc);
+                acc = fmaf(y1[s], x1[s], acc);
+            }
+        }
+        const float t = fmaxf(fmaf(-2.f, acc, rnorm[i] + cnorm[j]), 0.f);
+        float mn = INFINITY;
+        bool any = false, cov = false;
+        cross_apply(t, j, v.y, rthr[i], cthr, col_count, mn, any, cov);
+        if (row_min_bits != nullptr) atomicMin(row_min_bits + i, __float_as_uint(mn));
+        if (any) atomicOr(row_any + i, 1u);
+        if (cov) atomicOr(row_cover + i, 1u);
+    }
+}
+
 // Verification of one workgroup region (same grid as the filter pass): the entries are bucketed by reference
 // row in LDS, then each wave takes rows - the row goes to LDS once, every lane evaluates one candidate with the
 // exact engine's fmaf chain - and the exact reductions are applied.
@@ -337,7 +616,7 @@ __global__ void __launch_bounds__(256) cross_verify_kernel(const float* __restri
                                                            const float* __restrict__ rnorm, const float* __restrict__ rthr,
                                                            const float* __restrict__ C, int64_t ldc,
                                                            const float* __restrict__ cnorm, const float* __restrict__ cthr, int D,
-                                                           int nchunks, const uint2* __restrict__ wgq, int qcap,
+                                                           int nchunks, int grp_rows, const uint2* __restrict__ wgq, int qcap,
                                                            const int* __restrict__ wgq_count, int32_t* __restrict__ col_count,
                                                            unsigned* __restrict__ row_min_bits, unsigned* __restrict__ row_any,
                                                            unsigned* __restrict__ row_cover) {
@@ -348,7 +627,9 @@ __global__ void __launch_bounds__(256) cross_verify_kernel(const float* __restri
     const int dp = (D + 7) / 8 * 8;
     unsigned* sorted = reinterpret_cast<unsigned*>(vlds + 4 * dp);
     const uint2* q = wgq + (int64_t)blockIdx.x * qcap;
-    const int64_t prow0 = (int64_t)(blockIdx.x / nchunks) * TB;        // work_item(): row block of this region
+    // row block of this region: the filter kernel's work mapping (q_tiles is irrelevant for prow0)
+    const int64_t prow0 = grp_rows > 0 ? work_item_grouped(1, nchunks, (Nr + TB - 1) / TB, grp_rows).prow0
+                                       : (int64_t)(blockIdx.x / nchunks) * TB;
     if (threadIdx.x < TB) bucket[threadIdx.x] = 0;
     __syncthreads();
     constexpr int PER = 8;                                             // qcap <= 256 * PER
@@ -463,14 +744,34 @@ __global__ void __launch_bounds__(256) cross_fail_reset_kernel(const int* __rest
 }
 
 struct CrossFastPlan {
-    int nchunks, pre_chunks, qstride, qcap, ovcap;
+    int nchunks, pre_chunks, qstride, qcap, ovcap, grp_rows;
     int64_t blocks;
+    bool wide;                  // main pass on the 256 x 256 engine (cross_wide_kernel)
+    int pre_nchunks_unused;
 };
 
 static CrossFastPlan plan_cross_fast(int64_t Nr, int64_t Nc) {
     CrossFastPlan p;
     p.nchunks = choose_chunks(Nr, Nc);
-    p.blocks = ceil_div(Nr, TB) * p.nchunks;
+    static const int grp = env_int("AM_FAST_GROUP_ROWS", 8);                     // 0: plain (row block, chunk) order
+    p.grp_rows = (grp == 1 || grp == 2 || grp == 4 || grp == 8 || grp == 16 || grp == 32 || grp == 64) ? grp : 0;
+    p.blocks = p.grp_rows > 0 ? cross_grouped_blocks(ceil_div(Nr, TB), p.nchunks, p.grp_rows) : ceil_div(Nr, TB) * p.nchunks;
+    static const int wide = env_int("AM_FAST_WIDE", 1);
+    p.wide = wide != 0;
+    p.pre_nchunks_unused = 0;
+    if (p.wide) {
+        static const int wgrp = env_int("AM_WIDE_GROUP_ROWS", 8);
+        static const int wtarget = env_int("AM_WIDE_WG_TARGET", 6144);               // ~24 rounds of 256 CUs x 1 workgroup
+        p.grp_rows = (wgrp == 1 || wgrp == 2 || wgrp == 4 || wgrp == 8 || wgrp == 16 || wgrp == 32) ? wgrp : 8;
+        const int grp_chunks = 32 / p.grp_rows;
+        const int64_t rbw = ceil_div(Nr, WTB), qtw = ceil_div(Nc, WTB);
+        int64_t want = std::max<int64_t>(ceil_div(wtarget, rbw), 1);
+        want = ceil_div(want, grp_chunks) * grp_chunks;
+        want = std::min<int64_t>(want, std::max<int64_t>(qtw / grp_chunks * grp_chunks, 1));
+        want = std::min<int64_t>(want, qtw);
+        p.nchunks = (int)want;
+        p.blocks = wide_grouped_blocks(rbw, p.nchunks, p.grp_rows);
+    }
     static const int stride = env_int("AM_FAST_PRE_STRIDE", 16);
     p.qstride = stride;
     const int64_t sample_tiles = ceil_div(ceil_div(Nc, TB), p.qstride);
@@ -506,7 +807,7 @@ static bool cross_fast_enabled(int64_t Nr, int64_t Nc, int D) {
     static const int on = env_int("AM_PRDC_FAST", 1);
     static const int64_t min_pairs = (int64_t)env_int("AM_FAST_MIN_PAIRS_LOG2", 24);
     const size_t verify_lds = (size_t)(4 * ((D + 7) / 8 * 8) + 2048) * sizeof(float);
-    return on != 0 && D >= 32 && verify_lds <= 60 * 1024 && Nr * Nc >= ((int64_t)1 << min_pairs) &&
+    return on != 0 && D >= 32 && D <= FAST_MAX_DIM && verify_lds <= 60 * 1024 && Nr * Nc >= ((int64_t)1 << min_pairs) &&
            Nr < ((int64_t)1 << 31) && Nc < ((int64_t)1 << 31);
 }
 
@@ -541,26 +842,51 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
     const int dbg = env_int("AM_FAST_DBG", 0);
     // sampled pre-pass over every 16th column tile: certain "any" witnesses (and, when the row minimum is wanted,
     // an approximate minimum that bounds its candidate queue)
-    auto launch_filter = [&](auto kernel, unsigned grid, int nchunks, int qstride) {
+    auto launch_filter = [&](auto kernel, unsigned grid, int nchunks, int qstride, int grp_rows) {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(ENGINE_THREADS), FAST_LDS_BYTES, st, Rb, Nr, ldb / 2, rn, rt, Cb, Nc, ldb / 2,
                            cn, ct, Dh, nchunks, qstride, b.maxn, b.rmin_approx, rany, rcov, col_count, b.wgq, p.qcap, b.wgq_count,
-                           b.ovq, b.ov_count, p.ovcap, fail, dbg);
+                           b.ovq, b.ov_count, p.ovcap, fail, dbg, fast_c(D), grp_rows);
     };
     const unsigned pre_grid = (unsigned)(ceil_div(Nr, TB) * p.pre_chunks);
-    if (want_min) launch_filter(&cross_fast_kernel<true, true>, pre_grid, p.pre_chunks, p.qstride);
-    else launch_filter(&cross_fast_kernel<true, false>, pre_grid, p.pre_chunks, p.qstride);
-    AM_LAUNCH_CHECK();
-    clock_begin(AM_KERNEL_PRDC_CROSS, st);
-    if (want_min) launch_filter(&cross_fast_kernel<false, true>, (unsigned)p.blocks, p.nchunks, 1);
-    else launch_filter(&cross_fast_kernel<false, false>, (unsigned)p.blocks, p.nchunks, 1);
-    clock_end(AM_KERNEL_PRDC_CROSS, st);
+    if (want_min) launch_filter(&cross_fast_kernel<true, true>, pre_grid, p.pre_chunks, p.qstride, 0);
+    else launch_filter(&cross_fast_kernel<true, false>, pre_grid, p.pre_chunks, p.qstride, 0);
     AM_LAUNCH_CHECK();
     unsigned* rmin_or_null = want_min ? rmin : nullptr;
-    const size_t verify_lds = (size_t)(4 * ((D + 7) / 8 * 8) + p.qcap) * sizeof(float);
-    clock_begin(AM_KERNEL_PRDC_VERIFY, st);
-    hipLaunchKernelGGL(cross_verify_kernel, dim3((unsigned)p.blocks), dim3(256), verify_lds, st, R, Nr, ldr, rn, rt, C, ldc, cn, ct,
-                       D, p.nchunks, b.wgq, p.qcap, b.wgq_count, col_count, rmin_or_null, rany, rcov);
-    clock_end(AM_KERNEL_PRDC_VERIFY, st);
+    if (p.wide) {
+        static bool wattr_done = false;
+        if (!wattr_done) {
+            AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_wide_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_CROSS_LDS_BYTES));
+            AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_wide_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_CROSS_LDS_BYTES));
+            wattr_done = true;
+        }
+        auto launch_wide = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3((unsigned)p.blocks), dim3(WTHREADS), WIDE_CROSS_LDS_BYTES, st, Rb, Nr, ldb / 2, rn, rt, Cb,
+                               Nc, ldb / 2, cn, ct, Dh, p.nchunks, p.grp_rows, b.maxn, b.rmin_approx, rany, rcov, col_count, b.wgq,
+                               p.qcap, b.wgq_count, b.ovq, b.ov_count, p.ovcap, fail, dbg, fast_c(D));
+        };
+        clock_begin(AM_KERNEL_PRDC_CROSS, st);
+        if (want_min) launch_wide(&cross_wide_kernel<true>);
+        else launch_wide(&cross_wide_kernel<false>);
+        clock_end(AM_KERNEL_PRDC_CROSS, st);
+        AM_LAUNCH_CHECK();
+        clock_begin(AM_KERNEL_PRDC_VERIFY, st);
+        hipLaunchKernelGGL(cross_verify_regions_kernel, dim3((unsigned)p.blocks), dim3(256), 0, st, R, ldr, rn, rt, C, ldc, cn, ct, D,
+                           b.wgq, p.qcap, b.wgq_count, col_count, rmin_or_null, rany, rcov);
+        clock_end(AM_KERNEL_PRDC_VERIFY, st);
+    } else {
+        clock_begin(AM_KERNEL_PRDC_CROSS, st);
+        if (want_min) launch_filter(&cross_fast_kernel<false, true>, (unsigned)p.blocks, p.nchunks, 1, p.grp_rows);
+        else launch_filter(&cross_fast_kernel<false, false>, (unsigned)p.blocks, p.nchunks, 1, p.grp_rows);
+        clock_end(AM_KERNEL_PRDC_CROSS, st);
+        AM_LAUNCH_CHECK();
+        const size_t verify_lds = (size_t)(4 * ((D + 7) / 8 * 8) + p.qcap) * sizeof(float);
+        clock_begin(AM_KERNEL_PRDC_VERIFY, st);
+        hipLaunchKernelGGL(cross_verify_kernel, dim3((unsigned)p.blocks), dim3(256), verify_lds, st, R, Nr, ldr, rn, rt, C, ldc, cn,
+                           ct, D, p.nchunks, p.grp_rows, b.wgq, p.qcap, b.wgq_count, col_count, rmin_or_null, rany, rcov);
+        clock_end(AM_KERNEL_PRDC_VERIFY, st);
+    }
     AM_LAUNCH_CHECK();
     hipLaunchKernelGGL(cross_verify_overflow_kernel, dim3(1024), dim3(256), 0, st, R, ldr, rn, rt, C, ldc, cn, ct, D, b.ovq,
                        b.ov_count, p.ovcap, fail, col_count, rmin_or_null, rany, rcov);
@@ -585,7 +911,7 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
 
 // ------------------------------------------------------------------------------------------------
 // k-NN radii of a set against itself, filter pass: the symmetric sweep of knn_sym_kernel on the f16 copy.
-// thr[i] is an upper bound of (true (k+1)-th smallest t of row i) + E_i, E_i = FAST_C (|x_i|^2 + max_j |x_j|^2):
+// thr[i] is an upper bound of (true (k+1)-th smallest t of row i) + E_i, E_i = fast_c (|x_i|^2 + max_j |x_j|^2):
 // every pair with t_ij <= the row's final value has a_ij <= thr[i], in whichever direction it is met.
 //   own rows (lane-local):  queue (i, j) when a <= min(thr[i] at workgroup start, kthA + 2 E_i), kthA = the
 //                           (k+1)-th smallest max(a, 0) this lane has seen (true values of those columns are
@@ -691,7 +1017,7 @@ __global__ void __launch_bounds__(ENGINE_THREADS, 2) __attribute__((amdgpu_waves
 knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float* __restrict__ xnorm, float* thr, int Dh,
                 int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
                 int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
-                int* __restrict__ wgq_count, int part, int nparts) {
+                int* __restrict__ wgq_count, int part, int nparts, float fc) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
     const int64_t T = (N + TB - 1) / TB;
@@ -721,7 +1047,7 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
         epi.prow[nt] = i;
         epi.rowok[nt] = i < N;
         epi.xn[nt] = i < N ? xnorm[i] : 0.f;
-        epi.e2[nt] = 2.f * FAST_C * ((i < N ? xnorm[i] : 0.f) + nmax);
+        epi.e2[nt] = 2.f * fc * ((i < N ? xnorm[i] : 0.f) + nmax);
         epi.flt[nt] = i < N ? __hip_atomic_load(thr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = s < KCAP - k1 ? -INFINITY : INFINITY;
@@ -757,7 +1083,7 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
                 }
             }
             const float kthv = m[KCAP - 1];
-            const float bound = kthv + 2.f * FAST_C * (xnorm[i] + nmax);     // >= 0, so its bit pattern orders like the value
+            const float bound = kthv + 2.f * fc * (xnorm[i] + nmax);     // >= 0, so its bit pattern orders like the value
             atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
         }
     }
@@ -766,9 +1092,9 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
 // pre-pass result (approximate (k+1)-th smallest over the column sample) -> filter bound
 __global__ void __launch_bounds__(256) knn_fast_bound_kernel(const float* __restrict__ in, float* __restrict__ thr,
                                                              const float* __restrict__ xnorm, int64_t n,
-                                                             const unsigned* __restrict__ maxn, float factor) {
+                                                             const unsigned* __restrict__ maxn, float factor /* 1 or 2 times fast_c(D) */) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) thr[i] = in[i] + factor * FAST_C * (xnorm[i] + __uint_as_float(maxn[0]));     // +inf stays +inf
+    if (i < n) thr[i] = in[i] + factor * (xnorm[i] + __uint_as_float(maxn[0]));     // +inf stays +inf
 }
 
 // After the sweep: (1) the APPROXIMATE values of the queued pairs are filed under their rows
@@ -809,7 +1135,7 @@ __global__ void __launch_bounds__(256) knn_fast_prune_kernel(const float* __rest
                                                              const int* __restrict__ cnt, int cap, int64_t N, int k1,
                                                              const float* __restrict__ xnorm, const unsigned* __restrict__ maxn,
                                                              uint2* __restrict__ pairs, int pair_cap, int* __restrict__ pair_count,
-                                                             int* __restrict__ cnt2, int partitioned) {
+                                                             int* __restrict__ cnt2, int partitioned, float fc) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int c = i < N ? cnt[i] : 0;
@@ -831,7 +1157,7 @@ __global__ void __launch_bounds__(256) knn_fast_prune_kernel(const float* __rest
 #pragma unroll
         for (int s = 1; s < KCAP; ++s)
             if (s == k1 - 1) kq = m[s];
-        thr = kq + 2.f * FAST_C * (xnorm[i] + __uint_as_float(maxn[0]));
+        thr = kq + 2.f * fc * (xnorm[i] + __uint_as_float(maxn[0]));
         for (int s = 0; s < c; ++s) ns += fv[s] <= thr;
     }
     int incl = ns;                                        // wave-inclusive prefix sum of the survivor counts
@@ -932,7 +1258,7 @@ __global__ void knn_fast_select_kernel(const float* __restrict__ cand, const int
 static bool knn_fast_enabled(int64_t N, int D) {
     static const int on = env_int("AM_KNN_FAST", 1);
     static const int min_rows = env_int("AM_KNN_FAST_MIN_ROWS", 32768);   // below: the exact symmetric kernel is faster (measured)
-    return on != 0 && N >= min_rows && D >= 32 && N < ((int64_t)1 << 31);
+    return on != 0 && N >= min_rows && D >= 32 && D <= FAST_MAX_DIM && N < ((int64_t)1 << 31);
 }
 
 struct KnnFastBuffers {           // on top of the symmetric path's KnnBuffers
@@ -974,7 +1300,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     // 1) filter bounds for every row from a sampled f16 pass of the general kernel (here a row's OWN entries are
     //    queued too, so - unlike in the exact symmetric kernel - every row needs a bound from the start)
     if (bounds_in != nullptr) {
-        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, bounds_in, thr, b.xn, N, maxn, 1.f);
+        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, bounds_in, thr, b.xn, N, maxn, fast_c(D));
         AM_LAUNCH_CHECK();
     } else {
         if ((rc = launch_knn_vt<KCAP, EV_FAST, false>(Xb, N, ldh, b.xn, Xb, N, ldh, b.xn, Dh, p.pre_chunks, p.pre_stride, b.partial,
@@ -982,7 +1308,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
             return rc;
         hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.partial, N, p.pre_chunks,
                            k1, 1, thr);
-        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, thr, thr, b.xn, N, maxn, 2.f);
+        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, thr, thr, b.xn, N, maxn, 2.f * fast_c(D));
         AM_LAUNCH_CHECK();
     }
     AM_HIP_TRY(hipMemsetAsync(b.cnt, 0, (size_t)(N + 1) * sizeof(int), st));
@@ -1003,7 +1329,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     clock_begin(AM_KERNEL_KNN, st);
     hipLaunchKernelGGL(knn_fast_kernel<KCAP>, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st, Xb, N, ldh, b.xn, thr,
                        Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, f.wgv, qcap, b.wgq_count,
-                       part, nparts);
+                       part, nparts, fast_c(D));
     clock_end(AM_KERNEL_KNN, st);
     AM_LAUNCH_CHECK();
     // 3) approximate values filed by row, 4) pruned against the row's own (k+1)-th smallest, 5) exact values of the
@@ -1014,7 +1340,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     const int64_t pair_cap64 = std::min<int64_t>((int64_t)nwg * qcap, (int64_t)1 << 30);
     const int pair_cap = (int)pair_cap64;
     hipLaunchKernelGGL(knn_fast_prune_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.cand, f.fidx, b.cnt, p.cap,
-                       N, k1, b.xn, maxn, b.wgq, pair_cap, f.pair_count, f.cnt2, out_lists != nullptr ? 1 : 0);
+                       N, k1, b.xn, maxn, b.wgq, pair_cap, f.pair_count, f.cnt2, out_lists != nullptr ? 1 : 0, fast_c(D));
     AM_LAUNCH_CHECK();
     clock_begin(AM_KERNEL_KNN_VERIFY, st);
     hipLaunchKernelGGL(knn_fast_verify_kernel, dim3(4096), dim3(256), 0, st, X, ld, b.xn, D, b.wgq, f.pair_count, pair_cap, b.cand,
