@@ -986,7 +986,10 @@ static int launch_knn_sym(const float* X, int64_t N, int64_t ld, const float* xn
 using namespace am;
 
 // ---- k-NN planning (shared by the workspace query and the launcher) ---------------------------------
+namespace am { static bool knn_fast_enabled(int64_t N, int D); }   // pairwise_fast.h
+constexpr int KNN_WIDE_MAX_KCAP = 11;                     // list registers beside 128 accumulators: k <= 10 on the wide engine
 struct KnnPlan {
+    int tile_rows;              // 128, or 256 when the f16 filter sweep runs on the wide engine
     bool sym;
     int kcap, nchunks;          // main pass
     int pre_chunks, pre_stride; // sampling pre-pass (symmetric path)
@@ -1003,6 +1006,7 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
     static const int stride = env_int("AM_KNN_SYM_STRIDE", 16);
     const int pre_windows = 0;
     KnnPlan p;
+    p.tile_rows = TB;
     p.kcap = kcap_for(k + 1);
     // the mirrored-candidate machinery costs per PAIR, the saved MFMA work scales with D: worth it for
     // wide embeddings and enough rows (measured crossover, tools/ab_knn.py)
@@ -1017,13 +1021,19 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
         p.nchunks = choose_chunks(N, M);
         return p;
     }
-    const int64_t T = ceil_div(N, TB);
-    const int64_t sample_tiles = ceil_div(T, stride);
+    // the f16 filter sweep of k <= 10 runs on the 256 x 256 engine: row blocks and column tiles of 256 rows
+    static const int wide_on = env_int("AM_KNN_WIDE", 1);
+    const bool wide = wide_on != 0 && knn_fast_enabled(N, D) && p.kcap <= KNN_WIDE_MAX_KCAP && N >= 4 * 256;
+    if (wide) p.tile_rows = 256;
+    const int64_t T = ceil_div(N, p.tile_rows);
+    const int64_t sample_tiles = ceil_div(ceil_div(N, TB), stride);          // the sampled pre-pass stays on the 128-row engine
     p.pre_chunks = (int)std::min<int64_t>(sample_tiles, 16);
     // A row's half-range (T/2+1 tiles) is cut into ~`slices` windows; a workgroup publishes the (k+1)-th
     // smallest of ITS window as the row's new bound, so windows much shorter than the pre-pass sample
     // (N/stride columns) would publish nothing useful -> at most 16 slices.
-    static const int target = env_int("AM_WG_TARGET", 8192);
+    static const int target128 = env_int("AM_WG_TARGET", 8192);
+    static const int target256 = env_int("AM_KNN_WIDE_WG_TARGET", 4096);      // one workgroup per CU there
+    const int target = wide ? target256 : target128;
     static const int max_slices = env_int("AM_KNN_SYM_MAX_SLICES", 16);
     int64_t slices = ceil_div(target, T);
     slices = std::max<int64_t>(slices, 4);
@@ -1046,7 +1056,7 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
     p.nchunks = p.nwin;                               // partial-list slots
     // expected survivors per workgroup when only the sample bound is known:
     //   pairs = 128 * win_tiles * 128, hit rate = (k+1) / (N / stride); keep 8x head-room
-    const double expect = 128.0 * 128.0 * p.win_tiles * (double)(k + 1) * stride / (double)N;
+    const double expect = (double)p.tile_rows * p.tile_rows * p.win_tiles * (double)(k + 1) * stride / (double)N;
     static const int qcap_env = env_int("AM_KNN_SYM_QCAP", 0);
     p.qcap = qcap_env > 0 ? qcap_env : (int)std::min(8192.0, std::max(256.0, 8.0 * expect));   // (the f16 filter path queues both directions)
     return p;

@@ -924,12 +924,13 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
 // FAST_BOTH is set (a pair that passes the own-row test of a and the mirrored test of b is evaluated once).
 constexpr unsigned FAST_BOTH = 0x80000000u;
 
-template <int KCAP>
+// Lane / TBX / MT: geometry of the engine underneath - LaneInfo, 128, 2 (tile_engine.h) or WLane, 256, 4 (wide_engine.h)
+template <int KCAP, class Lane = LaneInfo, int TBX = TB, int MT = 2>
 struct KnnFastEpilogue {
     const float* qnorm;
     const float* thr;
     int64_t n, pblock;
-    float* aux;                 // LDS [2][2][128] : |x_j|^2 and thr[j] of the tile
+    float* aux;                 // LDS [2][2][TBX] : |x_j|^2 and thr[j] of the tile
     uint2* wgq;
     float* wgv;                 // approximate value of each queued pair (pruning, knn_fast_prune_kernel)
     int* qn;
@@ -942,9 +943,9 @@ struct KnnFastEpilogue {
     bool rowok[2];
     float best[2][KCAP];        // ascending; the first KCAP - (k+1) slots are -inf pads, so best[KCAP-1] is the (k+1)-th smallest
     float aux_n, aux_t;
-    const LaneInfo& L;
+    const Lane& L;
 
-    __device__ __forceinline__ KnnFastEpilogue(const LaneInfo& l) : L(l) {}
+    __device__ __forceinline__ KnnFastEpilogue(const Lane& l) : L(l) {}
     __device__ __forceinline__ void push(int64_t a, int64_t b, bool both, float val) {
         const int slot = atomicAdd(qn, 1);
         if (slot < qcap) {
@@ -956,29 +957,29 @@ struct KnnFastEpilogue {
         }
     }
     __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
-        if (L.tid < TB) {
-            const int64_t j = qtile * TB + L.tid;
+        if (L.tid < TBX) {
+            const int64_t j = qtile * TBX + L.tid;
             aux_n = j < n ? qnorm[j] : INFINITY;
             aux_t = j < n ? __hip_atomic_load(thr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
         }
     }
     __device__ __forceinline__ void aux_commit(int t) {
-        if (L.tid < TB) {
-            aux[(t & 1) * 2 * TB + L.tid] = aux_n;
-            aux[(t & 1) * 2 * TB + TB + L.tid] = aux_t;
+        if (L.tid < TBX) {
+            aux[(t & 1) * 2 * TBX + L.tid] = aux_n;
+            aux[(t & 1) * 2 * TBX + TBX + L.tid] = aux_t;
         }
     }
-    __device__ __forceinline__ void finish(int t, int64_t qtile, f32x16 (&acc)[2][2]) {
-        const float* a = aux + (t & 1) * 2 * TB + L.wm * 64 + L.h * 4;
+    __device__ __forceinline__ void finish(int t, int64_t qtile, f32x16 (&acc)[MT][2]) {
+        const float* a = aux + (t & 1) * 2 * TBX + L.wm * (MT * 32) + L.h * 4;
         const bool mirror = qtile != pblock;                // the diagonal tile holds both directions itself
-        const int64_t jbase = qtile * TB + L.wm * 64 + L.h * 4;
+        const int64_t jbase = qtile * TBX + L.wm * (MT * 32) + L.h * 4;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             f32x4 yn[4], tq[4];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
-                tq[g4] = *reinterpret_cast<const f32x4*>(a + TB + mt * 32 + g4 * 8);
+                tq[g4] = *reinterpret_cast<const f32x4*>(a + TBX + mt * 32 + g4 * 8);
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -1084,6 +1085,85 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
             }
             const float kthv = m[KCAP - 1];
             const float bound = kthv + 2.f * fc * (xnorm[i] + nmax);     // >= 0, so its bit pattern orders like the value
+            atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
+        }
+    }
+}
+
+// The same sweep on the 256 x 256 f16 engine (wide_engine.h): row blocks and column tiles of 256 rows, 512 threads.
+constexpr size_t KNN_WIDE_LDS_BYTES = (WENGINE_LDS_WORDS + 4 * WTB) * sizeof(float) + 16;
+
+template <int KCAP>
+__global__ void __launch_bounds__(WTHREADS, 1)
+knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float* __restrict__ xnorm, float* thr, int Dh,
+                int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
+                int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
+                int* __restrict__ wgq_count, int part, int nparts, float fc) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const WLane L;
+    const int64_t T = (N + WTB - 1) / WTB;
+    const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
+    if (sw.ntiles == 0) {
+        if (L.tid == 0) wgq_count[blockIdx.x] = 0;
+        return;
+    }
+    const float nmax = __uint_as_float(maxn[0]);
+    KnnFastEpilogue<KCAP, WLane, WTB, 4> epi(L);
+    epi.qnorm = xnorm;
+    epi.thr = thr;
+    epi.n = N;
+    epi.pblock = sw.pb;
+    epi.aux = lds + WENGINE_LDS_WORDS;
+    epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
+    epi.wgv = wgv + (int64_t)blockIdx.x * qcap;
+    epi.qn = reinterpret_cast<int*>(lds + WENGINE_LDS_WORDS + 4 * WTB);
+    epi.qcap = qcap;
+    epi.cnt = cnt;
+    epi.cap = cap;
+    epi.dsc = half_unscale(maxn[2], maxn[2]);
+    if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int64_t i = sw.pb * WTB + L.wn * 64 + nt * 32 + L.r;
+        epi.prow[nt] = i;
+        epi.rowok[nt] = i < N;
+        epi.xn[nt] = i < N ? xnorm[i] : 0.f;
+        epi.e2[nt] = 2.f * fc * ((i < N ? xnorm[i] : 0.f) + nmax);
+        epi.flt[nt] = i < N ? __hip_atomic_load(thr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = s < KCAP - k1 ? -INFINITY : INFINITY;
+    }
+    wide_pipeline(Xb, N, ldh, WideTiles{sw.qa}, Xb, N, ldh, sw.pb * WTB, sw.ntiles, Dh, lds, L, epi);
+    float* mg = lds;                                   // [256][4][KCAP]: the engine's buffers are free now
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float* dst = mg + ((L.wn * 64 + nt * 32 + L.r) * 4 + (L.wm * 2 + L.h)) * KCAP;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
+    }
+    __syncthreads();
+    if (L.tid == 0) wgq_count[blockIdx.x] = min(*epi.qn, qcap);
+    if (L.tid < WTB) {
+        const int64_t i = sw.pb * WTB + L.tid;
+        if (i < N) {
+            const float* src = mg + L.tid * 4 * KCAP;
+            float m[KCAP];
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) m[s] = src[s];
+            for (int s = KCAP; s < 4 * KCAP; ++s)
+                if (src[s] > -INFINITY) list_insert<KCAP>(m, src[s]);
+            float* out = partial + ((int64_t)sw.W * N + i) * KCAP;
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) __hip_atomic_store(out + s, m[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int w2 = sw.W + 1; w2 < nwin; ++w2) {
+                const float* src2 = partial + ((int64_t)w2 * N + i) * KCAP;
+                for (int s = 0; s < KCAP; ++s) {
+                    const float v = __hip_atomic_load(src2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v > -INFINITY) list_insert<KCAP>(m, v);
+                }
+            }
+            const float kthv = m[KCAP - 1];
+            const float bound = kthv + 2.f * fc * (xnorm[i] + nmax);
             atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
         }
     }
@@ -1323,13 +1403,23 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     if (!attr_done) {
         AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_fast_kernel<KCAP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIRWISE_LDS_BYTES + 16));
+        if constexpr (KCAP <= KNN_WIDE_MAX_KCAP)
+            AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_wide_kernel<KCAP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)KNN_WIDE_LDS_BYTES));
         attr_done = true;
     }
     const int qcap = p.qcap;
     clock_begin(AM_KERNEL_KNN, st);
-    hipLaunchKernelGGL(knn_fast_kernel<KCAP>, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st, Xb, N, ldh, b.xn, thr,
-                       Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, f.wgv, qcap, b.wgq_count,
-                       part, nparts, fast_c(D));
+    if (p.tile_rows == WTB) {
+        if constexpr (KCAP <= KNN_WIDE_MAX_KCAP)
+            hipLaunchKernelGGL(knn_wide_kernel<KCAP>, dim3(nwg), dim3(WTHREADS), KNN_WIDE_LDS_BYTES, st, Xb, N, ldh, b.xn, thr, Dh,
+                               p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, f.wgv, qcap, b.wgq_count,
+                               part, nparts, fast_c(D));
+    } else {
+        hipLaunchKernelGGL(knn_fast_kernel<KCAP>, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st, Xb, N, ldh, b.xn,
+                           thr, Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, f.wgv, qcap,
+                           b.wgq_count, part, nparts, fast_c(D));
+    }
     clock_end(AM_KERNEL_KNN, st);
     AM_LAUNCH_CHECK();
     // 3) approximate values filed by row, 4) pruned against the row's own (k+1)-th smallest, 5) exact values of the
