@@ -348,6 +348,31 @@ def test_knn_filter_path_bit_identical_at_production_sizes(rows, dim, k):
     assert outs[0] == outs[1], outs
 
 
+@pytest.mark.parametrize("data", ["clustered", "scales", "dups", "lowrank", "unit"])
+def test_filter_paths_bit_identical_on_adversarial_data(data):
+    """The f16 filter + exact verification forms of both PRDC kernels (production path at these sizes) against the exact
+    f32 kernels on inputs chosen to stress the error bound and the queues: tight clusters (cancellation noise, clamps,
+    ties), row norms spread over four orders of magnitude with zero rows (and a candidate set 1000x smaller than the
+    reference), exact duplicates, a near-rank-4 set with a large offset, unit-norm rows.  Radii, counts and flags must
+    agree bit for bit (sha1 of the outputs)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ, AB_ROWS="33000", AB_DIM="128", AB_K="5", AB_REPS="1", AB_DATA=data, AB_WANT_MIN="1")
+    for tool, pattern, off in (("ab_knn.py", r"radii sha1 ([0-9a-f]+)", {"AM_KNN_FAST": "0"}),
+                               ("ab_cross.py", r"sha1 ([0-9a-f]+)", {"AM_PRDC_FAST": "0", "AM_KNN_FAST": "0"})):
+        outs = []
+        for extra in (off, {}):
+            res = subprocess.run([sys.executable, os.path.join(root, "tools", tool)], env=dict(base, **extra),
+                                 capture_output=True, text=True, timeout=900)
+            m = re.search(pattern, res.stdout)
+            assert m, res.stdout + res.stderr
+            outs.append(m.group(1))
+        assert outs[0] == outs[1], (tool, data, outs)
+
+
 # ----------------------------------------------------------------- PCA projection (n_pca)
 def test_incremental_pca_vs_reference(am, golden):
     """Device PCA against the reference's scikit-learn based IncrementalPCA: first fit, incremental update,

@@ -7,13 +7,21 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from audio_metrics_amd import hip_ops as ops  # noqa: E402
 
 n = int(os.environ.get("AB_ROWS", "100000"))
 d = int(os.environ.get("AB_DIM", "512"))
-gen = torch.Generator(device="cuda").manual_seed(0)
-x = torch.randn(n, d, generator=gen, device="cuda")
-y = torch.randn(n, d, generator=gen, device="cuda") * 1.05 + 0.05
+from ab_data import make  # noqa: E402
+kind = os.environ.get("AB_DATA", "randn")
+if kind == "randn":
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(n, d, generator=gen, device="cuda")
+    y = torch.randn(n, d, generator=gen, device="cuda") * 1.05 + 0.05
+else:
+    x, y = make(kind, n, d, 0), make(kind, n, d, 1)
+    if kind == "scales":
+        y = y * 1e-3                                    # the candidate set three orders of magnitude smaller than the reference
 rx, ry = ops.knn_radii(x, 5), ops.knn_radii(y, 5)
 want_min = os.environ.get("AB_WANT_MIN", "0") == "1"
 ops.prdc_counts(x, y, rx, ry, want_min)

@@ -1,0 +1,28 @@
+"""Synthetic inputs for the A/B tools: well-behaved and adversarial embedding sets (device tensors)."""
+import torch
+
+
+def make(kind, n, d, seed):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(n, d, generator=gen, device="cuda")
+    if kind == "randn":
+        return x
+    if kind == "clustered":            # tight clusters: d2 dominated by cancellation noise, clamps to 0, ties
+        centers = torch.randn(50, d, generator=gen, device="cuda")
+        lab = torch.randint(0, 50, (n,), generator=gen, device="cuda")
+        return centers[lab] + 1e-3 * x
+    if kind == "scales":               # row norms spread over four orders of magnitude, a few all-zero rows
+        s = 10.0 ** (torch.rand(n, 1, generator=gen, device="cuda") * 4 - 2)
+        x = x * s
+        x[::997] = 0.0
+        return x
+    if kind == "dups":                 # every row has an exact duplicate: zero radii, exact ties
+        h = n // 2
+        return torch.cat([x[:h], x[:n - h]])
+    if kind == "lowrank":              # a 4-dimensional subspace plus tiny noise, large common offset
+        basis = torch.randn(4, d, generator=gen, device="cuda")
+        return torch.randn(n, 4, generator=gen, device="cuda") @ basis + 1e-4 * x + 3.0
+    if kind == "unit":                 # CLAP-like: positive offset, L2-normalised rows
+        x = x + 0.5
+        return x / x.norm(dim=1, keepdim=True)
+    raise ValueError(kind)

@@ -10,14 +10,15 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from audio_metrics_amd import hip_ops as ops  # noqa: E402
 
 n = int(os.environ.get("AB_ROWS", "100000"))
 d = int(os.environ.get("AB_DIM", "512"))
 k = int(os.environ.get("AB_K", "5"))
 reps = int(os.environ.get("AB_REPS", "3"))
-gen = torch.Generator(device="cuda").manual_seed(0)
-x = torch.randn(n, d, generator=gen, device="cuda")
+from ab_data import make  # noqa: E402
+x = make(os.environ.get("AB_DATA", "randn"), n, d, 0)
 r = ops.knn_radii(x, k)
 torch.cuda.synchronize()
 ts = []
