@@ -1230,15 +1230,17 @@ extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const fl
     }
 }
 
-// which form am_knn_radii_f32 / am_prdc_counts_f32 take for a shape: 0 exact general, 1 exact symmetric, 2 f16 filter + verify
+// which form am_knn_radii_f32 / am_prdc_counts_f32 take for a shape: 0 exact general, 1 exact symmetric,
+// 2 f16 filter + verify on the 128 x 128 engine, 3 the same on the 256 x 256 engine
 extern "C" int am_knn_path(int64_t N, int64_t M, int D, int k, int self) {
     if (N < 1 || M < 1 || D < 1 || k < 1 || k > AM_MAX_K) return -1;
     const KnnPlan p = plan_knn(N, M, D, k, self != 0 && N == M);
-    return !p.sym ? 0 : (knn_fast_enabled(N, D) ? 2 : 1);
+    return !p.sym ? 0 : (knn_fast_enabled(N, D) ? (p.tile_rows == 256 ? 3 : 2) : 1);
 }
 extern "C" int am_prdc_path(int64_t Nr, int64_t Nc, int D) {
     if (Nr < 1 || Nc < 1 || D < 1) return -1;
-    return cross_fast_enabled(Nr, Nc, D) ? 2 : 0;
+    if (!cross_fast_enabled(Nr, Nc, D)) return 0;
+    return plan_cross_fast(Nr, Nc).wide ? 3 : 2;
 }
 
 // ---- partitioned symmetric k-NN (multi-GPU; every rank holds the full set) --------------------------

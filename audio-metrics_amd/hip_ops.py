@@ -241,12 +241,12 @@ def knn_radii(x, k, columns=None):
 
 # ---- partitioned symmetric k-NN (multi-GPU, every rank holds the full set) ----
 def knn_path(n, m, d, k, self_distance=True):
-    """0 exact general kernel, 1 exact symmetric kernel, 2 f16 filter + exact verification."""
+    """0 exact general kernel, 1 exact symmetric kernel, 2 / 3 f16 filter + exact verification (128 / 256-row engine)."""
     return int(_lib.load().am_knn_path(int(n), int(m), int(d), int(k), 1 if self_distance else 0))
 
 
 def prdc_path(n_ref, n_cand, d):
-    """0 exact kernel, 2 f16 filter + exact verification."""
+    """0 exact kernel, 2 / 3 f16 filter + exact verification (128 / 256-row engine)."""
     return int(_lib.load().am_prdc_path(int(n_ref), int(n_cand), int(d)))
 
 

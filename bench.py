@@ -167,15 +167,16 @@ def main():
     if rank == 0:
         rows_local = hi - lo
         # Which form of the two PRDC tile kernels ran (am_knn_path / am_prdc_path: 0 exact general, 1 exact symmetric,
-        # 2 f16 filter sweep + exact f32 verification of the undecided pairs).
+        # 2 / 3 f16 filter sweep (128 / 256-row engine) + exact f32 verification of the undecided pairs).
         part_form = "am_knn_sym_part_f32" in kern
         knn_entry = "am_knn_sym_part_f32" if part_form else "am_knn_radii_f32"
         knn_path = ops.knn_path(n, n, d, k) if (world == 1 or part_form) else 0
         cross_path = ops.prdc_path(rows_local, n, d)
-        knn_kernel = {0: "knn_partial_kernel", 1: "knn_sym_kernel", 2: "knn_fast_kernel"}[knn_path]
-        cross_kernel = {0: "prdc_cross_kernel", 2: "cross_fast_kernel"}[cross_path]
-        peak_of = {0: F32_MFMA_PEAK_TFLOPS, 1: F32_MFMA_PEAK_TFLOPS, 2: F16_MFMA_PEAK_TFLOPS}
-        mfma_of = {0: "v_mfma_f32_32x32x2_f32", 1: "v_mfma_f32_32x32x2_f32", 2: "v_mfma_f32_32x32x16_f16"}
+        knn_kernel = {0: "knn_partial_kernel", 1: "knn_sym_kernel", 2: "knn_fast_kernel", 3: "knn_wide_kernel"}[knn_path]
+        cross_kernel = {0: "prdc_cross_kernel", 2: "cross_fast_kernel", 3: "cross_wide_kernel"}[cross_path]
+        peak_of = {0: F32_MFMA_PEAK_TFLOPS, 1: F32_MFMA_PEAK_TFLOPS, 2: F16_MFMA_PEAK_TFLOPS, 3: F16_MFMA_PEAK_TFLOPS}
+        mfma_of = {0: "v_mfma_f32_32x32x2_f32", 1: "v_mfma_f32_32x32x2_f32", 2: "v_mfma_f32_32x32x16_f16",
+                   3: "v_mfma_f32_32x32x16_f16"}
 
         def per_launch(name, entry):
             launches, total = clocks[name]
@@ -193,7 +194,8 @@ def main():
         # pairs - self distances are bitwise symmetric - so they EXECUTE about half of it.
         t_tiles = (n + 127) // 128
         flop_alg = 2.0 * rows_local * n * d
-        knn_exec = ((t_tiles // 2 + 1) / t_tiles) if knn_path in (1, 2) else 1.0
+        t_tiles = (n + 255) // 256 if knn_path == 3 else t_tiles
+        knn_exec = ((t_tiles // 2 + 1) / t_tiles) if knn_path in (1, 2, 3) else 1.0
         try:                                                # PMC-derived HBM-side bytes per launch, recorded from profiles/
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 traffic_table = json.load(f).get("bytes_per_launch", {})
@@ -216,7 +218,7 @@ def main():
         main["note"] = (
             "achieved = algorithmic flops 2*rows*N*D of one launch / launch_ms (hipEvents around the kernel inside the "
             "library, on its stream; compare rocprofv3's average for it); peak = dense MFMA peak of the instruction the "
-            "kernel issues.  Path 2 kernels are FILTERS: they evaluate every pair on the f16 matrix cores with a proven "
+            "kernel issues.  Path 2/3 kernels are FILTERS: they evaluate every pair on the f16 matrix cores with a proven "
             "error bound and queue the few pairs the bound cannot decide; those are re-evaluated with the exact f32 fmaf "
             "chain (verify kernels, listed under other_kernels), so the outputs are bit-identical to the exact f32 "
             "kernels'.  executed_frac = executed flops / launch_ms / peak is the MFMA-pipe utilisation (the symmetric "
@@ -245,7 +247,7 @@ def main():
                        "n_ref": n, "n_cand": n, "dim": d, "nearest_k": k, "kd_subsets": 100, "kd_subset_size": 1000,
                        "sharding": f"rows/{world}",
                        "arithmetic": "results are the exact f32 values (bit-identical to the f32-MFMA kernels); the PRDC tile "
-                                     "kernels pre-filter on f16 MFMA with f32 accumulation where am_knn_path/am_prdc_path = 2"},
+                                     "kernels pre-filter on f16 MFMA with f32 accumulation where am_knn_path/am_prdc_path >= 2"},
             "roofline": main,
             "other_tile_kernel": other,
             "other_kernels": verify,

@@ -126,6 +126,10 @@ int am_kd_rbf_f32(const float* X, int64_t N1, int64_t ldx,
  *   caller passes its row shard as X and the gathered set as Y).
  *   Distances follow torch.cdist's matmul form  sqrt(max(|x|^2+|y|^2-2x.y, 0))
  *   in f32; no N x M matrix is materialised.  1 <= k <= AM_MAX_K, k+1 <= M.
+ *   Y == X with >= 32768 rows (32 <= D <= 4096) runs as a scaled-f16 MFMA FILTER sweep over half of the tile pairs
+ *   followed by an f32 evaluation - with the arithmetic of the exact kernel - of the pairs its error bound cannot
+ *   rule out (csrc/pairwise_fast.h): the radii are bit-identical to the exact kernels', which remain the path for
+ *   the other shapes and the automatic per-row fallback.
  * ------------------------------------------------------------------------- */
 size_t am_knn_workspace_bytes(int64_t N, int64_t M, int D, int k);
 int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx,
@@ -168,7 +172,7 @@ int am_knn_lists_finish_f32(const float* lists, int nparts, const float* X, int6
  *   Outputs are OVERWRITTEN.  am_prdc_reduce turns the first three into the four integer totals
  *   { #cols with count>0, #rows with any, sum of counts, #rows covered } (device int64[4]); the caller
  *   divides in f64.
- *   Large problems run as a bf16-MFMA FILTER pass that queues every pair whose membership its error bound
+ *   Large problems run as a scaled-f16 MFMA FILTER pass that queues every pair whose membership its error bound
  *   cannot decide, followed by an f32 evaluation of exactly those pairs with the arithmetic of the exact
  *   kernel (csrc/pairwise_fast.h): the outputs are bit-identical to the exact kernel's, which remains the
  *   path for small problems and the automatic fallback.  Asking for out_row_min adds the candidates of the
@@ -188,15 +192,16 @@ int am_prdc_reduce(const int32_t* col_count, int64_t Nc,
  * When enabled, the library brackets every launch of the two tile kernels with a hipEvent pair recorded on
  * the caller's stream, so a benchmark can report the duration of exactly that kernel (the figure
  * `rocprofv3 --kernel-trace --stats` prints for it) rather than of the whole entry point.
- *   AM_KERNEL_KNN          the k-NN tile kernel: knn_fast_kernel (f16 filter sweep) where the filter path runs,
+ *   AM_KERNEL_KNN          the k-NN tile kernel: knn_wide_kernel / knn_fast_kernel (f16 filter sweep) where the filter path runs,
  *                          else knn_sym_kernel, else knn_partial_kernel's main pass (sampled pre-passes not counted)
- *   AM_KERNEL_PRDC_CROSS   the membership tile kernel: cross_fast_kernel (f16 filter) or prdc_cross_kernel
+ *   AM_KERNEL_PRDC_CROSS   the membership tile kernel: cross_wide_kernel / cross_fast_kernel (f16 filter) or prdc_cross_kernel
  *   AM_KERNEL_KNN_VERIFY   knn_fast_verify_kernel (exact f32 values of the queued pairs)
  *   AM_KERNEL_PRDC_VERIFY  cross_verify_kernel
  * am_kernel_clock_read waits for the recorded launches, returns their count and summed duration in
  * milliseconds, and resets that kernel's record.  Disabled by default; no cost when disabled.
  * am_knn_path / am_prdc_path tell which form the library picks for a shape (0 = exact general kernel,
- * 1 = exact symmetric kernel (k-NN only), 2 = f16 filter + exact verification). */
+ * 1 = exact symmetric kernel (k-NN only), 2 = f16 filter + exact verification on the 128 x 128 engine,
+ * 3 = the same on the 256 x 256 f16 engine). */
 enum am_clocked_kernel { AM_KERNEL_KNN = 0, AM_KERNEL_PRDC_CROSS = 1, AM_KERNEL_KNN_VERIFY = 2, AM_KERNEL_PRDC_VERIFY = 3 };
 int am_kernel_clock_enable(int on);
 int am_kernel_clock_read(int kernel, int64_t* launches, double* total_ms);
