@@ -1012,7 +1012,8 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
     // wide embeddings and enough rows (measured crossover, tools/ab_knn.py)
     p.sym = self && N >= sym_min && D >= sym_min_dim && N >= 2 * TB;
     // survivors per row are ~ (k+1) * (1 + stride/2 ... ) with a heavy tail: 64 slots per list entry
-    p.cap = cap_env > 0 ? cap_env : std::max(256, 64 * (k + 1));
+    // (larger sets: the tail of the per-row counts grows with N - 1198 at 1M rows against 196 at 100k, k = 5)
+    p.cap = cap_env > 0 ? cap_env : std::max(256, 64 * (k + 1)) * (int)(1 + N / 300000);
     p.pre_stride = stride;
     p.pre_chunks = 1;
     p.qcap = 0;
@@ -1036,7 +1037,9 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
     const int target = wide ? target256 : target128;
     static const int max_slices = env_int("AM_KNN_SYM_MAX_SLICES", 16);
     int64_t slices = ceil_div(target, T);
-    slices = std::max<int64_t>(slices, 4);
+    // at least ~11 slices (22 windows) however large the set: the published bounds tighten window by window, and with
+    // few, long windows the queues and per-row buffers of the first ones flood (measured at 1M rows)
+    slices = std::max<int64_t>(slices, std::max<int64_t>(4, std::min<int64_t>(11, T / 8)));
     slices = std::min<int64_t>(slices, std::min<int64_t>(T / 2, max_slices));
     slices = std::max<int64_t>(slices, 1);
     const int64_t half = T / 2 + 1;
@@ -1058,7 +1061,7 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
     //   pairs = 128 * win_tiles * 128, hit rate = (k+1) / (N / stride); keep 8x head-room
     const double expect = (double)p.tile_rows * p.tile_rows * p.win_tiles * (double)(k + 1) * stride / (double)N;
     static const int qcap_env = env_int("AM_KNN_SYM_QCAP", 0);
-    p.qcap = qcap_env > 0 ? qcap_env : (int)std::min(8192.0, std::max(256.0, 8.0 * expect));   // (the f16 filter path queues both directions)
+    p.qcap = qcap_env > 0 ? qcap_env : (int)std::min(32768.0, std::max(256.0, 8.0 * expect));   // (the f16 filter path queues both directions)
     return p;
 }
 

@@ -923,6 +923,7 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
 // Queue entry: (row a | FAST_BOTH, row b): the exact value t(a, b) is filed under row a, and under row b as well when
 // FAST_BOTH is set (a pair that passes the own-row test of a and the mirrored test of b is evaluated once).
 constexpr unsigned FAST_BOTH = 0x80000000u;
+constexpr unsigned FAST_HOLE = 0xffffffffu;                                  // pair-list slot left unwritten (list full)
 
 // Lane / TBX / MT: geometry of the engine underneath - LaneInfo, 128, 2 (tile_engine.h) or WLane, 256, 4 (wide_engine.h)
 template <int KCAP, class Lane = LaneInfo, int TBX = TB, int MT = 2>
@@ -935,6 +936,10 @@ struct KnnFastEpilogue {
     float* wgv;                 // approximate value of each queued pair (pruning, knn_fast_prune_kernel)
     int* qn;
     int qcap;
+    uint2* ovq;                 // global spill queue for entries that do not fit their region
+    float* ovv;
+    int* ovn;
+    int ovcap;
     int* cnt;
     int cap;
     float dsc;                  // -2 / (operand scale)^2
@@ -951,9 +956,15 @@ struct KnnFastEpilogue {
         if (slot < qcap) {
             wgq[slot] = make_uint2((unsigned)a | (both ? FAST_BOTH : 0u), (unsigned)b);
             wgv[slot] = val;
-        } else {                                            // region full: the row(s) go to the exact fix-up kernel
-            atomicAdd(cnt + a, cap + 1);
-            if (both) atomicAdd(cnt + b, cap + 1);
+        } else {                                            // region full: spill to the global queue
+            const int s2 = atomicAdd(ovn, 1);
+            if (s2 < ovcap) {
+                ovq[s2] = make_uint2((unsigned)a | (both ? FAST_BOTH : 0u), (unsigned)b);
+                ovv[s2] = val;
+            } else {                                        // that one is full too: the row(s) go to the exact fix-up kernel
+                atomicAdd(cnt + a, cap + 1);
+                if (both) atomicAdd(cnt + b, cap + 1);
+            }
         }
     }
     __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
@@ -1018,7 +1029,8 @@ __global__ void __launch_bounds__(ENGINE_THREADS, 2) __attribute__((amdgpu_waves
 knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float* __restrict__ xnorm, float* thr, int Dh,
                 int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
                 int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
-                int* __restrict__ wgq_count, int part, int nparts, float fc) {
+                int* __restrict__ wgq_count, int part, int nparts, float fc, uint2* __restrict__ ovq, float* __restrict__ ovv,
+                int* __restrict__ ovn, int ovcap) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
     const int64_t T = (N + TB - 1) / TB;
@@ -1038,6 +1050,10 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     epi.wgv = wgv + (int64_t)blockIdx.x * qcap;
     epi.qn = reinterpret_cast<int*>(lds + ENGINE_LDS_FLOATS + 4 * TB);
     epi.qcap = qcap;
+    epi.ovq = ovq;
+    epi.ovv = ovv;
+    epi.ovn = ovn;
+    epi.ovcap = ovcap;
     epi.cnt = cnt;
     epi.cap = cap;
     epi.dsc = half_unscale(maxn[2], maxn[2]);
@@ -1098,7 +1114,8 @@ __global__ void __launch_bounds__(WTHREADS, 1)
 knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float* __restrict__ xnorm, float* thr, int Dh,
                 int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
                 int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
-                int* __restrict__ wgq_count, int part, int nparts, float fc) {
+                int* __restrict__ wgq_count, int part, int nparts, float fc, uint2* __restrict__ ovq, float* __restrict__ ovv,
+                int* __restrict__ ovn, int ovcap) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const WLane L;
     const int64_t T = (N + WTB - 1) / WTB;
@@ -1118,6 +1135,10 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     epi.wgv = wgv + (int64_t)blockIdx.x * qcap;
     epi.qn = reinterpret_cast<int*>(lds + WENGINE_LDS_WORDS + 4 * WTB);
     epi.qcap = qcap;
+    epi.ovq = ovq;
+    epi.ovv = ovv;
+    epi.ovn = ovn;
+    epi.ovcap = ovcap;
     epi.cnt = cnt;
     epi.cap = cap;
     epi.dsc = half_unscale(maxn[2], maxn[2]);
@@ -1209,6 +1230,19 @@ __global__ void __launch_bounds__(256) knn_fast_scatter_kernel(const uint2* __re
     }
 }
 
+__global__ void __launch_bounds__(256) knn_fast_scatter_spill_kernel(const uint2* __restrict__ ovq, const float* __restrict__ ovv,
+                                                                     const int* __restrict__ ovn, int ovcap,
+                                                                     float* __restrict__ fval, unsigned* __restrict__ fidx,
+                                                                     int* __restrict__ cnt, int cap) {
+    const int n = min(*ovn, ovcap);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const uint2 p = ovq[e];
+        const unsigned a = p.x & ~FAST_BOTH;
+        knn_file_approx(fval, fidx, cnt, cap, a, ovv[e], p.y);
+        if (p.x & FAST_BOTH) knn_file_approx(fval, fidx, cnt, cap, p.y, ovv[e], a);
+    }
+}
+
 // one thread per row; survivors are appended to pairs[] (one atomicAdd per wave)
 template <int KCAP>
 __global__ void __launch_bounds__(256) knn_fast_prune_kernel(const float* __restrict__ fval, const unsigned* __restrict__ fidx,
@@ -1251,11 +1285,13 @@ __global__ void __launch_bounds__(256) knn_fast_prune_kernel(const float* __rest
     if (lane == 63 && total > 0) base = atomicAdd(pair_count, total);
     base = __shfl(base, 63);
     if (i >= N) return;
-    if (bad || base + total > pair_cap) {                 // (pair list full: cannot happen, it is as large as the queue regions together)
-        cnt2[i] = cap + 1;                                // -> exact fix-up
+    int at = base + incl - ns;
+    if (bad || at + ns > pair_cap) {                      // overflow on the way here, or the pair list is full: -> exact fix-up
+        cnt2[i] = cap + 1;
+        // a range that straddles the end of the list is not written: mark its slots below the end as holes
+        if (!bad) for (int e = at; e < pair_cap; ++e) pairs[e] = make_uint2(FAST_HOLE, 0u);
         return;
     }
-    int at = base + incl - ns;
     const unsigned* fi = fidx + i * (int64_t)cap;
     for (int s = 0; s < c; ++s)
         if (fv[s] <= thr) pairs[at++] = make_uint2((unsigned)i, fi[s]);
@@ -1280,7 +1316,10 @@ __global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __res
     for (int64_t e0 = (int64_t)blockIdx.x * 512 + threadIdx.x; e0 < n; e0 += (int64_t)gridDim.x * 512) {
         const int64_t e1 = e0 + 256;
         const bool two = e1 < n;
-        const uint2 p0 = pairs[e0], p1 = two ? pairs[e1] : p0;
+        uint2 p0 = pairs[e0], p1 = two ? pairs[e1] : p0;
+        const bool hole0 = p0.x == FAST_HOLE, hole1 = p1.x == FAST_HOLE;
+        if (hole0) p0 = make_uint2(0u, 0u);
+        if (hole1) p1 = make_uint2(0u, 0u);
         const float *xa0 = X + (int64_t)p0.x * ld, *xb0 = X + (int64_t)p0.y * ld;
         const float *xa1 = X + (int64_t)p1.x * ld, *xb1 = X + (int64_t)p1.y * ld;
         float acc0 = 0.f, acc1 = 0.f;
@@ -1295,8 +1334,8 @@ __global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __res
                 acc1 = fmaf(z1[s], w1[s], acc1);
             }
         }
-        knn_file(cand, cnt2, cap, p0.x, fmaxf(fmaf(-2.f, acc0, xnorm[p0.x] + xnorm[p0.y]), 0.f));
-        if (two) knn_file(cand, cnt2, cap, p1.x, fmaxf(fmaf(-2.f, acc1, xnorm[p1.x] + xnorm[p1.y]), 0.f));
+        if (!hole0) knn_file(cand, cnt2, cap, p0.x, fmaxf(fmaf(-2.f, acc0, xnorm[p0.x] + xnorm[p0.y]), 0.f));
+        if (two && !hole1) knn_file(cand, cnt2, cap, p1.x, fmaxf(fmaf(-2.f, acc1, xnorm[p1.x] + xnorm[p1.y]), 0.f));
     }
 }
 
@@ -1347,7 +1386,11 @@ struct KnnFastBuffers {           // on top of the symmetric path's KnnBuffers
     float* wgv;                   // approximate values of the queue entries
     unsigned* fidx;               // partner of each filed entry
     int *cnt2, *pair_count;
+    uint2* ovq;                   // spill queue (entries past a region's capacity)
+    float* ovv;
+    int* ovn;
 };
+constexpr int KNN_FAST_OVCAP = 1 << 22;
 
 static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan& p) {
     KnnFastBuffers f;
@@ -1355,8 +1398,11 @@ static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan&
     f.maxn = c.take<unsigned>(4);
     f.wgv = c.take<float>((size_t)p.nwin * p.per_win * p.qcap);
     f.fidx = c.take<unsigned>((size_t)N * p.cap);
-    f.cnt2 = c.take<int>(N + 1);                  // [N] = pair counter
+    f.cnt2 = c.take<int>(N + 2);                  // [N] = pair counter, [N + 1] = spill counter
     f.pair_count = f.cnt2 ? f.cnt2 + N : nullptr;
+    f.ovn = f.cnt2 ? f.cnt2 + N + 1 : nullptr;
+    f.ovq = c.take<uint2>(KNN_FAST_OVCAP);
+    f.ovv = c.take<float>(KNN_FAST_OVCAP);
     return f;
 }
 
@@ -1392,7 +1438,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
         AM_LAUNCH_CHECK();
     }
     AM_HIP_TRY(hipMemsetAsync(b.cnt, 0, (size_t)(N + 1) * sizeof(int), st));
-    AM_HIP_TRY(hipMemsetAsync(f.cnt2, 0, (size_t)(N + 1) * sizeof(int), st));
+    AM_HIP_TRY(hipMemsetAsync(f.cnt2, 0, (size_t)(N + 2) * sizeof(int), st));
     // 2) symmetric filter sweep
     const unsigned nwg = (unsigned)p.nwin * (unsigned)p.per_win;
     const int64_t nlist = (int64_t)p.nwin * N * KCAP;
@@ -1409,16 +1455,17 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
         attr_done = true;
     }
     const int qcap = p.qcap;
+    static const int ovcap = std::max(0, std::min(env_int("AM_KNN_FAST_OVCAP", KNN_FAST_OVCAP), KNN_FAST_OVCAP));   // (tests shrink it)
     clock_begin(AM_KERNEL_KNN, st);
     if (p.tile_rows == WTB) {
         if constexpr (KCAP <= KNN_WIDE_MAX_KCAP)
             hipLaunchKernelGGL(knn_wide_kernel<KCAP>, dim3(nwg), dim3(WTHREADS), KNN_WIDE_LDS_BYTES, st, Xb, N, ldh, b.xn, thr, Dh,
                                p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, f.wgv, qcap, b.wgq_count,
-                               part, nparts, fast_c(D));
+                               part, nparts, fast_c(D), f.ovq, f.ovv, f.ovn, ovcap);
     } else {
         hipLaunchKernelGGL(knn_fast_kernel<KCAP>, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st, Xb, N, ldh, b.xn,
                            thr, Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, f.wgv, qcap,
-                           b.wgq_count, part, nparts, fast_c(D));
+                           b.wgq_count, part, nparts, fast_c(D), f.ovq, f.ovv, f.ovn, ovcap);
     }
     clock_end(AM_KERNEL_KNN, st);
     AM_LAUNCH_CHECK();
@@ -1426,6 +1473,8 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     //    survivors, 6) selection, 7) exact fix-up of overflowed rows
     hipLaunchKernelGGL(knn_fast_scatter_kernel, dim3(nwg), dim3(256), 0, st, b.wgq, f.wgv, qcap, b.wgq_count, b.cand, f.fidx, b.cnt,
                        p.cap);
+    hipLaunchKernelGGL(knn_fast_scatter_spill_kernel, dim3(256), dim3(256), 0, st, f.ovq, f.ovv, f.ovn, ovcap, b.cand, f.fidx,
+                       b.cnt, p.cap);
     AM_LAUNCH_CHECK();
     const int64_t pair_cap64 = std::min<int64_t>((int64_t)nwg * qcap, (int64_t)1 << 30);
     const int pair_cap = (int)pair_cap64;
@@ -1448,16 +1497,16 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     static const int debug = env_int("AM_FAST_DEBUG", 0);
     if (debug) {                                       // development aid: synchronises
         AM_HIP_TRY(hipStreamSynchronize(st));
-        std::vector<int> wc(nwg), cn(N + 1), c2(N + 1);
+        std::vector<int> wc(nwg), cn(N + 1), c2(N + 2);
         AM_HIP_TRY(hipMemcpy(wc.data(), b.wgq_count, nwg * sizeof(int), hipMemcpyDeviceToHost));
         AM_HIP_TRY(hipMemcpy(cn.data(), b.cnt, (N + 1) * sizeof(int), hipMemcpyDeviceToHost));
-        AM_HIP_TRY(hipMemcpy(c2.data(), f.cnt2, (N + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        AM_HIP_TRY(hipMemcpy(c2.data(), f.cnt2, (N + 2) * sizeof(int), hipMemcpyDeviceToHost));
         long long tot = 0, full = 0, ctot = 0, bad = 0;
         int wmax = 0, cmax = 0;
         for (int v : wc) { tot += v; full += (v >= qcap); wmax = std::max(wmax, v); }
         for (int64_t i = 0; i < N; ++i) { ctot += std::min(cn[i], p.cap); cmax = std::max(cmax, cn[i]); bad += c2[i] > p.cap; }
         fprintf(stderr, "[knn_fast] wgs=%u nwin=%d qcap=%d queued=%lld (max/wg %d, full regions %lld) filed=%lld max/row=%d "
-                        "pairs verified=%d rows to fix-up=%lld\n", nwg, p.nwin, qcap, tot, wmax, full, ctot, cmax, c2[N], bad);
+                        "pairs verified=%d spilled=%d rows to fix-up=%lld\n", nwg, p.nwin, qcap, tot, wmax, full, ctot, cmax, c2[N], c2[N + 1], bad);
     }
     return AM_OK;
 }

@@ -80,11 +80,11 @@ def test_sharded_evaluate_with_hip_kernels(n_ref, n_cand):
 
 
 @pytest.mark.parametrize("nparts,k,rows,path", [(2, 5, 9100, 1), (3, 10, 9100, 1), (8, 5, 9100, 1),
-                                                (2, 5, 33100, 2), (5, 10, 33100, 2)])
+                                                (2, 5, 33100, 3), (5, 10, 33100, 3)])
 def test_partitioned_symmetric_knn_bit_identical(nparts, k, rows, path):
     """The multi-GPU form of the symmetric k-NN, emulated on one GPU: every part computed in turn, lists
     stacked as the all-gather would, then merged - bit-identical to the single-GPU result.  9100 rows take the
-    exact symmetric kernel (path 1), 33100 rows the f16 filter sweep + exact verification (path 2)."""
+    exact symmetric kernel (path 1), 33100 rows the f16 filter sweep on the 256-row engine + exact verification (path 3)."""
     import numpy as np
     from audio_metrics_amd import hip_ops as ops
     x = torch.as_tensor(gi.randn(97, rows, 136)).to("cuda:0")

@@ -286,7 +286,8 @@ def test_knn_symmetric_path_bit_exact(am):
 def test_knn_symmetric_fallbacks_agree():
     """General kernel, symmetric kernel, symmetric kernel with a 2-slot candidate buffer (every row overflows
     -> exact fix-up kernel) and with a 16-entry workgroup queue (direct per-row pushes), and the f16 filter path
-    (plain, with overflowing candidate buffers, with overflowing queue regions) give identical bits.
+    (plain, with overflowing candidate buffers, with overflowing queue regions -> spill queue, with an overflowing spill
+    queue -> exact fix-up) give identical bits.
     The knobs are process-wide environment variables, hence subprocesses."""
     import os
     import re
@@ -297,7 +298,8 @@ def test_knn_symmetric_fallbacks_agree():
     outs = []
     fast = {"AM_KNN_FAST_MIN_ROWS": "1000"}           # the f16 filter + exact verification path (pairwise_fast.h)
     for extra in ({"AM_KNN_SYM_MIN_ROWS": "100000000"}, {}, {"AM_KNN_SYM_CAP": "2"}, {"AM_KNN_SYM_QCAP": "16"},
-                  fast, dict(fast, AM_KNN_SYM_CAP="2"), dict(fast, AM_KNN_SYM_QCAP="16")):
+                  fast, dict(fast, AM_KNN_SYM_CAP="2"), dict(fast, AM_KNN_SYM_QCAP="16"),
+                  dict(fast, AM_KNN_SYM_QCAP="16", AM_KNN_FAST_OVCAP="64")):
         res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_knn.py")], env=dict(base, **extra),
                              capture_output=True, text=True, timeout=600)
         m = re.search(r"radii sha1 ([0-9a-f]+)", res.stdout)
