@@ -285,7 +285,7 @@ constexpr int EV_LDS = 64;       // operands go global -> LDS directly (buffer_l
 constexpr int EV_F16 = 128;      // operands are f16 pairs viewed as f32 words (filter passes only)
 
 // LDS image of the LDS-direct variant: unpadded 128-B rows (a wave's buffer_load_dwordx4 ... lds writes 64 x 16 B
-// contiguously = 8 whole rows), 16-B chunks XOR-swizzled by (row & 7) so the MFMA fragment reads stay conflict-free.
+// contiguously = 8 whole rows), 16-B chunks XOR-swizzled by ((row >> 1) & 7) so the MFMA fragment reads stay conflict-free.
 constexpr int LDR = 32;
 constexpr int TILE_FLOATS_R = TB * LDR;
 constexpr int STAGE_FLOATS_R = 2 * TILE_FLOATS_R;
@@ -293,7 +293,7 @@ constexpr int STAGE_FLOATS_R = 2 * TILE_FLOATS_R;
 // float offset inside a slab row that staging thread `tid` fetches (its LDS slot is always tid & 7)
 template <bool DIRECT>
 __device__ __forceinline__ int staging_col(int tid) {
-    if constexpr (DIRECT) return (((tid & 7) ^ ((tid >> 3) & 7)) * 4);
+    if constexpr (DIRECT) return (((tid & 7) ^ ((tid >> 4) & 7)) * 4);      // slot ^ ((row >> 1) & 7), row = tid >> 3 (+32 q)
     else return (tid & 7) * 4;
 }
 
@@ -368,7 +368,7 @@ __device__ __forceinline__ void addr_pipeline_early(const QAddrFn& qaddr, const 
                                                     int64_t q_tiles_total, float* __restrict__ lds, const LaneInfo& L,
                                                     Epi& epi);
 
-template <class QAddrFn, class Epi>
+template <bool F16, class QAddrFn, class Epi>
 __device__ __forceinline__ void addr_pipeline_lds(const QAddrFn& qaddr, const TileAddr& paddr, int ntiles, int D,
                                                   float* __restrict__ lds, const LaneInfo& L, Epi& epi);
 
@@ -411,7 +411,7 @@ __device__ __forceinline__ void dense_pipeline_early(const float* __restrict__ Q
         __device__ __forceinline__ void aux_commit(int t) { e.aux_commit(t); }
         __device__ __forceinline__ void finish(int t, int64_t, f32x16 (&acc)[2][2]) { e.finish(t, at(t), acc); }
     } shim{epi, abs_tile};
-    if constexpr (DIRECT) addr_pipeline_lds(qaddr, pa, ntiles, D, lds, L, shim);
+    if constexpr (DIRECT) addr_pipeline_lds<(V & EV_F16) != 0>(qaddr, pa, ntiles, D, lds, L, shim);
     else addr_pipeline_early<V, KTAIL>(qaddr, pa, ntiles, D, 0, lds, L, shim);
 }
 
@@ -425,7 +425,7 @@ __device__ __forceinline__ void lds_direct_b128(const TileRsrc& r, float* lds_wa
                                              (int)soff, 0, 0);
 }
 
-template <class QAddrFn, class Epi>
+template <bool F16, class QAddrFn, class Epi>
 __device__ __forceinline__ void addr_pipeline_lds(const QAddrFn& qaddr, const TileAddr& paddr, int ntiles, int D,
                                                   float* __restrict__ lds, const LaneInfo& L, Epi& epi) {
     const int nk = D / BK;
@@ -450,8 +450,9 @@ __device__ __forceinline__ void addr_pipeline_lds(const QAddrFn& qaddr, const Ti
             qa = qaddr(ft);
         }
     };
-    // fragment addresses: logical 16-B chunk 2c+h of row r sits in slot (2c+h) ^ (r & 7)
-    const int sw = L.r & 7;
+    // fragment addresses: logical 16-B chunk 2c+h of row r sits in slot (2c+h) ^ ((r >> 1) & 7)  (a swizzle by r & 7
+    // ties the slot's parity to the row's and is 2-way bank-conflicted for the MFMA fragment pattern; see wide_engine.h)
+    const int sw = (L.r >> 1) & 7;
     int coff[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) coff[c] = ((2 * c + L.h) ^ sw) * 4;
@@ -480,14 +481,18 @@ __device__ __forceinline__ void addr_pipeline_lds(const QAddrFn& qaddr, const Ti
         if (g + 1 < G) issue(g + 1);
         if (last_k) epi.aux_issue(nt_, nt_);
         const float* st = lds + (g & 1) * STAGE_FLOATS_R;
+        auto mm = [&](const FragSet& f) {
+            if constexpr (F16) mfma_chunk_f16(f, acc);
+            else mfma_chunk(f, acc);
+        };
         FragSet f0 = frags(st, 0);
         FragSet f1 = frags(st, 1);
-        mfma_chunk(f0, acc);
+        mm(f0);
         f0 = frags(st, 2);
-        mfma_chunk(f1, acc);
+        mm(f1);
         f1 = frags(st, 3);
-        mfma_chunk(f0, acc);
-        mfma_chunk(f1, acc);
+        mm(f0);
+        mm(f1);
         if (last_k) {
             epi.finish(t, t, acc);
             zero_acc(acc);
