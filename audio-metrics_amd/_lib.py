@@ -27,6 +27,8 @@ SIGNATURES = {
     "am_kd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "am_kd_poly_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, _P, _P, c_int, c_int,
                                c_double, c_double, c_int, _P, _P, c_size_t, _P]),
+    "am_kd_draw_indices": (c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, c_int64, c_int64, c_int,
+                                   c_int, _P, _P]),
     "am_kd_rbf_workspace_bytes": (c_size_t, [c_int, c_int]),
     "am_kd_rbf_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, _P, _P, c_int, c_int, c_double, _P, _P,
                               c_size_t, _P]),

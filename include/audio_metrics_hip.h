@@ -111,6 +111,14 @@ int am_kd_poly_f32(const float* X, int64_t N1, int64_t ldx,
                    double gamma, double coef0, int degree,
                    double* out_mmd, void* ws, size_t ws_bytes, am_stream_t stream);
 
+/* The subset index table of A8 (host arithmetic, host pointers): idx1[S][m], idx2[S][m] exactly as the reference draws
+ * them - `rng = np.random.default_rng(seed)`; per subset `rng.choice(n1, m, replace=False)` then
+ * `rng.choice(n2, m, replace=False)` (kd.py:176,185-186) - from the PCG64 state numpy seeds (state and increment as two
+ * 64-bit halves each).  A restatement of numpy 2.x's Generator.choice (Floyd's algorithm / tail shuffle on Lemire-
+ * bounded 32-bit draws); 200 draws take ~1 ms instead of ~10 ms of Python-level calls. */
+int am_kd_draw_indices(uint64_t state_hi, uint64_t state_lo, uint64_t inc_hi, uint64_t inc_lo,
+                       int64_t n1, int64_t n2, int S, int m, int64_t* idx1, int64_t* idx2);
+
 /* RBF variant (reference kd.py:86-109, selected with kernel_type="rbf"): K = exp(-|x-y|^2 / (2 sigma^2)),
  * squared distances |x|^2 + |y|^2 - 2 x.y with f64 norms and the f32 matrix-core dot product. */
 size_t am_kd_rbf_workspace_bytes(int S, int m);

@@ -1,0 +1,37 @@
+"""The library's restatement of numpy's Generator.choice (am_kd_draw_indices, host arithmetic: runs without a GPU)
+against numpy itself - the draw order is part of the kernel-distance result (reference kd.py:176,185-186)."""
+import numpy as np
+import pytest
+
+import audio_metrics_amd as am
+from audio_metrics_amd.metrics import kd
+
+
+@pytest.mark.parametrize("n1,n2,subsets,m,seed", [
+    (100000, 100000, 100, 1000, 1234),      # BASELINE shape: Floyd's algorithm on both sets
+    (40000, 35000, 20, 1000, 1234),         # n > 10000 and m > n / 50: numpy's tail-shuffle branch
+    (10000, 10001, 9, 150, 5),              # either side of the 10000 threshold
+    (50049, 50050, 5, 1000, 3),             # either side of m > n // 50
+    (300, 257, 11, 128, 99),                # the reference's small-sample shrink (m = n_min // 2)
+    (2, 3, 4, 1, 9), (7, 7, 3, 7, 0),       # degenerate sizes; m == n
+    (100000, 50, 3, 50, 1),
+])
+def test_native_draw_equals_numpy(n1, n2, subsets, m, seed):
+    am._lib.load()
+    a1, a2 = kd.subset_indices_native(n1, n2, subsets, m, seed)
+    b1, b2 = kd.subset_indices_numpy(n1, n2, subsets, m, seed)
+    assert a1.dtype == np.int64 and a1.shape == (subsets, m)
+    assert np.array_equal(a1, b1) and np.array_equal(a2, b2)
+
+
+def test_dispatch_uses_the_native_draw_and_matches_the_golden_first_draws():
+    assert kd._native_draw_trusted()
+    i1, i2 = kd.subset_indices(100000, 100000, 2, 1000, 1234)
+    # first draws of default_rng(1234) at n = 100000
+    assert i1[0, :8].tolist() == [57642, 95775, 28099, 5584, 88853, 71821, 71685, 94582]
+    assert i2[0, :8].tolist() == [54893, 10548, 28828, 19561, 15832, 25262, 27971, 29690]
+
+
+def test_bad_arguments_are_rejected():
+    with pytest.raises(am._lib.HipLibraryError):
+        kd.subset_indices_native(10, 10, 2, 11, 0)          # m > n
