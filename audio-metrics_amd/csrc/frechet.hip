@@ -251,7 +251,12 @@ extern "C" int am_frechet_f64(const double* mu_x, const double* cov_x, const dou
                        g * g, D, Yb[0], Zb[0], state);
     AM_LAUNCH_CHECK();
     int cur = 0;
-    NsState host_state;
+    // read-backs go through a pinned per-thread buffer: a pageable destination makes the runtime pin and unpin the page
+    // around every copy
+    static thread_local void* pinned = nullptr;
+    if (pinned == nullptr) AM_HIP_TRY(hipHostMalloc(&pinned, 256, hipHostMallocDefault));
+    NsState& host_state = *static_cast<NsState*>(pinned);
+    double* out5 = reinterpret_cast<double*>(static_cast<char*>(pinned) + 128);
     host_state.done = 0;
     for (int it = 0; it < max_iter; ++it) {
         hipLaunchKernelGGL(gemm_f64_kernel<MODE_NS_T>, grid1, blk, 0, st, GemmJob{Zb[cur], Yb[cur], T}, none, D,
@@ -276,8 +281,7 @@ extern "C" int am_frechet_f64(const double* mu_x, const double* cov_x, const dou
     }
     hipLaunchKernelGGL(fd_finish_kernel, dim3(1), blk, 0, st, mu_x, cov_x, mu_y, cov_y, D, (const NsState*)state, out_dev);
     AM_LAUNCH_CHECK();
-    double out5[5];
-    AM_HIP_TRY(hipMemcpyAsync(out5, out_dev, sizeof(out5), hipMemcpyDeviceToHost, st));
+    AM_HIP_TRY(hipMemcpyAsync(out5, out_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
     AM_HIP_TRY(hipStreamSynchronize(st));
     for (int i = 0; i < 4; ++i) out_host[i] = out5[i];
     AM_REQUIRE((int)out5[4] != 4, AM_ERR_NO_CONVERGENCE, "non-finite covariance product or trace in Newton-Schulz");

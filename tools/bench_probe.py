@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Development aid: per-step wall time of back-to-back evaluate_sharded calls (sporadic stalls show as outliers)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audio_metrics_amd.distributed import evaluate_sharded
+n = int(os.environ.get("AB_ROWS", "20000")); d = 512
+gen = torch.Generator(device="cuda").manual_seed(0)
+ref = torch.randn(n, d, generator=gen, device="cuda"); cand = torch.randn(n, d, generator=gen, device="cuda") * 1.05 + 0.05
+metrics = tuple(os.environ.get("AB_METRICS", "fad,kd,prdc").split(","))
+ts = []
+for _ in range(30):
+    t0 = time.perf_counter(); r = evaluate_sharded(ref, cand, metrics=metrics, nearest_k=5); ts.append(round((time.perf_counter() - t0) * 1e3, 1))
+print(metrics, ts, r)
