@@ -27,14 +27,9 @@ import torch.distributed as dist
 from .metrics.kd import subset_indices, KID_SUBSETS, KID_SUBSET_SIZE, KID_DEGREE, KID_COEF0
 
 
-class _NoEvent:
-    def record(self):
-        pass
-
-
-def _plain_stage(array, dev):
-    """Stand-in for hip_ops.stage_host_array when the compute object is a CPU stand-in (tests)."""
-    return torch.as_tensor(np.ascontiguousarray(array)), _NoEvent()
+def _plain_upload(array, dev):
+    """Stand-in for hip_ops.upload_host_array when the compute object is a CPU stand-in (tests)."""
+    return torch.as_tensor(np.ascontiguousarray(array))
 
 
 def _world(group):
@@ -153,12 +148,9 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
         idx1, idx2 = subset_indices(n_cand, n_ref, kid_subsets, m, rng_seed)     # features_1 = candidate
         mmds = torch.zeros(kid_subsets, dtype=torch.float64, device=dev)
         if rank < kid_subsets:                                 # this rank's subsets: rank, rank + world, ...
-            stage = getattr(ops, "stage_host_array", None) or _plain_stage
-            h1, e1 = stage(idx1[rank::world], dev)             # pinned host tables the kernel reads in place (no H2D copy)
-            h2, e2 = stage(idx2[rank::world], dev)
-            part = ops.kd_poly(cand_full, ref_full, h1, h2, 1.0 / d, KID_COEF0, KID_DEGREE)
-            e1.record()
-            e2.record()
+            upload = getattr(ops, "upload_host_array", None) or _plain_upload
+            part = ops.kd_poly(cand_full, ref_full, upload(idx1[rank::world], dev), upload(idx2[rank::world], dev),
+                               1.0 / d, KID_COEF0, KID_DEGREE)
             mmds[rank::world] = part
         _all_reduce(mmds, world, group)
         kd_pending = mmds

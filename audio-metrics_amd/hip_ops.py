@@ -23,61 +23,37 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
-_STAGING = {}          # (dtype, numel) -> [_Staged]
+_SIDE_STREAMS = {}
 
 
-class _NoEvent:
-    def record(self):
-        pass
-
-
-class _Staged:
-    """One pinned staging buffer: handed out (busy) until its consumer has been launched (record()), reusable once that
-    launch has completed on the device (event.query())."""
-
-    def __init__(self, numel, dtype):
-        self.host = torch.empty(numel, dtype=dtype).pin_memory()
-        self.event = torch.cuda.Event()
-        self.busy = False
-
-    def free(self):
-        return not self.busy and self.event.query()
-
-    def record(self):
-        self.event.record()
-        self.busy = False
-
-
-def stage_host_array(array, device):
-    """Host array -> pinned host tensor the kernels read IN PLACE (device-mapped host memory), plus the handle whose
-    record() the caller invokes after launching the kernel that consumes it.  No H2D copy: on this platform a
-    host-to-device copy of a few hundred KB through the DMA engine stalls for 75-100 ms every few calls (measured: the
-    2 x 800 KB kernel-distance index tables turned a 40 ms evaluate into a 115 ms one every fifth call at 100k rows),
-    and allocating pinned memory per call (`Tensor.pin_memory()`) has the same problem through hipHostMalloc /
-    hipHostFree.  The index tables are read once per gathered row, so reading them over the host link costs nothing
-    measurable.  Buffers are kept and reused once the launch that consumed them has completed."""
+def upload_host_array(array, device):
+    """Host array -> device tensor usable on the current stream, without blocking the host behind the work already
+    queued there: the (pageable, host-synchronous) copy is issued on an otherwise idle side stream and the current
+    stream waits for it on the device.  Pinned host memory is deliberately NOT used: on this platform both
+    `Tensor.pin_memory()` per call and kernels reading a pooled pinned buffer in place stall the host for 75-100 ms
+    every few calls (measured on the 2 x 800 KB kernel-distance index tables: a 10 ms evaluate became a 90 ms one every
+    third call), while pageable copies of the same data never did."""
     import numpy as np
     t = torch.as_tensor(np.ascontiguousarray(array))
     if getattr(device, "type", "cpu") != "cuda":
-        return t, _NoEvent()
-    pool = _STAGING.setdefault((t.dtype, t.numel()), [])
-    for entry in pool:
-        if entry.free():
-            break
-    else:
-        entry = _Staged(t.numel(), t.dtype)
-        pool.append(entry)
-    entry.busy = True
-    entry.host.copy_(t.reshape(-1))
-    return entry.host.view(t.shape), entry
+        return t
+    main = torch.cuda.current_stream(device)
+    side = _SIDE_STREAMS.get(device.index)
+    if side is None:
+        side = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device)
+    with torch.cuda.stream(side):
+        d = t.to(device)
+    done = torch.cuda.Event()
+    done.record(side)
+    main.wait_event(done)
+    d.record_stream(main)
+    return d
 
 
 def _index_table(t, name):
-    """int64 index table: a device tensor, or a pinned host tensor (read in place by the kernel)."""
-    if not isinstance(t, torch.Tensor) or not (t.is_cuda or t.is_pinned()):
-        raise _lib.HipLibraryError(f"{name} must be a device tensor or a pinned host tensor")
-    return t.to(torch.int64).contiguous() if t.is_cuda else (t if t.dtype == torch.int64 and t.is_contiguous() else
-                                                              t.to(torch.int64).contiguous().pin_memory())
+    """int64 [S, m] index table on the device."""
+    _require_cuda(t, name)
+    return t.to(torch.int64).contiguous()
 
 
 class KernelTimer:

@@ -120,14 +120,11 @@ def kid_features_to_metric(features_1, features_2, **kwargs):
     idx1, idx2 = subset_indices(n_samples_1, n_samples_2, kid_subsets, kid_subset_size,
                                 kwargs.get("rng_seed", 1234))
     dev = features_1.device
-    h1, e1 = ops.stage_host_array(idx1, dev)      # pinned host tables the kernel reads in place (no H2D copy)
-    h2, e2 = ops.stage_host_array(idx2, dev)
+    d1, d2 = torch.as_tensor(idx1).to(dev), torch.as_tensor(idx2).to(dev)
     if kernel_type == "rbf":          # kd.py:136-140
-        mmds = ops.kd_rbf(features_1, features_2, h1, h2, kwargs.get("kid_sigma", KID_SIGMA))
+        mmds = ops.kd_rbf(features_1, features_2, d1, d2, kwargs.get("kid_sigma", KID_SIGMA))
     else:
-        mmds = ops.kd_poly(features_1, features_2, h1, h2, gamma, kwargs.get("kid_coef0", KID_COEF0),
+        mmds = ops.kd_poly(features_1, features_2, d1, d2, gamma, kwargs.get("kid_coef0", KID_COEF0),
                            kwargs.get("kid_degree", KID_DEGREE))
-    e1.record()
-    e2.record()
     mmds = mmds.cpu().numpy()
     return {KEY_METRIC_KID_MEAN: float(np.mean(mmds)), KEY_METRIC_KID_STD: float(np.std(mmds))}

@@ -7,8 +7,9 @@ from audio_metrics_amd.distributed import evaluate_sharded
 n = int(os.environ.get("AB_ROWS", "20000")); d = 512
 gen = torch.Generator(device="cuda").manual_seed(0)
 ref = torch.randn(n, d, generator=gen, device="cuda"); cand = torch.randn(n, d, generator=gen, device="cuda") * 1.05 + 0.05
-metrics = tuple(os.environ.get("AB_METRICS", "fad,kd,prdc").split(","))
-ts = []
-for _ in range(30):
-    t0 = time.perf_counter(); r = evaluate_sharded(ref, cand, metrics=metrics, nearest_k=5); ts.append(round((time.perf_counter() - t0) * 1e3, 1))
-print(metrics, ts, r)
+for combo in os.environ.get("AB_COMBOS", "fad,kd,prdc").split(";"):
+    metrics = tuple(combo.split(","))
+    ts = []
+    for _ in range(30):
+        t0 = time.perf_counter(); r = evaluate_sharded(ref, cand, metrics=metrics, nearest_k=5); ts.append(round((time.perf_counter() - t0) * 1e3, 1))
+    print(metrics, ts, r.get("kernel_distance_mean"), flush=True)
