@@ -767,6 +767,9 @@ static CrossFastPlan plan_cross_fast(int64_t Nr, int64_t Nc) {
         const int64_t rbw = ceil_div(Nr, WTB), qtw = ceil_div(Nc, WTB);
         int64_t want = std::max<int64_t>(ceil_div(wtarget, rbw), 1);
         want = ceil_div(want, grp_chunks) * grp_chunks;
+        // at least ~8 column tiles per workgroup (row shards of a multi-GPU run would otherwise get 3-tile work items
+        // whose pipeline fill and epilogue set-up dominate)
+        want = std::min<int64_t>(want, std::max<int64_t>(qtw / 8 / grp_chunks * grp_chunks, grp_chunks));
         want = std::min<int64_t>(want, std::max<int64_t>(qtw / grp_chunks * grp_chunks, 1));
         want = std::min<int64_t>(want, qtw);
         p.nchunks = (int)want;

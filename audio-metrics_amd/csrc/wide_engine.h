@@ -138,6 +138,17 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, f.p[n]), acc[m][n], 0, 0, 0);
         }
     };
+    // first chunk of a tile: C = 0 as an inline constant instead of 128 register clears per tile
+    auto mm_first = [&](const Frags& f) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f16x8 a = __builtin_bit_cast(f16x8, f.q[m]);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, f.p[n]), zero, 0, 0, 0);
+        }
+    };
 
     issue(0);
     epi.aux_issue(0, qtile_of(0));
@@ -155,7 +166,8 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
         const float* st = lds + (g & 1) * WSTAGE_WORDS;
         Frags f0 = frags(st, 0);
         Frags f1 = frags(st, 1);
-        mm(f0);
+        if (kt == 0) mm_first(f0);
+        else mm(f0);
         f0 = frags(st, 2);
         mm(f1);
         f1 = frags(st, 3);
@@ -163,7 +175,6 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
         mm(f1);
         if (last_k) {
             epi.finish(t, qtile_of(t), acc);
-            wide_zero(acc);
             epi.aux_commit(nt_);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);         // the slab of stage g+1 has landed in LDS
