@@ -747,7 +747,6 @@ struct CrossFastPlan {
     int nchunks, pre_chunks, qstride, qcap, ovcap, grp_rows;
     int64_t blocks;
     bool wide;                  // main pass on the 256 x 256 engine (cross_wide_kernel)
-    int pre_nchunks_unused;
 };
 
 static CrossFastPlan plan_cross_fast(int64_t Nr, int64_t Nc) {
@@ -758,7 +757,6 @@ static CrossFastPlan plan_cross_fast(int64_t Nr, int64_t Nc) {
     p.blocks = p.grp_rows > 0 ? cross_grouped_blocks(ceil_div(Nr, TB), p.nchunks, p.grp_rows) : ceil_div(Nr, TB) * p.nchunks;
     static const int wide = env_int("AM_FAST_WIDE", 1);
     p.wide = wide != 0;
-    p.pre_nchunks_unused = 0;
     if (p.wide) {
         static const int wgrp = env_int("AM_WIDE_GROUP_ROWS", 8);
         static const int wtarget = env_int("AM_WIDE_WG_TARGET", 6144);               // ~24 rounds of 256 CUs x 1 workgroup
@@ -1300,7 +1298,7 @@ __global__ void __launch_bounds__(256) knn_fast_prune_kernel(const float* __rest
         if (fv[s] <= thr) pairs[at++] = make_uint2((unsigned)i, fi[s]);
 }
 
-// One pair per lane, two pairs per thread interleaved for ILP; each lane walks its two rows with the exact engine's
+// One pair per lane; each lane walks its two rows with the exact engine's
 // fmaf chain (t(a,b) == t(b,a) bit for bit: products commute and the inner order is the same).  Consecutive pairs
 // share their first row (the list is written row by row), so those reads coalesce; the partner rows come from L2 /
 // Infinity Cache.
@@ -1316,29 +1314,40 @@ __global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __res
                                                               int cap) {
     const int n = min(*pair_count, pair_cap);
     const int dp = (D + 7) / 8 * 8;
-    for (int64_t e0 = (int64_t)blockIdx.x * 512 + threadIdx.x; e0 < n; e0 += (int64_t)gridDim.x * 512) {
-        const int64_t e1 = e0 + 256;
-        const bool two = e1 < n;
-        uint2 p0 = pairs[e0], p1 = two ? pairs[e1] : p0;
-        const bool hole0 = p0.x == FAST_HOLE, hole1 = p1.x == FAST_HOLE;
-        if (hole0) p0 = make_uint2(0u, 0u);
-        if (hole1) p1 = make_uint2(0u, 0u);
-        const float *xa0 = X + (int64_t)p0.x * ld, *xb0 = X + (int64_t)p0.y * ld;
-        const float *xa1 = X + (int64_t)p1.x * ld, *xb1 = X + (int64_t)p1.y * ld;
-        float acc0 = 0.f, acc1 = 0.f;
-        for (int c = 0; c < dp; c += 8) {
-            const f32x4 u0 = load_k4(xa0, c, D), u1 = load_k4(xa0, c + 4, D), v0 = load_k4(xb0, c, D), v1 = load_k4(xb0, c + 4, D);
-            const f32x4 w0 = load_k4(xa1, c, D), w1 = load_k4(xa1, c + 4, D), z0 = load_k4(xb1, c, D), z1 = load_k4(xb1, c + 4, D);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        uint2 p = pairs[e];
+        const bool hole = p.x == FAST_HOLE;
+        if (hole) p = make_uint2(0u, 0u);
+        const float *xa = X + (int64_t)p.x * ld, *xb = X + (int64_t)p.y * ld;
+        float acc = 0.f;
+        // one pair per lane; whole 128-byte lines of both rows per step (16 independent loads in flight), then the 32
+        // products in the engine's order
+        int c = 0;
+        for (; c + 32 <= dp && c + 32 <= D; c += 32) {
+            f32x4 u[8], v[8];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc0 = fmaf(v0[s], u0[s], acc0);
-                acc1 = fmaf(z0[s], w0[s], acc1);
-                acc0 = fmaf(v1[s], u1[s], acc0);
-                acc1 = fmaf(z1[s], w1[s], acc1);
+            for (int q = 0; q < 8; ++q) {
+                u[q] = *reinterpret_cast<const f32x4*>(xa + c + 4 * q);
+                v[q] = *reinterpret_cast<const f32x4*>(xb + c + 4 * q);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc = fmaf(v[q][s], u[q][s], acc);
+                    acc = fmaf(v[q + 1][s], u[q + 1][s], acc);
+                }
             }
         }
-        if (!hole0) knn_file(cand, cnt2, cap, p0.x, fmaxf(fmaf(-2.f, acc0, xnorm[p0.x] + xnorm[p0.y]), 0.f));
-        if (two && !hole1) knn_file(cand, cnt2, cap, p1.x, fmaxf(fmaf(-2.f, acc1, xnorm[p1.x] + xnorm[p1.y]), 0.f));
+        for (; c < dp; c += 8) {                          // tail (D % 32 != 0)
+            const f32x4 u0 = load_k4(xa, c, D), u1 = load_k4(xa, c + 4, D), v0 = load_k4(xb, c, D), v1 = load_k4(xb, c + 4, D);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc = fmaf(v0[s], u0[s], acc);
+                acc = fmaf(v1[s], u1[s], acc);
+            }
+        }
+        if (!hole) knn_file(cand, cnt2, cap, p.x, fmaxf(fmaf(-2.f, acc, xnorm[p.x] + xnorm[p.y]), 0.f));
     }
 }
 
