@@ -43,16 +43,26 @@ static inline int64_t half_ld(int D) { return (int64_t)(D + FAST_LDH_ALIGN - 1) 
 // largest |element| of a matrix through its bit pattern (sign cleared; NaN/inf sort above every finite value)
 __global__ void __launch_bounds__(256) maxabs_bits_kernel(const float* __restrict__ X, int64_t N, int64_t ld, int D,
                                                           unsigned* __restrict__ out) {
-    const int64_t dq = (D + 3) / 4;
+    // one wave per row at a time (the access pattern of row_sqnorm_kernel: no index divisions, whole rows coalesced)
+    const int lane = threadIdx.x & 63;
     unsigned m = 0u;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < N * dq; idx += (int64_t)gridDim.x * 256) {
-        const f32x4 v = load_k4(X + (idx / dq) * ld, (int)(idx % dq) * 4, D);
-        m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
-        m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < N; row += (int64_t)gridDim.x * 4) {
+        const float* x = X + row * ld;
+        for (int k = lane * 4; k < D; k += 256) {
+            const f32x4 v = load_k4(x, k, D);
+            m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+            m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+    __shared__ unsigned wave_max[4];                       // one atomic per workgroup: the target is a single address
+    if (lane == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+        if (m != 0u) atomicMax(out, m);
+    }
 }
 
 // ---- scaled f32 -> f16 copy (RNE), zero-padded to ldh columns; one thread per 8 elements
@@ -89,7 +99,8 @@ static int launch_to_half(const float* X, int64_t N, int64_t ld, int D, const fl
                           uint16_t* Xh, hipStream_t st) {
     const int64_t ldh = half_ld(D);
     hipLaunchKernelGGL(max_bits_kernel, dim3(256), dim3(256), 0, st, norms, N, stats + which);
-    hipLaunchKernelGGL(maxabs_bits_kernel, dim3(1024), dim3(256), 0, st, X, N, ld, D, stats + 2 + which);
+    hipLaunchKernelGGL(maxabs_bits_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(N, 4), 1024)), dim3(256), 0, st, X, N, ld, D,
+                       stats + 2 + which);
     const int64_t threads = N * (ldh / 8);
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, X, N, ld, D, ldh,
                        stats + 2 + which, Xh);
