@@ -375,6 +375,25 @@ def test_filter_paths_bit_identical_on_adversarial_data(data):
         assert outs[0] == outs[1], (tool, data, outs)
 
 
+@pytest.mark.parametrize("n_ref,n_cand", [(70000, 300), (300, 70000), (33000, 1500)])
+def test_membership_filter_unequal_sets_bit_exact(am, n_ref, n_cand):
+    """Very unequal set sizes through the 256-row filter engine (one column chunk / two row blocks / ragged edges):
+    counts, flags and row minima equal the C model bit for bit (radii chosen so that a few percent of the pairs count)."""
+    from oracle import exact
+    assert am.hip_ops.prdc_path(n_ref, n_cand, 64) == 3
+    ref, cand = gi.pair("shifted", 700 + n_cand % 97, n_ref, n_cand, 64)
+    rng = np.random.default_rng(5)
+    r_ref = (9.0 + rng.random(n_ref) * 2.5).astype(np.float32)           # around the bulk of the distances (~11.5)
+    r_cand = (9.0 + rng.random(n_cand) * 2.5).astype(np.float32)
+    col, rany, rcov, rmin = am.hip_ops.prdc_counts(dev(ref), dev(cand), dev(r_ref), dev(r_cand), want_min=True)
+    ecol, eany, emin = exact.prdc_counts(ref, cand, r_ref, r_cand)
+    assert int(ecol.sum()) > 1000
+    assert np.array_equal(col.cpu().numpy(), ecol)
+    assert np.array_equal(rany.cpu().numpy(), eany)
+    assert np.array_equal(rmin.cpu().numpy().view(np.uint32), emin.view(np.uint32))
+    assert np.array_equal(rcov.cpu().numpy().astype(bool), emin < r_ref)
+
+
 # ----------------------------------------------------------------- PCA projection (n_pca)
 def test_incremental_pca_vs_reference(am, golden):
     """Device PCA against the reference's scikit-learn based IncrementalPCA: first fit, incremental update,
