@@ -22,7 +22,8 @@ else:
     x, y = make(kind, n, d, 0), make(kind, n, d, 1)
     if kind == "scales":
         y = y * 1e-3                                    # the candidate set three orders of magnitude smaller than the reference
-rx, ry = ops.knn_radii(x, 5), ops.knn_radii(y, 5)
+kk = int(os.environ.get("AB_K", "5"))
+rx, ry = ops.knn_radii(x, kk), ops.knn_radii(y, kk)
 want_min = os.environ.get("AB_WANT_MIN", "0") == "1"
 ops.prdc_counts(x, y, rx, ry, want_min)
 torch.cuda.synchronize()
