@@ -5,6 +5,7 @@ computation below is a call into libaudio_metrics_hip.so on torch's current
 HIP stream.  There is no CPU path: CPU tensors are rejected.
 """
 import ctypes
+import os
 
 import torch
 
@@ -214,6 +215,56 @@ def frechet(mu_x, cov_x, mu_y, cov_y, max_iter=64, tol=1e-13):
     _call(lib, "am_frechet_f64", _ptr(mu_x), _ptr(cov_x), _ptr(mu_y), _ptr(cov_y), d, int(max_iter), float(tol),
                                   ctypes.cast(out, ctypes.c_void_p), _ptr(ws), nb, _stream())
     return dict(fd=out[0], tr_sqrt=out[1], iters=int(out[2]), resid=out[3])
+
+
+class _FrechetJob:
+    """am_frechet_f64 running on a side stream from a helper thread (see frechet_async)."""
+
+    def __init__(self, args, device):
+        import threading
+        self._out = None
+        self._err = None
+        main = torch.cuda.current_stream(device)
+        self._side = _SIDE_STREAMS.get(("fad", device.index))
+        if self._side is None:
+            self._side = _SIDE_STREAMS[("fad", device.index)] = torch.cuda.Stream(device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._side.wait_event(ready)                       # the statistics were produced on the caller's stream
+        for t in args:
+            if isinstance(t, torch.Tensor):
+                t.record_stream(self._side)
+
+        def run():
+            try:
+                torch.cuda.set_device(device)
+                with torch.cuda.stream(self._side):
+                    self._out = frechet(*args)
+            except BaseException as e:                     # re-raised in result()
+                self._err = e
+
+        self._thread = threading.Thread(target=run, name="am-frechet", daemon=True)
+        self._thread.start()
+
+    def result(self):
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
+        return self._out
+
+
+def frechet_async(mu_x, cov_x, mu_y, cov_y, max_iter=64, tol=1e-13):
+    """frechet() on a side stream from a helper thread; .result() joins it.  The solver is host-driven (it polls its
+    convergence state), so overlapping it with other GPU work needs its own thread as well as its own stream."""
+    if os.environ.get("AM_FAD_OVERLAP", "1") == "0":
+        class _Done:
+            def __init__(self, out):
+                self._out = out
+
+            def result(self):
+                return self._out
+        return _Done(frechet(mu_x, cov_x, mu_y, cov_y, max_iter, tol))
+    return _FrechetJob((mu_x, cov_x, mu_y, cov_y, max_iter, tol), mu_x.device)
 
 
 def apa_scalar(d_y_x, d_y_xp, d_x_xp):
