@@ -31,7 +31,7 @@
 
 namespace am {
 
-constexpr int EV_FAST = EV_DEFAULT | EV_F16;
+constexpr int EV_FAST = EV_DEFAULT | EV_F16 | EV_LDS;       // 128-row engine, f16 operands, LDS-direct fills (no ds_write: the store path bounds the staged form)
 constexpr int FAST_MAX_DIM = 4096;                                            // fast_c's derivation holds up to here
 static inline float fast_c(int D) {
     return 0.0009765625f + 1.9073486328125e-06f + 2.98023223876953125e-08f * sqrtf((float)D) + (float)D * 4.76837158203125e-07f;
