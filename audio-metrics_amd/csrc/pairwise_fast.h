@@ -1323,44 +1323,59 @@ __device__ __forceinline__ void knn_file(float* __restrict__ cand, int* __restri
     if (slot < cap) cand[row * (int64_t)cap + slot] = t;
 }
 
+// A wave takes 64 pairs at a time.  Its 128 rows are fetched in 128-byte pieces with COALESCED loads (8 lanes per row
+// piece, 8 rows per instruction) into the wave's own LDS tile, then lane p reads the two pieces of pair p back and runs
+// the 32 products of the chain (row stride 36 floats: the reads are bank-conflict free).  One 16-byte load per lane and
+// row, as in the first version of this kernel, makes every load instruction touch 64 different cache lines: the
+// texture-address unit, not the memory, then bounds the kernel (0.30 ms for 92 k pairs on a 1/8 share).
+constexpr int VERIFY_LD = 36;                                       // floats per 32-float piece in LDS
+constexpr size_t VERIFY_LDS_BYTES = (size_t)4 * 128 * VERIFY_LD * sizeof(float);   // 4 waves x 128 rows
+
 __global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __restrict__ X, int64_t ld,
                                                               const float* __restrict__ xnorm, int D,
                                                               const uint2* __restrict__ pairs, const int* __restrict__ pair_count,
                                                               int pair_cap, float* __restrict__ cand, int* __restrict__ cnt2,
                                                               int cap) {
+    extern __shared__ __attribute__((aligned(16))) float vlds[];
     const int n = min(*pair_count, pair_cap);
     const int dp = (D + 7) / 8 * 8;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-        uint2 p = pairs[e];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* tile = vlds + wave * 128 * VERIFY_LD;                     // rows 0..63: first rows of the pairs, 64..127: second rows
+    const int grp = lane >> 3, slot = lane & 7;
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64; base < n; base += (int64_t)gridDim.x * 256) {
+        const int64_t e = base + lane;
+        uint2 p = e < n ? pairs[e] : make_uint2(FAST_HOLE, 0u);
         const bool hole = p.x == FAST_HOLE;
         if (hole) p = make_uint2(0u, 0u);
-        const float *xa = X + (int64_t)p.x * ld, *xb = X + (int64_t)p.y * ld;
-        float acc = 0.f;
-        // one pair per lane; whole 128-byte lines of both rows per step (16 independent loads in flight), then the 32
-        // products in the engine's order
-        int c = 0;
-        for (; c + 32 <= dp && c + 32 <= D; c += 32) {
-            f32x4 u[8], v[8];
+        // the row this lane fetches in load instruction rr: tile row rr * 8 + grp
+        const float* src[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                u[q] = *reinterpret_cast<const f32x4*>(xa + c + 4 * q);
-                v[q] = *reinterpret_cast<const f32x4*>(xb + c + 4 * q);
-            }
+        for (int rr = 0; rr < 16; ++rr) {
+            const int trow = rr * 8 + grp;
+            const unsigned idx = (unsigned)__shfl((int)(trow < 64 ? p.x : p.y), trow & 63);
+            src[rr] = X + (int64_t)idx * ld;
+        }
+        float acc = 0.f;
+        for (int c = 0; c < dp; c += 32) {
+            f32x4 piece[16];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) piece[rr] = load_k4(src[rr], c + slot * 4, D);
+            __builtin_amdgcn_wave_barrier();                         // the previous piece has been consumed (same wave: LDS ops stay in order)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr)
+                *reinterpret_cast<f32x4*>(tile + (rr * 8 + grp) * VERIFY_LD + slot * 4) = piece[rr];
+            __builtin_amdgcn_wave_barrier();
+            const float* ua = tile + lane * VERIFY_LD;
+            const float* va = tile + (64 + lane) * VERIFY_LD;
 #pragma unroll
             for (int q = 0; q < 8; q += 2) {
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(ua + 4 * q), u1 = *reinterpret_cast<const f32x4*>(ua + 4 * q + 4);
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(va + 4 * q), v1 = *reinterpret_cast<const f32x4*>(va + 4 * q + 4);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc = fmaf(v[q][s], u[q][s], acc);
-                    acc = fmaf(v[q + 1][s], u[q + 1][s], acc);
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    acc = fmaf(v0[s2], u0[s2], acc);
+                    acc = fmaf(v1[s2], u1[s2], acc);
                 }
-            }
-        }
-        for (; c < dp; c += 8) {                          // tail (D % 32 != 0)
-            const f32x4 u0 = load_k4(xa, c, D), u1 = load_k4(xa, c + 4, D), v0 = load_k4(xb, c, D), v1 = load_k4(xb, c + 4, D);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc = fmaf(v0[s], u0[s], acc);
-                acc = fmaf(v1[s], u1[s], acc);
             }
         }
         if (!hole) knn_file(cand, cnt2, cap, p.x, fmaxf(fmaf(-2.f, acc, xnorm[p.x] + xnorm[p.y]), 0.f));
@@ -1510,8 +1525,14 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
                        N, k1, b.xn, maxn, b.wgq, pair_cap, f.pair_count, f.cnt2, out_lists != nullptr ? 1 : 0, fast_c(D));
     AM_LAUNCH_CHECK();
     clock_begin(AM_KERNEL_KNN_VERIFY, st);
-    hipLaunchKernelGGL(knn_fast_verify_kernel, dim3(4096), dim3(256), 0, st, X, ld, b.xn, D, b.wgq, f.pair_count, pair_cap, b.cand,
-                       f.cnt2, p.cap);
+    static bool vattr_done = false;
+    if (!vattr_done) {
+        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_fast_verify_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)VERIFY_LDS_BYTES));
+        vattr_done = true;
+    }
+    hipLaunchKernelGGL(knn_fast_verify_kernel, dim3(2048), dim3(256), VERIFY_LDS_BYTES, st, X, ld, b.xn, D, b.wgq, f.pair_count,
+                       pair_cap, b.cand, f.cnt2, p.cap);
     clock_end(AM_KERNEL_KNN_VERIFY, st);
     AM_LAUNCH_CHECK();
     hipLaunchKernelGGL(knn_fast_select_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.cand, f.cnt2, p.cap, N, k1,
