@@ -319,7 +319,7 @@ def test_cross_kernel_schedules_agree():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = dict(os.environ, AB_ROWS="5000", AB_DIM="160", AB_WANT_MIN="1")
     outs = []
-    # the fourth run is the production path at this size: the bf16 filter + exact verification (pairwise_fast.h)
+    # the fourth run is the production path at this size: the f16 filter + exact verification (pairwise_fast.h)
     for extra in ({"AM_ENGINE_VARIANT": "0", "AM_PRDC_FAST": "0"}, {"AM_ENGINE_VARIANT": "35", "AM_PRDC_FAST": "0"},
                   {"AM_ENGINE_VARIANT": "99", "AM_PRDC_FAST": "0"}, {}):
         res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_cross.py")],
