@@ -253,6 +253,9 @@ def main():
             "other_kernels": verify,
             "kernels_ms_per_call": {name: tot / c for name, (c, tot) in sorted(kern.items())},
             "kernels_calls_per_step": {name: c / args.steps for name, (c, tot) in sorted(kern.items())},
+            "kernels_note": ("event-to-event time of each C-ABI entry point on its own stream; am_frechet_f64 runs from a helper "
+                             "thread on a side stream UNDER the PRDC kernels, so its own timeline is stretched (0.86 ms alone) and "
+                             "overlaps the others - the entries do not add up to ms_per_step"),
             "result": result,
         }
         if world == 1:
