@@ -170,9 +170,11 @@ struct CrossFastEpilogue {
         const int slot = atomicAdd(qn, 1);
         if (slot < qcap) {
             wgq[slot] = make_uint2((unsigned)i, jflag);
-        } else {                                            // region full: spill to the global queue
-            const int s2 = atomicAdd(ov_count, 1);
-            if (s2 < ovcap) ovq[s2] = make_uint2((unsigned)i, jflag);
+        } else if (*reinterpret_cast<volatile int*>(fail) == 0) {   // region full: spill to the global queue
+            // (once the fail flag is up nothing is counted any more: on inputs the bound cannot decide - e.g. sets three
+            // orders of magnitude apart - billions of pairs arrive here and would wrap the counter)
+            const unsigned s2 = atomicAdd(reinterpret_cast<unsigned*>(ov_count), 1u);
+            if (s2 < (unsigned)ovcap) ovq[s2] = make_uint2((unsigned)i, jflag);
             else *fail = 1;                                 // -> the exact kernel redoes the whole call
         }
     }
@@ -385,9 +387,9 @@ struct CrossWideEpilogue {
         const int slot = atomicAdd(qn, 1);
         if (slot < qcap) {
             wgq[slot] = make_uint2((unsigned)i, jflag);
-        } else {
-            const int s2 = atomicAdd(ov_count, 1);
-            if (s2 < ovcap) ovq[s2] = make_uint2((unsigned)i, jflag);
+        } else if (*reinterpret_cast<volatile int*>(fail) == 0) {   // (see CrossFastEpilogue::push)
+            const unsigned s2 = atomicAdd(reinterpret_cast<unsigned*>(ov_count), 1u);
+            if (s2 < (unsigned)ovcap) ovq[s2] = make_uint2((unsigned)i, jflag);
             else *fail = 1;
         }
     }
@@ -935,6 +937,8 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
 // Queue entry: (row a | FAST_BOTH, row b): the exact value t(a, b) is filed under row a, and under row b as well when
 // FAST_BOTH is set (a pair that passes the own-row test of a and the mirrored test of b is evaluated once).
 constexpr unsigned FAST_BOTH = 0x80000000u;
+constexpr int FAST_ROW_OVERFLOW = 0x40000000;                                 // OR-ed into a row's entry count: > any cap, and the
+                                                                              // later +1's of the scatter cannot wrap it
 constexpr unsigned FAST_HOLE = 0xffffffffu;                                  // pair-list slot left unwritten (list full)
 
 // Lane / TBX / MT: geometry of the engine underneath - LaneInfo, 128, 2 (tile_engine.h) or WLane, 256, 4 (wide_engine.h)
@@ -950,7 +954,7 @@ struct KnnFastEpilogue {
     int qcap;
     uint2* ovq;                 // global spill queue for entries that do not fit their region
     float* ovv;
-    int* ovn;
+    unsigned long long* ovn;
     int ovcap;
     int* cnt;
     int cap;
@@ -969,19 +973,21 @@ struct KnnFastEpilogue {
             wgq[slot] = make_uint2((unsigned)a | (both ? FAST_BOTH : 0u), (unsigned)b);
             wgv[slot] = val;
         } else if constexpr (KCAP <= 6) {                   // region full: spill to the global queue
-            const int s2 = atomicAdd(ovn, 1);
-            if (s2 < ovcap) {
+            // (inputs the bound cannot decide send hundreds of millions of pairs here: neither the counter nor the
+            // per-row markers may wrap)
+            const unsigned long long s2 = atomicAdd(ovn, 1ull);          // 64-bit: cannot wrap
+            if (s2 < (unsigned long long)ovcap) {
                 ovq[s2] = make_uint2((unsigned)a | (both ? FAST_BOTH : 0u), (unsigned)b);
                 ovv[s2] = val;
             } else {                                        // that one is full too: the row(s) go to the exact fix-up kernel
-                atomicAdd(cnt + a, cap + 1);
-                if (both) atomicAdd(cnt + b, cap + 1);
+                atomicOr(cnt + a, FAST_ROW_OVERFLOW);
+                if (both) atomicOr(cnt + b, FAST_ROW_OVERFLOW);
             }
         } else {
             // longer lists (k > 5): no spill path - its extra live state tips these instantiations into scratch
             // spills (measured: 12.7 -> 33 ms at k = 10); a full region sends the row(s) to the exact fix-up kernel
-            atomicAdd(cnt + a, cap + 1);
-            if (both) atomicAdd(cnt + b, cap + 1);
+            atomicOr(cnt + a, FAST_ROW_OVERFLOW);
+            if (both) atomicOr(cnt + b, FAST_ROW_OVERFLOW);
         }
     }
     __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
@@ -1047,7 +1053,7 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
                 int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
                 int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
                 int* __restrict__ wgq_count, int part, int nparts, float fc, uint2* __restrict__ ovq, float* __restrict__ ovv,
-                int* __restrict__ ovn, int ovcap) {
+                unsigned long long* __restrict__ ovn, int ovcap) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
     const int64_t T = (N + TB - 1) / TB;
@@ -1132,7 +1138,7 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
                 int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
                 int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
                 int* __restrict__ wgq_count, int part, int nparts, float fc, uint2* __restrict__ ovq, float* __restrict__ ovv,
-                int* __restrict__ ovn, int ovcap) {
+                unsigned long long* __restrict__ ovn, int ovcap) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const WLane L;
     const int64_t T = (N + WTB - 1) / WTB;
@@ -1248,10 +1254,10 @@ __global__ void __launch_bounds__(256) knn_fast_scatter_kernel(const uint2* __re
 }
 
 __global__ void __launch_bounds__(256) knn_fast_scatter_spill_kernel(const uint2* __restrict__ ovq, const float* __restrict__ ovv,
-                                                                     const int* __restrict__ ovn, int ovcap,
+                                                                     const unsigned long long* __restrict__ ovn, int ovcap,
                                                                      float* __restrict__ fval, unsigned* __restrict__ fidx,
                                                                      int* __restrict__ cnt, int cap) {
-    const int n = min(*ovn, ovcap);
+    const int n = (int)min(*ovn, (unsigned long long)ovcap);
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         const uint2 p = ovq[e];
         const unsigned a = p.x & ~FAST_BOTH;
@@ -1431,7 +1437,7 @@ struct KnnFastBuffers {           // on top of the symmetric path's KnnBuffers
     int *cnt2, *pair_count;
     uint2* ovq;                   // spill queue (entries past a region's capacity)
     float* ovv;
-    int* ovn;
+    unsigned long long* ovn;      // entries offered to it (64-bit: adversarial inputs offer billions)
 };
 constexpr int KNN_FAST_OVCAP = 1 << 22;
 
@@ -1441,9 +1447,9 @@ static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan&
     f.maxn = c.take<unsigned>(4);
     f.wgv = c.take<float>((size_t)p.nwin * p.per_win * p.qcap);
     f.fidx = c.take<unsigned>((size_t)N * p.cap);
-    f.cnt2 = c.take<int>(N + 2);                  // [N] = pair counter, [N + 1] = spill counter
+    f.cnt2 = c.take<int>(N + 2);                  // [N] = pair counter
     f.pair_count = f.cnt2 ? f.cnt2 + N : nullptr;
-    f.ovn = f.cnt2 ? f.cnt2 + N + 1 : nullptr;
+    f.ovn = c.take<unsigned long long>(1);
     f.ovq = c.take<uint2>(KNN_FAST_OVCAP);
     f.ovv = c.take<float>(KNN_FAST_OVCAP);
     return f;
@@ -1482,6 +1488,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     }
     AM_HIP_TRY(hipMemsetAsync(b.cnt, 0, (size_t)(N + 1) * sizeof(int), st));
     AM_HIP_TRY(hipMemsetAsync(f.cnt2, 0, (size_t)(N + 2) * sizeof(int), st));
+    AM_HIP_TRY(hipMemsetAsync(f.ovn, 0, sizeof(unsigned long long), st));
     // 2) symmetric filter sweep
     const unsigned nwg = (unsigned)p.nwin * (unsigned)p.per_win;
     const int64_t nlist = (int64_t)p.nwin * N * KCAP;
@@ -1552,10 +1559,12 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
         AM_HIP_TRY(hipMemcpy(c2.data(), f.cnt2, (N + 2) * sizeof(int), hipMemcpyDeviceToHost));
         long long tot = 0, full = 0, ctot = 0, bad = 0;
         int wmax = 0, cmax = 0;
+        unsigned long long spilled = 0;
+        AM_HIP_TRY(hipMemcpy(&spilled, f.ovn, sizeof(spilled), hipMemcpyDeviceToHost));
         for (int v : wc) { tot += v; full += (v >= qcap); wmax = std::max(wmax, v); }
         for (int64_t i = 0; i < N; ++i) { ctot += std::min(cn[i], p.cap); cmax = std::max(cmax, cn[i]); bad += c2[i] > p.cap; }
         fprintf(stderr, "[knn_fast] wgs=%u nwin=%d qcap=%d queued=%lld (max/wg %d, full regions %lld) filed=%lld max/row=%d "
-                        "pairs verified=%d spilled=%d rows to fix-up=%lld\n", nwg, p.nwin, qcap, tot, wmax, full, ctot, cmax, c2[N], c2[N + 1], bad);
+                        "pairs verified=%d spilled=%llu rows to fix-up=%lld\n", nwg, p.nwin, qcap, tot, wmax, full, ctot, cmax, c2[N], spilled, bad);
     }
     return AM_OK;
 }

@@ -375,6 +375,27 @@ def test_filter_paths_bit_identical_on_adversarial_data(data):
         assert outs[0] == outs[1], (tool, data, outs)
 
 
+def test_membership_filter_survives_undecidable_inputs():
+    """Found by tools/fuzz_filter.py: a candidate set three orders of magnitude smaller than the reference makes the
+    error bound useless for most rows - more than 2^31 pairs reach the spill path, whose 32-bit counter wrapped and
+    sent writes out of bounds.  The path must notice, hand the call to the exact kernel, and return its bits."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ, AB_ROWS="52000", AB_DIM="200", AB_K="3", AB_REPS="1", AB_DATA="scales", AB_SEED="290",
+                AB_WANT_MIN="1")
+    outs = []
+    for extra in ({"AM_PRDC_FAST": "0", "AM_KNN_FAST": "0"}, {}):
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_cross.py")], env=dict(base, **extra),
+                             capture_output=True, text=True, timeout=900)
+        m = re.search(r"sha1 ([0-9a-f]+)", res.stdout)
+        assert m, res.stdout[-500:] + res.stderr[-1500:]
+        outs.append(m.group(1))
+    assert outs[0] == outs[1], outs
+
+
 @pytest.mark.parametrize("n_ref,n_cand", [(70000, 300), (300, 70000), (33000, 1500)])
 def test_membership_filter_unequal_sets_bit_exact(am, n_ref, n_cand):
     """Very unequal set sizes through the 256-row filter engine (one column chunk / two row blocks / ragged edges):

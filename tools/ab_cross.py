@@ -19,7 +19,8 @@ if kind == "randn":
     x = torch.randn(n, d, generator=gen, device="cuda")
     y = torch.randn(n, d, generator=gen, device="cuda") * 1.05 + 0.05
 else:
-    x, y = make(kind, n, d, 0), make(kind, n, d, 1)
+    seed = int(os.environ.get("AB_SEED", "0"))
+    x, y = make(kind, n, d, 2 * seed), make(kind, n, d, 2 * seed + 1)
     if kind == "scales":
         y = y * 1e-3                                    # the candidate set three orders of magnitude smaller than the reference
 kk = int(os.environ.get("AB_K", "5"))

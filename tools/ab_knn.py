@@ -18,7 +18,7 @@ d = int(os.environ.get("AB_DIM", "512"))
 k = int(os.environ.get("AB_K", "5"))
 reps = int(os.environ.get("AB_REPS", "3"))
 from ab_data import make  # noqa: E402
-x = make(os.environ.get("AB_DATA", "randn"), n, d, 0)
+x = make(os.environ.get("AB_DATA", "randn"), n, d, int(os.environ.get("AB_SEED", "0")))
 r = ops.knn_radii(x, k)
 torch.cuda.synchronize()
 ts = []
