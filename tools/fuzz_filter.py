@@ -13,7 +13,7 @@ rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(n_cases):
     rows = rnd.choice([33000, 34567, 40000, 47001, 52000, 65536, 81000, 100000])
-    dim = rnd.choice([64, 96, 128, 200, 256, 384, 512])
+    dim = rnd.choice([64, 67, 96, 128, 130, 200, 256, 257, 384, 512])
     k = rnd.choice([1, 3, 5, 8, 10])
     data = rnd.choice(["randn", "clustered", "scales", "lowrank", "unit", "dups"])
     base = dict(os.environ, AB_ROWS=str(rows), AB_DIM=str(dim), AB_K=str(k), AB_REPS="1", AB_DATA=data,
