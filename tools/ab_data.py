@@ -25,4 +25,15 @@ def make(kind, n, d, seed):
     if kind == "unit":                 # CLAP-like: positive offset, L2-normalised rows
         x = x + 0.5
         return x / x.norm(dim=1, keepdim=True)
+    if kind == "tiny":                 # all magnitudes near 1e-18: squared norms close to the f32 underflow range
+        return x * 1e-18
+    if kind == "huge":                 # magnitudes near 1e15: squared norms ~1e33 (below f32 overflow), products large
+        return x * 1e15
+    if kind == "const":                # every row identical: all distances are rounding noise, every tie exact
+        return x[:1].expand(n, d).contiguous()
+    if kind == "sparse":               # one-hot-like rows: most products are exact zeros, many exactly equal distances
+        idx = torch.randint(0, d, (n,), generator=gen, device="cuda")
+        out = torch.zeros(n, d, device="cuda")
+        out[torch.arange(n, device="cuda"), idx] = 1.0 + 0.01 * torch.rand(n, generator=gen, device="cuda")
+        return out
     raise ValueError(kind)

@@ -15,7 +15,7 @@ for case in range(n_cases):
     rows = rnd.choice([33000, 34567, 40000, 47001, 52000, 65536, 81000, 100000])
     dim = rnd.choice([64, 67, 96, 128, 130, 200, 256, 257, 384, 512])
     k = rnd.choice([1, 3, 5, 8, 10])
-    data = rnd.choice(["randn", "clustered", "scales", "lowrank", "unit", "dups"])
+    data = rnd.choice(os.environ.get("FUZZ_DATA", "randn,clustered,scales,lowrank,unit,dups").split(","))
     base = dict(os.environ, AB_ROWS=str(rows), AB_DIM=str(dim), AB_K=str(k), AB_REPS="1", AB_DATA=data,
                 AB_SEED=str(rnd.randrange(1000)), AB_WANT_MIN=str(rnd.randrange(2)))
     line = f"case {case}: rows={rows} dim={dim} k={k} data={data} seed={base['AB_SEED']} want_min={base['AB_WANT_MIN']}"
