@@ -16,9 +16,10 @@ for case in range(n_cases):
     dim = rnd.choice([64, 67, 96, 128, 130, 200, 256, 257, 384, 512])
     k = rnd.choice([1, 3, 5, 8, 10])
     data = rnd.choice(os.environ.get("FUZZ_DATA", "randn,clustered,scales,lowrank,unit,dups").split(","))
-    base = dict(os.environ, AB_ROWS=str(rows), AB_DIM=str(dim), AB_K=str(k), AB_REPS="1", AB_DATA=data,
+    rows2 = rnd.choice([rows, rows, max(600, rows // 7), min(100000, rows * 2), 3001])      # candidate rows (membership only)
+    base = dict(os.environ, AB_ROWS=str(rows), AB_ROWS2=str(rows2), AB_DIM=str(dim), AB_K=str(k), AB_REPS="1", AB_DATA=data,
                 AB_SEED=str(rnd.randrange(1000)), AB_WANT_MIN=str(rnd.randrange(2)))
-    line = f"case {case}: rows={rows} dim={dim} k={k} data={data} seed={base['AB_SEED']} want_min={base['AB_WANT_MIN']}"
+    line = f"case {case}: rows={rows}/{rows2} dim={dim} k={k} data={data} seed={base['AB_SEED']} want_min={base['AB_WANT_MIN']}"
     for tool, pattern, off in (("ab_knn.py", r"radii sha1 ([0-9a-f]+)", {"AM_KNN_FAST": "0"}),
                                ("ab_cross.py", r"sha1 ([0-9a-f]+)", {"AM_PRDC_FAST": "0", "AM_KNN_FAST": "0"})):
         outs = []
