@@ -31,7 +31,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_
 F16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: bf16/f16 dense peak (v_mfma_f32_32x32x16_f16)
 
 
-def cpu_baseline(ref, cand, k, sample_rows=8000):
+def cpu_baseline(ref, cand, k, sample_rows=16000):
     """The CPU oracle (a port of the reference's torch/numpy calls, oracle/) timed on
     this host.  stats + FAD + KD run at the full size; PRDC materialises N x N
     matrices in the reference (164 GB at 100k), so it is timed on a row subsample
