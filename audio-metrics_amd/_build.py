@@ -8,6 +8,9 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libaudio_metrics_hip.so")
+# A/B build of the same sources with -DAM_DEV_KNOBS: environment-variable knobs, older engine schedules and debug dumps.
+# Never loaded by the product path; tools/ and the tests that force fallback paths ask for it with AM_HIP_LIBRARY=dev.
+DEV_LIB_PATH = os.path.join(LIB_DIR, "libaudio_metrics_hip_dev.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
 
 
@@ -22,29 +25,26 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def is_stale():
-    if not os.path.exists(LIB_PATH):
+def is_stale(lib_path=LIB_PATH):
+    if not os.path.exists(lib_path):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(lib_path)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
         glob.glob(os.path.join(os.path.dirname(PKG_DIR), "include", "*.h"))
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build_library(force=False, verbose=False):
-    """Compile every csrc/*.hip into one shared object.  Objects are built in
-    parallel (one hipcc per file) and linked with hipcc -shared."""
-    if not force and not is_stale():
-        return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    obj_dir = os.path.join(LIB_DIR, "obj")
+def _start_objects(hipcc, obj_dir, extra):
     os.makedirs(obj_dir, exist_ok=True)
-    hipcc = _hipcc()
     procs = []
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, *HIPCC_FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *HIPCC_FLAGS, *extra, "-c", src, "-o", obj]
         procs.append((cmd, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    return procs
+
+
+def _finish(hipcc, procs, lib_path, verbose):
     objs = []
     for cmd, obj, p in procs:
         out, _ = p.communicate()
@@ -53,10 +53,25 @@ def build_library(force=False, verbose=False):
         if verbose and out.strip():
             print(out)
         objs.append(obj)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs]
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed: %s\n%s" % (" ".join(link), r.stdout))
+    return lib_path
+
+
+def build_library(force=False, verbose=False, dev=True):
+    """Compile every csrc/*.hip into the shipped shared object and (dev=True) its -DAM_DEV_KNOBS twin.  Objects are
+    built in parallel (one hipcc per file and flavour) and linked with hipcc -shared."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = []
+    if force or is_stale(LIB_PATH):
+        jobs.append((_start_objects(hipcc, os.path.join(LIB_DIR, "obj"), []), LIB_PATH))
+    if dev and (force or is_stale(DEV_LIB_PATH)):
+        jobs.append((_start_objects(hipcc, os.path.join(LIB_DIR, "obj_dev"), ["-DAM_DEV_KNOBS"]), DEV_LIB_PATH))
+    for procs, path in jobs:
+        _finish(hipcc, procs, path, verbose)
     return LIB_PATH
 
 

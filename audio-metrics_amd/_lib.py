@@ -7,7 +7,7 @@ import ctypes
 import os
 from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
 
-from ._build import LIB_PATH
+from ._build import DEV_LIB_PATH, LIB_PATH
 
 _P = c_void_p
 
@@ -23,6 +23,8 @@ SIGNATURES = {
     "am_stats_merge_f64": (c_int, [c_int64, _P, _P, c_int64, _P, _P, c_int, _P, _P, _P]),
     "am_frechet_workspace_bytes": (c_size_t, [c_int]),
     "am_frechet_f64": (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, _P, _P, c_size_t, _P]),
+    "am_frechet_first_block": (c_int, []),
+    "am_frechet_enqueue_f64": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P, _P, c_size_t, _P]),
     "am_apa_f64": (c_double, [c_double, c_double, c_double]),
     "am_kd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "am_kd_poly_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, _P, _P, c_int, c_int,
@@ -48,6 +50,7 @@ SIGNATURES = {
     "am_kernel_clock_read": (c_int, [c_int, _P, _P]),
     "am_knn_path": (c_int, [c_int64, c_int64, c_int, c_int, c_int]),
     "am_prdc_path": (c_int, [c_int64, c_int64, c_int]),
+    "am_filter_stats_enable": (c_int, [_P]),
 }
 
 
@@ -59,7 +62,8 @@ _lib = None
 
 
 def library_path():
-    return LIB_PATH
+    """The shipped library; AM_HIP_LIBRARY=dev (tools and fallback-path tests only) selects the -DAM_DEV_KNOBS build."""
+    return DEV_LIB_PATH if os.environ.get("AM_HIP_LIBRARY") == "dev" else LIB_PATH
 
 
 def load():
@@ -67,16 +71,17 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = library_path()
+    if not os.path.exists(path):
         raise HipLibraryError(
-            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            f"{path} is missing: the HIP extension has not been built "
             "(run `python __graft_entry__.py build`). There is no CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+            raise HipLibraryError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
     _lib = lib

@@ -1,65 +1,99 @@
-"""``AudioMetrics(add_reference / evaluate)`` - drop-in front end.
+"""``AudioMetrics`` - the drop-in front end (``add_reference`` / ``evaluate`` / ``save_state`` / ``load_state``).
 
-Mirrors src/audio_metrics/audio_metrics.py:15-313: same constructor kwargs, methods,
-result keys (``fad``, ``kernel_distance_mean``, ``kernel_distance_std``, ``precision``,
-``recall``, ``density``, ``coverage``, ``apa``), state-dict layout and error behaviour.
+Public surface, result keys, state-file layout and error behaviour are those of the reference's class
+(src/audio_metrics/audio_metrics.py:15-313); the organisation is this build's own:
+
+  * the three reference sets and their PCA-projected shadows are described by one table (``REFERENCE_SETS``) that
+    drives accumulation, reset, projection caching and (de)serialisation;
+  * metrics are entries of a dispatch table evaluated in the reference's result-key order;
+  * the embedder runs on every GPU of ``device_indices`` (``embed.EmbedderPool``), each GPU aggregating its own
+    rows; with ``process_group`` (one process per GPU, torch.distributed over RCCL) every rank feeds its shard of
+    the audio and the metrics are reduced across ranks by ``distributed.py``.
 Everything below the embedder runs on the MI355X through the HIP library."""
+from collections import namedtuple
 from pathlib import Path
 
 import torch
 
 from .data import AudioMetricsData
-from .embed import ItemCategory, embedding_pipeline
+from .embed import EmbedderPool, ItemCategory, embedding_pipeline
 from .embedders import DEFAULT_EMBEDDER, EMBEDDERS
 from .metrics.apa import apa, apa_compute_d_x_xp
 from .metrics.fad import frechet_distance
 from .metrics.kd import kernel_distance
 from .metrics.prdc import prdc
-from .mix_functions import DEFAULT_MIX_FUNCTION, MIX_FUNCTIONS
+from .mix_functions import resolve_mix_function
 from .projection import IncrementalPCA
+
+# attribute -> (category that feeds it, projection attribute it goes through, attribute of its projected shadow)
+SetSpec = namedtuple("SetSpec", "category projection shadow")
+REFERENCE_SETS = {
+    "stem_reference": SetSpec(ItemCategory.stem, "stem_projection", "stem_reference_pca"),
+    "mix_reference": SetSpec(ItemCategory.aligned, "mix_projection", "mix_reference_pca"),
+    "mix_anti_reference": SetSpec(ItemCategory.misaligned, "mix_projection", "mix_anti_reference_pca"),
+}
+PROJECTIONS = ("stem_projection", "mix_projection")
+PLAIN_STATE = ("metrics", "need_apa", "win_dur", "input_sr", "apa_d_x_xp")
+ROW_METRICS = frozenset(("kd", "precision", "prdc"))          # metrics that need the stored rows (audio_metrics.py:17)
+MAX_NEAREST_K = 10                                             # audio_metrics.py:263
+
+EMPTY_REFERENCE = ("The reference dataset is empty. This can have various causes:"
+                   "  - You have not called AudioMetrics.add_reference()"
+                   "  - You have called AudioMetrics.add_reference() with an empty dataset"
+                   "  - The duration of your audio is shorter than `win_dur` ({win_dur}s)."
+                   "    (You can specify your own `win_dur` when instantiating AudioMetrics)")
+
+
+def _visible_devices(device_indices):
+    if not torch.cuda.is_available():
+        raise RuntimeError("No GPUs found, cannot compute audio metrics")            # gpu_parallel.py:27-28
+    if device_indices is None:
+        return [torch.device("cuda", torch.cuda.current_device())]
+    devices = [torch.device("cuda", int(i)) for i in device_indices]
+    if not devices:
+        raise RuntimeError("No GPUs found, cannot compute audio metrics")
+    return devices
+
+
+class _Sets:
+    """What one evaluate() call works on: (candidate, reference[, anti-reference]) after projection."""
+    __slots__ = ("stem_cand", "stem_ref", "mix_cand", "mix_ref", "mix_anti")
+
+    def __init__(self):
+        for name in self.__slots__:
+            setattr(self, name, None)
 
 
 class AudioMetrics:
-    _need_embeddings = set(("kd", "precision", "prdc"))       # audio_metrics.py:17
-    _amd = ("stem_reference", "mix_reference", "mix_anti_reference",
-            "stem_reference_pca", "mix_reference_pca", "mix_anti_reference_pca")
+    _need_embeddings = set(ROW_METRICS)
 
     def __init__(self, metrics=["apa", "fad"], n_pca=None, device_indices=None, embedder=None, mix_function=None,
-                 win_dur=5.0, input_sr=None):
-        self.device = self._pick_device(device_indices)
+                 win_dur=5.0, input_sr=None, process_group=None):
+        self._devices = _visible_devices(device_indices)
+        self.device = self._devices[0]                 # where statistics, stored rows and metric kernels live
+        self._group = process_group
         self.metrics = metrics
-        self.need_apa = "apa" in self.metrics
+        self.need_apa = "apa" in metrics
         self.win_dur = win_dur
         self.input_sr = input_sr
-        if n_pca is None:
-            self.stem_projection = None
-            self.mix_projection = None
-        else:
-            self.stem_projection = IncrementalPCA(n_components=n_pca, device=self.device)
-            self.mix_projection = IncrementalPCA(n_components=n_pca, device=self.device)
+        for name in PROJECTIONS:
+            setattr(self, name, None if n_pca is None else IncrementalPCA(n_components=n_pca, device=self.device))
+        if n_pca is not None and process_group is not None:
+            raise NotImplementedError("n_pca is not supported together with process_group")
         self.embedder = self.get_embedder(embedder) if embedder is None or isinstance(embedder, str) else embedder
-        self.mix_function = (self.get_mix_function(mix_function)
-                             if mix_function is None or isinstance(mix_function, str) else mix_function)
+        # resolved (and, for the library's own names, checked for its dependencies) here rather than at the first mix
+        self.mix_function = self.get_mix_function(mix_function)
+        self._pool = EmbedderPool(self.embedder, self._devices)
         self.apa_d_x_xp = None
-        self.reset_reference(_init=True)
-        self.mix_reference_pca = None
-        self.mix_anti_reference_pca = None
-        self.stem_reference_pca = None
+        for name, spec in REFERENCE_SETS.items():
+            setattr(self, name, None)
+            setattr(self, spec.shadow, None)
+        self.reset_reference()
 
-    # ------------------------------------------------------------ configuration
-    @staticmethod
-    def _pick_device(device_indices):
-        """The reference spreads embedder replicas over `device_indices`; here the embedder and
-        the metric kernels share ONE GPU: the first listed index (default: the current device)."""
-        if not torch.cuda.is_available():
-            raise RuntimeError("No GPUs found, cannot compute audio metrics")       # gpu_parallel.py:27-28
-        if device_indices:
-            return torch.device("cuda", int(device_indices[0]))
-        return torch.device("cuda", torch.cuda.current_device())
-
+    # ------------------------------------------------------------ what this configuration needs
     @property
     def stems_mode(self):
-        return any(metric for metric in self.metrics if metric != "apa")
+        return any(m != "apa" for m in self.metrics)
 
     @property
     def store_mix_embeddings(self):
@@ -67,168 +101,188 @@ class AudioMetrics:
 
     @property
     def store_stem_embeddings(self):
-        return self.stem_projection is not None or any(metric in self._need_embeddings for metric in self.metrics)
+        return self.stem_projection is not None or not ROW_METRICS.isdisjoint(self.metrics)
+
+    def _active(self, name):
+        return self.stems_mode if name == "stem_reference" else self.need_apa
+
+    def _stored(self, name):
+        return self.store_stem_embeddings if name == "stem_reference" else self.store_mix_embeddings
 
     def get_mix_function(self, mix_function):
-        if mix_function is None:
-            mix_function = DEFAULT_MIX_FUNCTION
-        func = MIX_FUNCTIONS.get(mix_function)
-        if func is None:
-            raise ValueError(f"Unknown mix_function {mix_function}, must be one of {MIX_FUNCTIONS.keys()}")
-        return func
+        if callable(mix_function):
+            return mix_function
+        return resolve_mix_function(mix_function, needed=self.need_apa)
 
     def get_embedder(self, embedder):
-        if embedder is None:
-            embedder = DEFAULT_EMBEDDER
-        info = EMBEDDERS.get(embedder)
-        if info is None:
-            raise ValueError(f"Unknown embedder {embedder}, must be one of {EMBEDDERS.keys()}")
-        cls, kwargs = info
-        return cls(**kwargs, device=self.device)
+        name = DEFAULT_EMBEDDER if embedder is None else embedder
+        if name not in EMBEDDERS:
+            raise ValueError(f"Unknown embedder {name}, must be one of {EMBEDDERS.keys()}")
+        factory, kwargs = EMBEDDERS[name]
+        return factory(**kwargs, device=self.device)
 
-    # ------------------------------------------------------------ state
-    def save_state(self, fp: str | Path):
-        state = dict(self.__dict__)
-        for key in ("mix_function", "embedder", "device"):
-            state.pop(key, None)
-        for attr in self._amd:
-            item = state.get(attr)
-            if item:
-                state[attr] = item.serialize()
-        for attr in ("stem_projection", "mix_projection"):
-            item = state.get(attr)
-            if item:
-                state[attr] = item.__getstate__().copy()
-        torch.save(state, fp)
-
-    def load_state(self, fp: str | Path):
-        state = torch.load(fp, weights_only=True)
-        for attr in self._amd:
-            item = state.get(attr)
-            if item:
-                state[attr] = AudioMetricsData.deserialize(item, device=self.device)
-        for attr in ("stem_projection", "mix_projection"):
-            item = state.get(attr)
-            if item:
-                getattr(self, attr).__setstate__(item)
-                del state[attr]
-        self.__dict__.update(state)
-
-    def reset_reference(self, _init=False):
+    # ------------------------------------------------------------ reference bookkeeping
+    def reset_reference(self):
+        """Empty reference sets for everything this configuration accumulates (audio_metrics.py:151-161)."""
+        for name, spec in REFERENCE_SETS.items():
+            if self._active(name):
+                setattr(self, name, AudioMetricsData(self._stored(name), device=self.device))
+                setattr(self, spec.shadow, None)
         if self.need_apa:
             self.apa_d_x_xp = None
-            self.mix_reference = AudioMetricsData(self.store_mix_embeddings, device=self.device)
-            self.mix_anti_reference = AudioMetricsData(self.store_mix_embeddings, device=self.device)
-            self.mix_reference_pca = None
-            self.mix_anti_reference_pca = None
-        elif _init:
-            self.mix_reference = None
-            self.mix_anti_reference = None
-        if self.stems_mode:
-            self.stem_reference = AudioMetricsData(self.store_stem_embeddings, device=self.device)
-            self.stem_reference_pca = None
-        elif _init:
-            self.stem_reference = None
 
     def assert_reference(self):
-        msg = ("The reference dataset is empty. This can have various causes:"
-               "  - You have not called AudioMetrics.add_reference()"
-               "  - You have called AudioMetrics.add_reference() with an empty dataset"
-               f"  - The duration of your audio is shorter than `win_dur` ({self.win_dur}s)."
-               "    (You can specify your own `win_dur` when instantiating AudioMetrics)")
-        if self.stems_mode and self.stem_reference.n is None:
-            raise ValueError(msg)
-        if self.need_apa and self.mix_reference.n is None:
-            raise ValueError(msg)
+        for name in REFERENCE_SETS:
+            if name != "mix_anti_reference" and self._active(name) and self._global_count(getattr(self, name)) == 0:
+                raise ValueError(EMPTY_REFERENCE.format(win_dur=self.win_dur))
 
-    # ------------------------------------------------------------ PCA projection (audio_metrics.py:163-209)
-    def ensure_stem_projection(self, ref, cand):
-        if self.stem_projection is None:
-            return ref, cand
-        store_embs = any(metric in self._need_embeddings for metric in self.metrics)
-        if self.stem_reference_pca is None:
-            self.stem_projection.partial_fit(ref.embeddings)
-            ref_emb = self.stem_projection.transform(ref.embeddings)
-            ref = AudioMetricsData(store_embs, device=self.device)
-            ref.add(ref_emb)
-            self.stem_reference_pca = ref
-        ref = self.stem_reference_pca
-        cand_emb = self.stem_projection.transform(cand.embeddings)
-        cand = AudioMetricsData(store_embs, device=self.device)
-        cand.add(cand_emb)
-        return ref, cand
-
-    def ensure_mix_projection(self, ref, anti_ref, cand):
-        if self.mix_projection is None:
-            return ref, anti_ref, cand
-        if self.mix_reference_pca is None:
-            self.mix_projection.partial_fit(ref.embeddings)
-            ref_emb = self.mix_projection.transform(ref.embeddings)
-            anti_ref_emb = self.mix_projection.transform(anti_ref.embeddings)
-            ref = AudioMetricsData(store_embeddings=False, device=self.device)
-            anti_ref = AudioMetricsData(store_embeddings=False, device=self.device)
-            ref.add(ref_emb)
-            anti_ref.add(anti_ref_emb)
-            self.mix_reference_pca = ref
-            self.mix_anti_reference_pca = anti_ref
-        ref, anti_ref = self.mix_reference_pca, self.mix_anti_reference_pca
-        cand_emb = self.mix_projection.transform(cand.embeddings)
-        cand = AudioMetricsData(store_embeddings=False, device=self.device)
-        cand.add(cand_emb)
-        return ref, anti_ref, cand
-
-    # ------------------------------------------------------------ the two entry points
-    def _pipeline(self, waveforms, apa_mode):
+    def _embed(self, waveforms, apa_mode):
         return embedding_pipeline(
-            waveforms, embedder=self.embedder, mix_function=self.mix_function,
+            waveforms, embedder=self.embedder, mix_function=self.mix_function, gpu_handler=self._pool,
             apa_mode=apa_mode if self.need_apa else None, stems_mode=self.stems_mode,
             store_mix_embeddings=self.store_mix_embeddings, store_stem_embeddings=self.store_stem_embeddings,
             win_dur=self.win_dur, input_sr=self.input_sr, device=self.device)
 
     def add_reference(self, reference):
-        metrics = self._pipeline(reference, "reference")
-        stem_reference = metrics.get(ItemCategory.stem)
-        if stem_reference is not None:
-            self.stem_reference_pca = None
-            self.stem_reference += stem_reference
-            self.stem_reference.recompute_stats()            # audio_metrics.py:139
-        mix_reference = metrics.get(ItemCategory.aligned)
-        if mix_reference is not None:
-            self.mix_reference_pca = None
-            self.mix_anti_reference_pca = None
-            self.mix_reference += mix_reference
-        mix_anti_reference = metrics.get(ItemCategory.misaligned)
-        if mix_anti_reference is not None:
-            self.mix_anti_reference += mix_anti_reference
+        fresh = self._embed(reference, "reference")
+        for name, spec in REFERENCE_SETS.items():
+            part = fresh.get(spec.category)
+            if part is None:
+                continue
+            if name != "mix_anti_reference":              # new rows outdate the projected shadows of their group
+                for other, other_spec in REFERENCE_SETS.items():
+                    if other_spec.projection == spec.projection:
+                        setattr(self, other_spec.shadow, None)
+            target = getattr(self, name)
+            target += part
+            if name == "stem_reference":
+                target.recompute_stats()                    # audio_metrics.py:139
+        # (the reference keeps a cached d_x_xp across add_reference calls, audio_metrics.py:251-252; so does this)
 
+    # ------------------------------------------------------------ PCA projection (audio_metrics.py:163-209)
+    def _through(self, projection, data, store):
+        out = AudioMetricsData(store, device=self.device)
+        out.add(projection.transform(data.embeddings))
+        return out
+
+    def _projected(self, projection_name, names, candidate, store):
+        """(references of `names`..., candidate) in the space of `projection_name`; the projected reference sets
+        are cached in their shadow attributes, the projection is (incrementally) fitted on the FIRST set only."""
+        projection = getattr(self, projection_name)
+        if projection is None:
+            return [getattr(self, n) for n in names] + [candidate]
+        shadows = [REFERENCE_SETS[n].shadow for n in names]
+        if getattr(self, shadows[0]) is None:
+            projection.partial_fit(getattr(self, names[0]).embeddings)
+            for n, shadow in zip(names, shadows):
+                setattr(self, shadow, self._through(projection, getattr(self, n), store))
+        return [getattr(self, s) for s in shadows] + [self._through(projection, candidate, store)]
+
+    # ------------------------------------------------------------ evaluation
     def __call__(self, candidate):
         return self.evaluate(candidate)
 
     def evaluate(self, candidate):
         self.assert_reference()
-        metrics = self._pipeline(candidate, "candidate")
-        stem_cand = metrics.get(ItemCategory.stem)
-        apa_cand = metrics.get(ItemCategory.aligned)
-        stem_ref, apa_ref, apa_anti_ref = self.stem_reference, self.mix_reference, self.mix_anti_reference
-        if self.stems_mode and (stem_cand is None or stem_cand.n is None):
-            raise ValueError("No stem candidate embeddings were computed")
-        if self.need_apa and (apa_cand is None or apa_cand.n is None):
-            raise ValueError("No apa candidate embeddings were computed")
+        fresh = self._embed(candidate, "candidate")
+        sets = _Sets()
         if self.stems_mode:
-            stem_ref, stem_cand = self.ensure_stem_projection(stem_ref, stem_cand)
+            cand = fresh.get(ItemCategory.stem)
+            if cand is None or self._global_count(cand) == 0:
+                raise ValueError("No stem candidate embeddings were computed")
+            sets.stem_ref, sets.stem_cand = self._projected(
+                "stem_projection", ["stem_reference"], cand, not ROW_METRICS.isdisjoint(self.metrics))
         if self.need_apa:
-            apa_ref, apa_anti_ref, apa_cand = self.ensure_mix_projection(apa_ref, apa_anti_ref, apa_cand)
-            if self.apa_d_x_xp is None:
-                self.apa_d_x_xp = apa_compute_d_x_xp(apa_ref, apa_anti_ref)
+            cand = fresh.get(ItemCategory.aligned)
+            if cand is None or self._global_count(cand) == 0:
+                raise ValueError("No apa candidate embeddings were computed")
+            sets.mix_ref, sets.mix_anti, sets.mix_cand = self._projected(
+                "mix_projection", ["mix_reference", "mix_anti_reference"], cand, False)
+        if self._group is not None:
+            return self._evaluate_sharded(sets)
+        result = {}
+        for key, run in METRIC_TABLE:
+            if key in self.metrics:
+                result.update(run(self, sets))
+        return result
 
+    # -- single-process metric runners (result-key order of audio_metrics.py:254-274)
+    def _run_fad(self, sets):
+        return {"fad": frechet_distance(sets.stem_cand, sets.stem_ref)}
+
+    def _run_kd(self, sets):
+        return kernel_distance(sets.stem_cand, sets.stem_ref)       # candidate is features_1 (audio_metrics.py:260)
+
+    def _run_prdc(self, sets):
+        k = max(1, min(MAX_NEAREST_K, len(sets.stem_ref), len(sets.stem_cand)))
+        return prdc(sets.stem_ref, sets.stem_cand, k)
+
+    def _run_apa(self, sets):
+        if self.apa_d_x_xp is None:
+            self.apa_d_x_xp = apa_compute_d_x_xp(sets.mix_ref, sets.mix_anti)
+        return {"apa": apa(sets.mix_cand, sets.mix_ref, sets.mix_anti, self.apa_d_x_xp)}
+
+    # -- one process per GPU: this rank holds a shard of every set
+    def _global_count(self, data):
+        if data is None:
+            return 0
+        if self._group is None:
+            return len(data)
+        from . import distributed
+        return distributed.global_count(len(data), self.device, self._group)
+
+    def _evaluate_sharded(self, sets):
+        from . import distributed
+        group = self._group
         result = {}
         if "fad" in self.metrics:
-            result["fad"] = frechet_distance(stem_cand, stem_ref)
-        if "kd" in self.metrics:
-            result.update(kernel_distance(stem_cand, stem_ref))          # candidate is features_1 (audio_metrics.py:260)
-        if "prdc" in self.metrics:
-            k = max(1, min(10, len(stem_ref), len(stem_cand)))
-            result.update(prdc(stem_ref, stem_cand, k))
+            cand, ref = (distributed.merged_stats(d, group) for d in (sets.stem_cand, sets.stem_ref))
+            result["fad"] = frechet_distance(cand, ref)
+        rows = [m for m in ("kd", "prdc") if m in self.metrics]
+        if rows:
+            n_ref, n_cand = self._global_count(sets.stem_ref), self._global_count(sets.stem_cand)
+            k = max(1, min(MAX_NEAREST_K, n_ref, n_cand))
+            result.update(distributed.evaluate_sharded(
+                distributed.local_rows(sets.stem_ref), distributed.local_rows(sets.stem_cand),
+                metrics=rows, nearest_k=k, group=group))
         if self.need_apa:
-            result["apa"] = apa(apa_cand, apa_ref, apa_anti_ref, self.apa_d_x_xp)
+            cand, ref, anti = (distributed.merged_stats(d, group) for d in (sets.mix_cand, sets.mix_ref, sets.mix_anti))
+            if self.apa_d_x_xp is None:
+                self.apa_d_x_xp = apa_compute_d_x_xp(ref, anti)
+            result["apa"] = apa(cand, ref, anti, self.apa_d_x_xp)
         return result
+
+    # ------------------------------------------------------------ state files (audio_metrics.py:78-104)
+    def save_state(self, fp: str | Path):
+        """The reference's layout: its instance dictionary without embedder / mix function, reference sets as
+        ``AudioMetricsData.serialize()`` dicts (host tensors), projections as their ``__getstate__`` dicts."""
+        state = {key: getattr(self, key) for key in PLAIN_STATE}
+        for name in PROJECTIONS:
+            projection = getattr(self, name)
+            state[name] = projection.__getstate__().copy() if projection is not None else None
+        for name, spec in REFERENCE_SETS.items():
+            for attr in (name, spec.shadow):
+                data = getattr(self, attr)
+                state[attr] = data.serialize() if data is not None else None
+        torch.save(state, fp)
+
+    def load_state(self, fp: str | Path):
+        state = dict(torch.load(fp, weights_only=True))
+        for name, spec in REFERENCE_SETS.items():
+            for attr in (name, spec.shadow):
+                if attr in state:
+                    item = state.pop(attr)
+                    setattr(self, attr, AudioMetricsData.deserialize(item, device=self.device) if item else item)
+        for name in PROJECTIONS:
+            item = state.pop(name, None)
+            if item:
+                if getattr(self, name) is None:
+                    setattr(self, name, IncrementalPCA(n_components=item.get("n_components"), device=self.device))
+                getattr(self, name).__setstate__(item)
+        for key, value in state.items():                   # plain fields (and anything else a reference file carries)
+            if key not in ("embedder", "mix_function", "device"):
+                setattr(self, key, value)
+
+
+METRIC_TABLE = (("fad", AudioMetrics._run_fad), ("kd", AudioMetrics._run_kd), ("prdc", AudioMetrics._run_prdc),
+                ("apa", AudioMetrics._run_apa))

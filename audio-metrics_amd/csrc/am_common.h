@@ -40,6 +40,10 @@ void set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once PER
+// DEVICE (one process may drive several GPUs: AudioMetrics(device_indices=[...]) runs one thread per GPU).
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
+
 // optional hipEvent bracket around the tile kernels (am_kernel_clock_enable / am_kernel_clock_read)
 void clock_begin(int kernel, hipStream_t st);
 void clock_end(int kernel, hipStream_t st);

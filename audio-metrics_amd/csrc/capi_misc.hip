@@ -18,6 +18,21 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- per-device kernel attributes -----------------------------------------------------------------
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<int, const void*>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    const std::pair<int, const void*> key(dev, kernel);
+    if (std::find(done.begin(), done.end(), key) != done.end()) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.push_back(key);
+    return e;
+}
+
 // ---- kernel clock ---------------------------------------------------------------------------------
 namespace {
 constexpr int N_CLOCKED = 4;

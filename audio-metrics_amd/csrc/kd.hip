@@ -253,8 +253,7 @@ static int run_kd(const float* X, int64_t N1, int64_t ldx, const float* Y, int64
     const bool generic = (uint64_t)N1 * (uint64_t)ldx * 4u >= 0xffffffffull || (uint64_t)N2 * (uint64_t)ldy * 4u >= 0xffffffffull;
     const int mode = (((D % BK) != 0 && !generic) ? 1 : 0) | (rbf ? 2 : 0) | (generic ? 4 : 0);
     auto launch = [&](auto kernel) -> int {
-        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)KD_LDS_BYTES));
+        AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)KD_LDS_BYTES));
         hipLaunchKernelGGL(kernel, dim3((unsigned)((int64_t)S * per_subset)), dim3(ENGINE_THREADS), KD_LDS_BYTES, st,
                            X, ldx, Y, ldy, D, idx1, idx2, m, T, ntri, gamma, coef0, degree, partial, rbf, n1, n2, N1, N2);
         AM_LAUNCH_CHECK();

@@ -853,7 +853,10 @@ __global__ void __launch_bounds__(256) prdc_reduce_kernel(const int32_t* __restr
 }
 
 // ------------------------------------------------------------------ host side
-// Development knobs (A/B experiments on the GPU box); unset in production use.
+// Development knobs exist only in the A/B build (-DAM_DEV_KNOBS -> libaudio_metrics_hip_dev.so, loaded by the tools and
+// by the tests that force fallback paths).  In the shipped library every knob is its default, a compile-time constant:
+// no getenv, path selection is a pure function of the shapes, and the older engine schedules are not instantiated.
+#ifdef AM_DEV_KNOBS
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -862,6 +865,10 @@ static int engine_variant() {
     static const int v = env_int("AM_ENGINE_VARIANT", EV_DEFAULT);
     return v;
 }
+#else
+static constexpr int env_int(const char*, int dflt) { return dflt; }
+static constexpr int engine_variant() { return EV_DEFAULT; }
+#endif
 
 static int choose_chunks(int64_t p_rows, int64_t q_rows) {
     const int64_t row_blocks = ceil_div(p_rows, TB);
@@ -897,11 +904,8 @@ template <int KCAP, int V, bool KTAIL>
 static int launch_knn_vt(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
                          const float* yn, int D, int nchunks, int qstride, float* partial, hipStream_t st,
                          const unsigned* half_scale = nullptr) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_partial_kernel<KCAP, V, KTAIL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIRWISE_LDS_BYTES));
-        attr_done = true;
+    {
+        AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_partial_kernel<KCAP, V, KTAIL>), (int)PAIRWISE_LDS_BYTES));
     }
     const int64_t blocks = ceil_div(N, TB) * nchunks;
     if (qstride == 1) clock_begin(AM_KERNEL_KNN, st);         // main pass only; qstride > 1 is the sampled pre-pass
@@ -928,13 +932,16 @@ static int launch_knn(const float* X, int64_t N, int64_t ldx, const float* xn, c
                       const float* yn, int D, int k1, int nchunks, int qstride, bool squared, float* partial,
                       float* out_r, hipStream_t st) {
     int rc;
+#ifdef AM_DEV_KNOBS
     if constexpr (KCAP == 6) {                       // older schedules stay selectable for A/B runs (k <= 5 kernel only)
         switch (qstride == 1 ? engine_variant() : EV_DEFAULT) {
             case 0: rc = launch_knn_v<KCAP, 0>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, 1, partial, st); break;
             case 3: rc = launch_knn_v<KCAP, 3>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, 1, partial, st); break;
             default: rc = launch_knn_v<KCAP, EV_DEFAULT>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st); break;
         }
-    } else {
+    } else
+#endif
+    {
         rc = launch_knn_v<KCAP, EV_DEFAULT>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st);
     }
     if (rc != AM_OK) return rc;
@@ -957,8 +964,7 @@ static int launch_knn_sym(const float* X, int64_t N, int64_t ld, const float* xn
                        reinterpret_cast<unsigned*>(partial), nlist, 0x7f800000u);
     AM_LAUNCH_CHECK();
     auto launch = [&](auto kernel) -> int {
-        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)PAIRWISE_LDS_BYTES + 16));
+        AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)PAIRWISE_LDS_BYTES + 16));
         clock_begin(AM_KERNEL_KNN, st);
         hipLaunchKernelGGL(kernel, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st,
                            X, N, ld, xn, thr, D, win_tiles, nwin, per_win, k1, partial, cand, cnt, cap, wgq, qcap, wgq_count,
@@ -1129,6 +1135,7 @@ static int run_knn(const float* X, int64_t N, int64_t ldx, const float* Y, int64
     // 2) half of the tile pairs + mirrored candidates, 3) merge, 4) exact fix-up of overflowed rows
     rc = launch_knn_sym<KCAP>(X, N, ldx, b.xn, b.thr, D, k1, p.win_tiles, p.nwin, p.per_win, b.partial, b.cand, b.cnt, p.cap,
                               b.wgq, p.qcap, b.wgq_count, b.ov_list, b.ov_count, out_r, st);
+#ifdef AM_DEV_KNOBS
     static const int debug = env_int("AM_KNN_DEBUG", 0);
     if (rc == AM_OK && debug) {                      // development aid: candidate statistics (synchronises!)
         std::vector<int> cnt(N + 1);
@@ -1185,6 +1192,7 @@ static int run_knn(const float* X, int64_t N, int64_t ldx, const float* Y, int64
                 (long long)N, k1, p.nchunks, p.pre_stride, p.cap, p.qcap, (double)tot / N, mx, cnt[N], (double)wtot / nwg, wmx,
                 wfull, nwg);
     }
+#endif
     return rc;
 }
 
@@ -1231,6 +1239,19 @@ extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const fl
         case 16: return run_knn<16>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
         default: return run_knn<32>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
     }
+}
+
+extern "C" int am_filter_stats_enable(int64_t* device_slots) {
+    if (device_slots == nullptr) {
+        g_filter_stats = nullptr;
+        g_filter_stats_device = -1;
+        return AM_OK;
+    }
+    int dev = -1;
+    AM_HIP_TRY(hipGetDevice(&dev));
+    g_filter_stats = reinterpret_cast<long long*>(device_slots);
+    g_filter_stats_device = dev;
+    return AM_OK;
 }
 
 // which form am_knn_radii_f32 / am_prdc_counts_f32 take for a shape: 0 exact general, 1 exact symmetric,
@@ -1454,8 +1475,7 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
     const int nchunks = choose_chunks(Nr, Nc);
     const int64_t blocks = ceil_div(Nr, TB) * nchunks;
     auto launch = [&](auto kernel) -> int {
-        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)PAIRWISE_LDS_BYTES));
+        AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)PAIRWISE_LDS_BYTES));
         if (!fast) clock_begin(AM_KERNEL_PRDC_CROSS, st);
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES, st, R, Nr, ldr, rn, rt,
                            C, Nc, ldc, cn, ct, D, nchunks, out_col_count, rmin, rany, env_int("AM_CROSS_ORDER", 0), run_flag);
@@ -1463,10 +1483,15 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
         AM_LAUNCH_CHECK();
         return AM_OK;
     };
+#ifdef AM_DEV_KNOBS
     if (engine_variant() == 0) rc = launch(&prdc_cross_kernel<0, false>);
     else if ((D % BK) != 0) rc = launch(&prdc_cross_kernel<EV_DEFAULT, true>);
     else if (engine_variant() == (EV_DEFAULT | EV_LDS)) rc = launch(&prdc_cross_kernel<EV_DEFAULT | EV_LDS, false>);
     else rc = launch(&prdc_cross_kernel<EV_DEFAULT, false>);
+#else
+    if ((D % BK) != 0) rc = launch(&prdc_cross_kernel<EV_DEFAULT, true>);
+    else rc = launch(&prdc_cross_kernel<EV_DEFAULT, false>);
+#endif
     if (rc != AM_OK) return rc;
     hipLaunchKernelGGL(prdc_finish_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, rmin, rany,
                        fast ? rcov : static_cast<unsigned*>(nullptr), run_flag, r_ref, Nr, out_row_min, out_row_any, out_row_cover);
@@ -1476,8 +1501,8 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
 
 extern "C" int am_prdc_reduce(const int32_t* col_count, int64_t Nc, const uint8_t* row_any, const uint8_t* row_cover,
                               int64_t Nr, int64_t* out4, am_stream_t stream) {
-    AM_REQUIRE(col_count && row_any && row_cover && out4, AM_ERR_BAD_ARG, "null pointer");
-    AM_REQUIRE(Nc >= 1 && Nr >= 1, AM_ERR_BAD_SHAPE, "empty input");
+    AM_REQUIRE(col_count && out4 && (Nr == 0 || (row_any && row_cover)), AM_ERR_BAD_ARG, "null pointer");
+    AM_REQUIRE(Nc >= 1 && Nr >= 0, AM_ERR_BAD_SHAPE, "empty input");     // Nr == 0: column totals only (multi-GPU second pass)
     hipStream_t st = static_cast<hipStream_t>(stream);
     AM_HIP_TRY(hipMemsetAsync(out4, 0, 4 * sizeof(int64_t), st));
     const int64_t n = Nc > Nr ? Nc : Nr;

@@ -94,6 +94,44 @@ __global__ void __launch_bounds__(256) max_bits_kernel(const float* __restrict__
     if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
 }
 
+// ---- optional filter statistics (am_filter_stats_enable): how much work the filter passes left for the exact kernels.
+// int64 slots: 0 k-NN calls, 1 entries queued by the sweep, 2 of those through the spill queue, 3 pairs evaluated exactly,
+// 4 rows recomputed by the exact fix-up kernel; 5 membership calls, 6 pairs queued, 7 of those through the overflow queue,
+// 8 calls handed to the exact kernel (both queues overflowed or the operands could not be scaled).
+constexpr int FILTER_STATS_SLOTS = 16;
+static long long* g_filter_stats = nullptr;                 // caller-owned device buffer, nullptr = off
+static int g_filter_stats_device = -1;
+
+static long long* filter_stats_for_current_device() {
+    if (g_filter_stats == nullptr) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != g_filter_stats_device) return nullptr;
+    return g_filter_stats;
+}
+
+__global__ void __launch_bounds__(256) filter_stats_kernel(const int* __restrict__ wgq_count, int64_t nwg, long long* __restrict__ stats,
+                                                           int slot_calls, int slot_queued, const unsigned long long* spill64,
+                                                           const int* spill32, int spill_cap, int slot_spill, const int* extra_a,
+                                                           int slot_a, const int* extra_b, int slot_b) {
+    long long q = 0;
+    for (int64_t i = threadIdx.x; i < nwg; i += 256) q += wgq_count[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+    __shared__ long long red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long spill = 0;
+        if (spill64 != nullptr) spill = (long long)min(*spill64, (unsigned long long)spill_cap);
+        if (spill32 != nullptr) spill = min(*spill32, spill_cap);
+        atomicAdd(reinterpret_cast<unsigned long long*>(stats + slot_calls), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long*>(stats + slot_queued), (unsigned long long)(red[0] + red[1] + red[2] + red[3] + spill));
+        atomicAdd(reinterpret_cast<unsigned long long*>(stats + slot_spill), (unsigned long long)spill);
+        if (extra_a != nullptr) atomicAdd(reinterpret_cast<unsigned long long*>(stats + slot_a), (unsigned long long)*extra_a);
+        if (extra_b != nullptr) atomicAdd(reinterpret_cast<unsigned long long*>(stats + slot_b), (unsigned long long)*extra_b);
+    }
+}
+
 // stats[which] (0/1: largest squared norm, 2/3: largest |element|) of one matrix, then its scaled f16 copy
 static int launch_to_half(const float* X, int64_t N, int64_t ld, int D, const float* norms, unsigned* stats, int which,
                           uint16_t* Xh, hipStream_t st) {
@@ -843,15 +881,13 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
     const float* Rb = reinterpret_cast<const float*>(b.rb);
     const float* Cb = reinterpret_cast<const float*>(b.cb);
     int* fail = b.ov_count + 1;
-    static bool attr_done = false;
-    if (!attr_done) {
+    {
         const void* kernels[] = {reinterpret_cast<const void*>(&cross_fast_kernel<true, true>),
                                  reinterpret_cast<const void*>(&cross_fast_kernel<true, false>),
                                  reinterpret_cast<const void*>(&cross_fast_kernel<false, true>),
                                  reinterpret_cast<const void*>(&cross_fast_kernel<false, false>)};
         for (const void* k : kernels)
-            AM_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FAST_LDS_BYTES));
-        attr_done = true;
+            AM_HIP_TRY(ensure_dynamic_lds(k, (int)FAST_LDS_BYTES));
     }
     const int dbg = env_int("AM_FAST_DBG", 0);
     // sampled pre-pass over every 16th column tile: certain "any" witnesses (and, when the row minimum is wanted,
@@ -867,13 +903,9 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
     AM_LAUNCH_CHECK();
     unsigned* rmin_or_null = want_min ? rmin : nullptr;
     if (p.wide) {
-        static bool wattr_done = false;
-        if (!wattr_done) {
-            AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_wide_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_CROSS_LDS_BYTES));
-            AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_wide_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_CROSS_LDS_BYTES));
-            wattr_done = true;
+        {
+            AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&cross_wide_kernel<true>), (int)WIDE_CROSS_LDS_BYTES));
+            AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&cross_wide_kernel<false>), (int)WIDE_CROSS_LDS_BYTES));
         }
         auto launch_wide = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3((unsigned)p.blocks), dim3(WTHREADS), WIDE_CROSS_LDS_BYTES, st, Rb, Nr, ldb / 2, rn, rt, Cb,
@@ -907,6 +939,13 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
     AM_LAUNCH_CHECK();
     hipLaunchKernelGGL(cross_fail_reset_kernel, dim3(256), dim3(256), 0, st, fail, col_count, Nc, rmin, rany, rcov, Nr);
     AM_LAUNCH_CHECK();
+    if (long long* stats = filter_stats_for_current_device()) {
+        hipLaunchKernelGGL(filter_stats_kernel, dim3(1), dim3(256), 0, st, b.wgq_count, (int64_t)p.blocks, stats, 5, 6,
+                           (const unsigned long long*)nullptr, (const int*)b.ov_count, p.ovcap, 7, (const int*)fail, 8,
+                           (const int*)nullptr, 0);
+        AM_LAUNCH_CHECK();
+    }
+#ifdef AM_DEV_KNOBS
     static const int debug = env_int("AM_FAST_DEBUG", 0);
     if (debug) {                                       // development aid: synchronises
         AM_HIP_TRY(hipStreamSynchronize(st));
@@ -920,6 +959,7 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
         fprintf(stderr, "[cross_fast] blocks=%lld nchunks=%d queued=%lld (max/wg %d, full regions %lld) overflow queue=%d fail=%d\n",
                 (long long)p.blocks, p.nchunks, tot, wmax, full, ovc[0], ovc[1]);
     }
+#endif
     return AM_OK;
 }
 
@@ -1495,14 +1535,10 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)ceil_div(nlist, 256)), dim3(256), 0, st,
                        reinterpret_cast<unsigned*>(b.partial), nlist, 0x7f800000u);
     AM_LAUNCH_CHECK();
-    static bool attr_done = false;
-    if (!attr_done) {
-        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_fast_kernel<KCAP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIRWISE_LDS_BYTES + 16));
+    {
+        AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_fast_kernel<KCAP>), (int)PAIRWISE_LDS_BYTES + 16));
         if constexpr (KCAP <= KNN_WIDE_MAX_KCAP)
-            AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_wide_kernel<KCAP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)KNN_WIDE_LDS_BYTES));
-        attr_done = true;
+            AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_wide_kernel<KCAP>), (int)KNN_WIDE_LDS_BYTES));
     }
     const int qcap = p.qcap;
     static const int ovcap = std::max(0, std::min(env_int("AM_KNN_FAST_OVCAP", KNN_FAST_OVCAP), KNN_FAST_OVCAP));   // (tests shrink it)
@@ -1532,11 +1568,8 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
                        N, k1, b.xn, maxn, b.wgq, pair_cap, f.pair_count, f.cnt2, out_lists != nullptr ? 1 : 0, fast_c(D));
     AM_LAUNCH_CHECK();
     clock_begin(AM_KERNEL_KNN_VERIFY, st);
-    static bool vattr_done = false;
-    if (!vattr_done) {
-        AM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_fast_verify_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)VERIFY_LDS_BYTES));
-        vattr_done = true;
+    {
+        AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_fast_verify_kernel), (int)VERIFY_LDS_BYTES));
     }
     hipLaunchKernelGGL(knn_fast_verify_kernel, dim3(2048), dim3(256), VERIFY_LDS_BYTES, st, X, ld, b.xn, D, b.wgq, f.pair_count,
                        pair_cap, b.cand, f.cnt2, p.cap);
@@ -1550,6 +1583,13 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
                            b.xn, D, k1, b.ov_list, b.ov_count, out_r);
         AM_LAUNCH_CHECK();
     }
+    if (long long* stats = filter_stats_for_current_device()) {
+        hipLaunchKernelGGL(filter_stats_kernel, dim3(1), dim3(256), 0, st, b.wgq_count, (int64_t)nwg, stats, 0, 1,
+                           (const unsigned long long*)f.ovn, (const int*)nullptr, ovcap, 2, (const int*)f.pair_count, 3,
+                           out_lists == nullptr ? (const int*)b.ov_count : (const int*)nullptr, 4);
+        AM_LAUNCH_CHECK();
+    }
+#ifdef AM_DEV_KNOBS
     static const int debug = env_int("AM_FAST_DEBUG", 0);
     if (debug) {                                       // development aid: synchronises
         AM_HIP_TRY(hipStreamSynchronize(st));
@@ -1566,6 +1606,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
         fprintf(stderr, "[knn_fast] wgs=%u nwin=%d qcap=%d queued=%lld (max/wg %d, full regions %lld) filed=%lld max/row=%d "
                         "pairs verified=%d spilled=%llu rows to fix-up=%lld\n", nwg, p.nwin, qcap, tot, wmax, full, ctot, cmax, c2[N], spilled, bad);
     }
+#endif
     return AM_OK;
 }
 

@@ -26,17 +26,16 @@ def default_device():
 
 
 def ensure_tensor(x, device=None):
-    """data.py:6-9."""
-    if not isinstance(x, torch.Tensor):
-        x = torch.as_tensor(x)
-    return x.to(device, non_blocking=True) if device else x
+    """Anything array-like as a torch tensor, optionally moved to `device` (role of data.py:6-9)."""
+    t = x if torch.is_tensor(x) else torch.as_tensor(x)
+    if device is None or device == "":
+        return t
+    return t.to(device, non_blocking=True)
 
 
 def ensure_ndarray(x):
-    """data.py:12-15."""
-    if isinstance(x, torch.Tensor):
-        x = x.cpu().numpy()
-    return x
+    """Tensors come back to the host as numpy arrays; everything else passes through (role of data.py:12-15)."""
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else x
 
 
 def _ld_for(d):
@@ -45,13 +44,11 @@ def _ld_for(d):
 
 class AudioMetricsData:
     def __init__(self, store_embeddings=True, device=None):
-        self.mean = None
-        self.n = None
-        self.cov = None
-        self.store_embeddings = store_embeddings
+        self.n = self.mean = self.cov = None
+        self.store_embeddings = bool(store_embeddings)
         self.embeddings = None            # [n, D] f32 view of self._buf
-        self.radii = {}
-        self.dtype = torch.float64
+        self.radii = {}                   # "radii_{k}" -> f32[n]
+        self.dtype = torch.float64        # dtype of the statistics
         self._device = torch.device(device) if device is not None else None
         self._buf = None                  # [capacity, ld] f32, rows 16-B aligned
 
@@ -98,6 +95,21 @@ class AudioMetricsData:
         self.dtype = state.get("dtype", torch.float64)
         return self
 
+    def to(self, device):
+        """This set on another GPU (statistics, stored rows and cached radii copied device to device)."""
+        device = torch.device(device)
+        if self.n is not None and device == self.device:
+            return self
+        other = AudioMetricsData(self.store_embeddings, device=device)
+        if self.n is None:
+            return other
+        other.n = self.n
+        other.mean, other.cov = self.mean.to(device), self.cov.to(device)
+        if self.embeddings is not None:
+            other._append(ops.as_matrix(self.embeddings.to(device)))
+        other.radii = {key: r.to(device) for key, r in self.radii.items()}
+        return other
+
     def add(self, embeddings):
         e = self._to_device_matrix(embeddings)
         n = e.shape[0]
@@ -109,20 +121,25 @@ class AudioMetricsData:
             self._update_embeddings(e)
 
     def recompute_stats(self):
-        if self.embeddings is not None:
-            self.n = len(self.embeddings)
-            self.mean, self.cov = ops.stats(self.embeddings)
-            if self.n == 1:
-                # reference quirk kept on purpose: a (1, 1) zero matrix, not (D, D) (data.py:56)
-                self.cov = torch.zeros((1, 1), dtype=self.dtype, device=self.device)
+        """One-shot statistics of the stored rows (data.py:49-58); a no-op without stored rows."""
+        rows = self.embeddings
+        if rows is None:
+            return
+        self.n = int(rows.shape[0])
+        self.mean, self.cov = ops.stats(rows)
+        if self.n < 2:
+            # reference quirk kept on purpose: a (1, 1) zero matrix, not (D, D) (data.py:56)
+            self.cov = torch.zeros((1, 1), dtype=self.dtype, device=self.device)
 
     def get_radii(self, k_neighbor):
-        key = f"radii_{k_neighbor}"
-        radii = self.radii.get(key)
-        if radii is None and self.embeddings is not None:
-            radii = ops.knn_radii(self.embeddings, k_neighbor)
-            self.radii[key] = radii       # never invalidated on append - same as the reference
-        return radii
+        """k-NN radii of the stored rows, computed once per k and kept (like the reference's cache, data.py:60-66, an
+        append does NOT invalidate it); None when no rows are stored."""
+        slot = "radii_%d" % int(k_neighbor)
+        if slot not in self.radii:
+            if self.embeddings is None:
+                return None
+            self.radii[slot] = ops.knn_radii(self.embeddings, int(k_neighbor))
+        return self.radii[slot]
 
     def _update_embeddings(self, embeddings):
         self._append(self._to_device_matrix(embeddings))
@@ -140,29 +157,39 @@ class AudioMetricsData:
         self.embeddings = self._buf[:n_old + n_new, :d]
 
     def __len__(self):
-        return self.n or 0
+        return 0 if self.n is None else int(self.n)
 
     def _update_stats(self, mean, cov, n):
         if self.n is None:
             self.mean, self.cov, self.n = mean, cov, n
             return
+        d = self.mean.numel()
+        if self.n == 1 and tuple(self.cov.shape) != (d, d):
+            # recompute_stats' n == 1 quirk left a (1, 1) zero matrix; the reference's merge broadcasts it with
+            # weight (n1 - 1) = 0 (data.py:85-92), which equals merging a D x D zero matrix
+            self.cov = torch.zeros((d, d), dtype=self.dtype, device=self.mean.device)
+        if n == 1 and tuple(cov.shape) != (d, d):
+            cov = torch.zeros((d, d), dtype=self.dtype, device=self.mean.device)
         self.mean, self.cov = ops.stats_merge(self.n, self.mean, self.cov, n, mean, cov, inplace=True)
         self.n = self.n + n
 
     def __iadd__(self, other):
-        assert isinstance(other, AudioMetricsData)
-        if other.n is None:
-            return self
-        if self.n is None:
-            self.store_embeddings = other.store_embeddings
-        assert self.store_embeddings == other.store_embeddings
-        self._update_stats(other.mean.clone(), other.cov.clone(), other.n)
-        if self.store_embeddings:
-            self._update_embeddings(other.embeddings)
+        """Absorb another set: Chan merge of the statistics and, when rows are kept, an append (data.py:96-106).  An empty
+        receiver adopts the other side's storage mode; mixing modes afterwards is an error."""
+        if not isinstance(other, AudioMetricsData):
+            raise AssertionError("can only merge AudioMetricsData objects")
+        if len(other) > 0:
+            if len(self) == 0:
+                self.store_embeddings = other.store_embeddings
+            elif self.store_embeddings != other.store_embeddings:
+                raise AssertionError("cannot merge a set that stores its embeddings with one that does not")
+            self._update_stats(other.mean.clone(), other.cov.clone(), other.n)
+            if self.store_embeddings:
+                self._update_embeddings(other.embeddings)
         return self
 
     def __add__(self, other):
-        new = AudioMetricsData(device=self._device)
-        new += self
-        new += other
-        return new
+        total = AudioMetricsData(device=self._device)
+        for part in (self, other):
+            total += part
+        return total

@@ -4,21 +4,23 @@ torch.distributed over RCCL / xGMI).
 Embedding sets are partitioned by contiguous sample-index ranges; every metric
 is a reduction over rows plus at most one exchange step:
 
-  stats / FAD   local column sums -> all-reduce -> global mean;
-                local centred scatter -> all-reduce -> covariance; the 2 MB
-                Newton-Schulz problem is then solved redundantly on every rank.
-  KD            all-gather of the embeddings (needed by PRDC anyway); subsets are
-                dealt round-robin to ranks; the S partial results are summed.
-  PRDC          each rank owns a row block of both sets against the gathered
-                columns: radii stay local -> all-gather; column counts ->
-                all-reduce; row flags are reduced to integer totals locally and
-                summed.
+  stats / FAD   local column sums of BOTH sets -> one all-reduce -> global means;
+                local centred scatters of both sets -> one all-reduce -> covariances;
+                the 2 MB Newton-Schulz problem is then solved redundantly on every rank,
+                on a side stream under the PRDC kernels.
+  KD            all-gather of the embeddings (needed by PRDC anyway), started before the
+                statistics kernels and awaited after them; subsets are dealt round-robin
+                to ranks; the S partial results are summed.
+  PRDC          each rank owns a row block of both sets against the gathered columns:
+                radii stay local -> all-gather; column counts and the two local row totals
+                travel in one int32 buffer -> one all-reduce.
 
 All collectives carry exact integers or f64 partial sums whose reduction order
 is fixed by the backend, and with world_size == 1 the same code is the
-single-GPU ``evaluate``.  The local compute object ``ops`` defaults to the HIP
-library (``hip_ops``); tests inject a CPU oracle-backed stand-in to exercise the
-sharding and collective logic under gloo.
+single-GPU ``evaluate``.  A rank may hold zero rows of a set (fewer samples than
+ranks): it contributes zeros and takes part in every collective.  The local
+compute object ``ops`` defaults to the HIP library (``hip_ops``); tests inject a
+CPU oracle-backed stand-in to exercise the sharding and collective logic under gloo.
 """
 import numpy as np
 import torch
@@ -49,38 +51,139 @@ def _all_reduce(t, world, group):
     return t
 
 
-def _all_gather_into(out, local, world, group):
-    """all_gather_into_tensor where the backend has it for this device (RCCL), else the list form."""
-    try:
-        dist.all_gather_into_tensor(out, local, group=group)
-    except (RuntimeError, NotImplementedError):
-        parts = list(out.view(world, *local.shape).unbind(0))
-        dist.all_gather(parts, local.contiguous(), group=group)
+def _flat_gather_supported(group):
+    """RCCL gathers straight into one tensor; gloo takes the list form (decided once from the backend, never by
+    catching a failed collective: an exception on one rank must not turn into a different collective there)."""
+    return dist.get_backend(group) == "nccl"
+
+
+def _all_gather_into(out, local, world, group, async_op=False):
+    if _flat_gather_supported(group):
+        return dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=async_op)
+    parts = list(out.view(world, *local.shape).unbind(0))
+    return dist.all_gather(parts, local.contiguous(), group=group, async_op=async_op)
+
+
+class _Gathered:
+    """Row shards of unequal length being concatenated: start() issues the collective, rows() waits and trims."""
+
+    def __init__(self, local, counts, world, group, async_op=True):
+        self.counts, self.world, self.local = counts, world, local
+        self.work = None
+        if world == 1:
+            return
+        width = tuple(local.shape[1:])
+        cmax = max(counts)
+        if local.shape[0] == cmax:
+            pad = local
+        else:
+            pad = torch.zeros((cmax, *width), dtype=local.dtype, device=local.device)
+            pad[:local.shape[0]] = local
+        self.out = torch.empty((world * cmax, *width), dtype=local.dtype, device=local.device)
+        self.work = _all_gather_into(self.out, pad, world, group, async_op=async_op)
+        self._pad = pad                                   # stays alive until the collective has run
+
+    def rows(self):
+        if self.world == 1:
+            return self.local
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        cmax = max(self.counts)
+        if all(c == cmax for c in self.counts):
+            return self.out
+        return torch.cat([self.out[r * cmax:r * cmax + self.counts[r]] for r in range(self.world)])
 
 
 def _all_gather_rows(local, counts, world, group):
-    """Concatenate row shards of unequal length (counts[r] rows from rank r)."""
+    return _Gathered(local, counts, world, group, async_op=False).rows()
+
+
+def global_count(n_local, device, group=None):
+    """Total number of rows over the ranks (every rank must call)."""
+    world, _ = _world(group)
     if world == 1:
-        return local
-    width = local.shape[1:] if local.dim() > 1 else ()
-    cmax = max(counts)
-    pad = torch.zeros((cmax, *width), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
-    out = torch.empty((world * cmax, *width), dtype=local.dtype, device=local.device)
-    _all_gather_into(out, pad, world, group)
-    if all(c == cmax for c in counts):
-        return out
-    return torch.cat([out[r * cmax:r * cmax + counts[r]] for r in range(world)])
+        return int(n_local)
+    t = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    _all_reduce(t, world, group)
+    return int(t.item())
 
 
-def global_stats(local, n_total, ops, world, group):
-    """(mean f64[D], cov f64[D,D]) of the row-sharded set."""
-    s = ops.colsum(local)
-    _all_reduce(s, world, group)
-    mean = s / float(n_total)
-    sc = ops.scatter(local, mean)
+def local_rows(data):
+    """This rank's stored rows of an ``AudioMetricsData`` as an [n, D] matrix (possibly with zero rows)."""
+    if data is None or data.embeddings is None:
+        raise ValueError("the metric needs the stored embeddings of a set that kept none")
+    return data.embeddings
+
+
+def global_stats_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group):
+    """((mean, cov) of the reference, (mean, cov) of the candidate) of two row-sharded sets: two all-reduces in all
+    (one fused buffer per phase)."""
+    d = ref_local.shape[1]
+    dev = ref_local.device
+
+    def colsum(x):
+        return ops.colsum(x) if x.shape[0] > 0 else torch.zeros(d, dtype=torch.float64, device=dev)
+
+    sums = torch.stack((colsum(ref_local), colsum(cand_local)))                 # [2, D]
+    _all_reduce(sums, world, group)
+    mean_r, mean_c = sums[0] / float(n_ref), sums[1] / float(n_cand)
+
+    def scatter(x, mean):
+        return ops.scatter(x, mean) if x.shape[0] > 0 else torch.zeros((d, d), dtype=torch.float64, device=dev)
+
+    sc = torch.stack((scatter(ref_local, mean_r), scatter(cand_local, mean_c)))  # [2, D, D]
     _all_reduce(sc, world, group)
-    return mean, sc / float(n_total - 1)
+    return (mean_r, sc[0] / float(max(n_ref - 1, 1))), (mean_c, sc[1] / float(max(n_cand - 1, 1)))
+
+
+class _Stats:
+    """(n, mean, cov) holder with the attributes the metric functions read."""
+
+    def __init__(self, n, mean, cov):
+        self.n, self.mean, self.cov = n, mean, cov
+        self.embeddings, self.radii = None, {}
+
+    def __len__(self):
+        return self.n or 0
+
+
+def merged_stats(data, group=None, ops=None):
+    """Statistics of the union of every rank's ``AudioMetricsData`` (stats-only sets: FAD / APA operands): the
+    (n, mean, cov) triples are all-gathered (2 MB per rank at D = 512) and Chan-merged in rank order on every
+    rank - the reference's own merge (data.py:77-94), so the result does not depend on who holds which rows."""
+    if ops is None:
+        from . import hip_ops as ops
+    world, _ = _world(group)
+    if world == 1:
+        return data
+    dev = data.device
+    n_local = len(data)
+    d_t = torch.tensor([0 if n_local == 0 else data.mean.numel()], dtype=torch.int64, device=dev)
+    dist.all_reduce(d_t, op=dist.ReduceOp.MAX, group=group)
+    d = int(d_t.item())
+    if d == 0:
+        return data
+    packed = torch.zeros(1 + d + d * d, dtype=torch.float64, device=dev)
+    if n_local:
+        packed[0] = float(n_local)
+        packed[1:1 + d] = data.mean
+        cov = data.cov if tuple(data.cov.shape) == (d, d) else torch.zeros((d, d), dtype=torch.float64, device=dev)
+        packed[1 + d:] = cov.reshape(-1)
+    everyone = torch.empty((world, packed.numel()), dtype=torch.float64, device=dev)
+    _all_gather_into(everyone.view(-1), packed, world, group)
+    counts = [int(round(v)) for v in everyone[:, 0].cpu().tolist()]
+    n, mean, cov = 0, None, None
+    for r in range(world):
+        if counts[r] == 0:
+            continue
+        m_r, c_r = everyone[r, 1:1 + d].clone(), everyone[r, 1 + d:].view(d, d).clone()
+        if n == 0:
+            n, mean, cov = counts[r], m_r, c_r
+        else:
+            mean, cov = ops.stats_merge(n, mean, cov, counts[r], m_r, c_r, inplace=True)
+            n += counts[r]
+    return _Stats(n or None, mean, cov)
 
 
 def sharded_radii(local, full, counts, k, ops, world, rank, group):
@@ -91,14 +194,17 @@ def sharded_radii(local, full, counts, k, ops, world, rank, group):
     n, d = full.shape
     lo = sum(counts[:rank])
     hi = lo + counts[rank]
-    if world > 1 and hasattr(ops, "knn_sym_part") and ops.knn_sym_eligible(n, d, k):
+    if world > 1 and min(counts) > 0 and hasattr(ops, "knn_sym_part") and ops.knn_sym_eligible(n, d, k):
         bounds = _all_gather_rows(ops.knn_bounds(full, k, lo, counts[rank]), counts, world, group)
         lists = ops.knn_sym_part(full, k, rank, world, bounds)
         all_lists = torch.empty((world, *lists.shape), dtype=lists.dtype, device=lists.device)
         _all_gather_into(all_lists.view(-1), lists.view(-1), world, group)
         r_full = ops.knn_lists_finish(all_lists, full, k)
         return r_full[lo:hi], r_full
-    r_local = ops.knn_radii(local, k, columns=full)
+    if local.shape[0] > 0:
+        r_local = ops.knn_radii(local, k, columns=full)
+    else:
+        r_local = torch.empty(0, dtype=torch.float32, device=full.device)
     return r_local, _all_gather_rows(r_local, counts, world, group)
 
 
@@ -119,36 +225,43 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
         allc = [counts.cpu().tolist()]
     ref_counts, cand_counts = [c[0] for c in allc], [c[1] for c in allc]
     n_ref, n_cand = sum(ref_counts), sum(cand_counts)
+    if n_ref == 0 or n_cand == 0:                          # the same error on every rank (all of them hold the totals)
+        raise ValueError(f"empty embedding set: {n_ref} reference and {n_cand} candidate rows over {world} ranks")
     d = ref_local.shape[1]
-    # Issue order: the long asynchronous PRDC chain first, then the host-side preparation of the KD index
-    # table (numpy PCG64 draws, ~10 ms) and the FAD solver (which synchronises to read its convergence
-    # state) while the GPU is busy.  The result dict keeps the reference's key order.
+
+    # 1) the big exchange first: the gathered copies are only needed after the statistics, so the transfer
+    #    (410 MB at 2 x 100k x 512) runs under the statistics kernels
     need_full = ("kd" in metrics) or ("prdc" in metrics)
     if need_full:
-        ref_full = _all_gather_rows(ref_local, ref_counts, world, group)
-        cand_full = _all_gather_rows(cand_local, cand_counts, world, group)
+        ref_g = _Gathered(ref_local, ref_counts, world, group)
+        cand_g = _Gathered(cand_local, cand_counts, world, group)
 
-    # The Frechet solve is a chain of ~36 small latency-bound kernels with host polling (0.9 ms of GPU time in which most
-    # of the chip idles).  When the long PRDC chain follows, the statistics are taken first and the solve runs on a side
-    # stream from a helper thread, under the PRDC kernels (its workgroups slip in as tile workgroups retire); the
-    # helper thread issues no collectives.
+    # 2) statistics; the Frechet solve goes to a side stream right away (its stopping rule runs on the device, so
+    #    the host just enqueues it) and overlaps the PRDC chain issued next
     fad_job = None
-    if "fad" in metrics and "prdc" in metrics and getattr(ops, "frechet_async", None) is not None:
-        mu_r, cov_r = global_stats(ref_local, n_ref, ops, world, group)
-        mu_c, cov_c = global_stats(cand_local, n_cand, ops, world, group)
-        fad_job = ops.frechet_async(mu_c, cov_c, mu_r, cov_r)
+    if "fad" in metrics:
+        (mu_r, cov_r), (mu_c, cov_c) = global_stats_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group)
+        starter = getattr(ops, "frechet_async", None)
+        fad_job = starter(mu_c, cov_c, mu_r, cov_r) if starter is not None else None
+
+    if need_full:
+        ref_full, cand_full = ref_g.rows(), cand_g.rows()
 
     prdc_pending = None
     if "prdc" in metrics:
         k = nearest_k
         r_ref_l, _ = sharded_radii(ref_local, ref_full, ref_counts, k, ops, world, rank, group)
         _, r_cand = sharded_radii(cand_local, cand_full, cand_counts, k, ops, world, rank, group)
-        col, rany, rcov = ops.prdc_counts(ref_local, cand_full, r_ref_l, r_cand)
-        _all_reduce(col, world, group)
-        tot = ops.prdc_reduce(col, rany, rcov)                 # [n_prec, n_rec(local), sum_cnt, n_cov(local)]
-        rows = torch.stack((tot[1], tot[3]))                   # (no host-side index list: that would be a blocking H2D copy)
-        _all_reduce(rows, world, group)
-        prdc_pending = (tot, rows, k)
+        packed = torch.zeros(n_cand + 2, dtype=torch.int32, device=dev)        # column counts | #rows any | #rows covered
+        if ref_local.shape[0] > 0:
+            col, rany, rcov = ops.prdc_counts(ref_local, cand_full, r_ref_l, r_cand)
+            local_tot = ops.prdc_reduce(col, rany, rcov)
+            packed[:n_cand] = col
+            packed[n_cand:] = torch.stack((local_tot[1], local_tot[3])).to(torch.int32)
+        _all_reduce(packed, world, group)
+        none = torch.zeros(0, dtype=torch.uint8, device=dev)
+        tot = ops.prdc_reduce(packed[:n_cand], none, none)                     # [#cols with count > 0, 0, sum of counts, 0]
+        prdc_pending = (tot, packed[n_cand:], k)
 
     kd_pending = None
     if "kd" in metrics:
@@ -169,8 +282,6 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
     if fad_job is not None:
         result["fad"] = fad_job.result()["fd"]
     elif "fad" in metrics:
-        mu_r, cov_r = global_stats(ref_local, n_ref, ops, world, group)
-        mu_c, cov_c = global_stats(cand_local, n_cand, ops, world, group)
         result["fad"] = ops.frechet(mu_c, cov_c, mu_r, cov_r)["fd"]
     if kd_pending is not None:
         mm = kd_pending.cpu().numpy()
@@ -178,6 +289,7 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
         result["kernel_distance_std"] = float(np.std(mm))
     if prdc_pending is not None:
         tot, rows, k = prdc_pending
+        tot, rows = tot.cpu().tolist(), rows.cpu().tolist()
         n_prec, sum_cnt = int(tot[0]), int(tot[2])
         n_rec, n_cov = int(rows[0]), int(rows[1])
         result.update(precision=n_prec / n_cand, recall=n_rec / n_ref,

@@ -18,6 +18,27 @@ LAION_CLAP_MUSIC_CHECKPOINT_URL = "https://huggingface.co/lukewys/laion_clap/res
 LAION_CLAP_LAYERS = ["audio_projection.0", "audio_projection.2"]
 
 
+def local_checkpoint(ckpt):
+    """Path of a checkpoint given as a path or URL: URLs are fetched once into ~/.cache/audio_metrics (the reference
+    downloads into its appdirs cache, util/get_url.py); an unreachable URL is a clear error here, not a confusing one
+    inside the model loader."""
+    import os
+    import urllib.request
+    if "://" not in str(ckpt):
+        return ckpt
+    cache = os.path.join(os.path.expanduser("~"), ".cache", "audio_metrics")
+    path = os.path.join(cache, os.path.basename(str(ckpt)))
+    if not os.path.exists(path):
+        os.makedirs(cache, exist_ok=True)
+        try:
+            urllib.request.urlretrieve(ckpt, path + ".part")
+        except OSError as e:
+            raise RuntimeError(f"cannot fetch the checkpoint {ckpt} ({e}); download it yourself and pass its path "
+                               f"as `ckpt`, or place it at {path}") from e
+        os.replace(path + ".part", path)
+    return path
+
+
 class LaionCLAP:
     """LAION-CLAP HTSAT-base audio tower, 512-d, 48 kHz (reference embedders/clap.py:10-60)."""
 
@@ -29,6 +50,7 @@ class LaionCLAP:
                               "available in this environment; pass an embedder object or embedder='synthetic_clap512'") from e
         if ckpt is None:
             ckpt = LAION_CLAP_MUSIC_CHECKPOINT_URL
+        ckpt = local_checkpoint(ckpt)                       # load_ckpt takes a file, not a URL (clap.py:16)
         self.clap = laion_clap.CLAP_Module(enable_fusion=False, amodel="HTSAT-base")
         self.clap.load_ckpt(ckpt, verbose=False)
         if device is not None:

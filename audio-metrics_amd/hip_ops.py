@@ -12,8 +12,9 @@ import torch
 from . import _lib
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """torch's current stream ON `device` (the tensors' device, not the thread's current device)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _ptr(t):
@@ -98,17 +99,49 @@ def kernel_clock_read(kernel):
     return n.value, ms.value
 
 
-def _call(lib, name, *args):
-    timer = KernelTimer.active
-    if timer is not None:
-        a = torch.cuda.Event(enable_timing=True)
-        b = torch.cuda.Event(enable_timing=True)
-        a.record()
-        status = getattr(lib, name)(*args)
-        b.record()
-        timer.records.append((name, a, b))
-    else:
-        status = getattr(lib, name)(*args)
+FILTER_STATS_NAMES = ("knn_calls", "knn_queued", "knn_spilled", "knn_verified_pairs", "knn_fallback_rows",
+                      "prdc_calls", "prdc_queued", "prdc_overflow_queue", "prdc_fallback_calls")
+_FILTER_STATS = {}
+
+
+def filter_stats_enable(device, on=True):
+    """Have the filter-form PRDC entry points add their queue / verification / fallback counts to a device buffer
+    (am_filter_stats_enable); filter_stats_read() returns and clears them."""
+    device = torch.device(device)
+    with torch.cuda.device(device):
+        if on:
+            buf = torch.zeros(16, dtype=torch.int64, device=device)
+            _FILTER_STATS[device.index] = buf
+            _lib.check(_lib.load().am_filter_stats_enable(_ptr(buf)), "am_filter_stats_enable")
+        else:
+            _FILTER_STATS.pop(device.index, None)
+            _lib.check(_lib.load().am_filter_stats_enable(ctypes.c_void_p(None)), "am_filter_stats_enable")
+
+
+def filter_stats_read(device):
+    buf = _FILTER_STATS[torch.device(device).index]
+    values = buf.cpu().tolist()
+    buf.zero_()
+    return dict(zip(FILTER_STATS_NAMES, values))
+
+
+def _call(lib, name, device, *args):
+    """Call entry point `name` with `device` current and torch's current stream of THAT device appended as the
+    trailing am_stream_t argument: the library launches on the device that is current in the calling thread, and the
+    tensors may live on another one than the thread's (AudioMetrics(device_indices=[1]) while cuda:0 is current)."""
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device)
+        args = (*args, ctypes.c_void_p(stream.cuda_stream))
+        timer = KernelTimer.active
+        if timer is not None:
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            status = getattr(lib, name)(*args)
+            b.record(stream)
+            timer.records.append((name, a, b))
+        else:
+            status = getattr(lib, name)(*args)
     _lib.check(status, name)
 
 
@@ -117,6 +150,14 @@ def _require_cuda(t, name):
         raise _lib.HipLibraryError(
             f"{name} must be a tensor resident on the MI355X (got {type(t).__name__} on "
             f"{getattr(t, 'device', 'host')}); this package has no CPU fallback")
+
+
+def _same_device(*tensors):
+    dev = tensors[0].device
+    for t in tensors[1:]:
+        if t.device != dev:
+            raise ValueError(f"tensors on different devices: {dev} and {t.device}")
+    return dev
 
 
 def as_matrix(e, name="embeddings"):
@@ -161,7 +202,7 @@ def stats(e):
     cov = torch.empty((d, d), dtype=torch.float64, device=e.device)
     nb = lib.am_stats_workspace_bytes(n, d)
     ws = _workspace(nb, e.device)
-    _call(lib, "am_stats_f32", _ptr(e), n, d, _ld(e), _ptr(mean), _ptr(cov), _ptr(ws), nb, _stream())
+    _call(lib, "am_stats_f32", e.device, _ptr(e), n, d, _ld(e), _ptr(mean), _ptr(cov), _ptr(ws), nb)
     return mean, cov
 
 
@@ -172,7 +213,7 @@ def colsum(e):
     out = torch.empty(d, dtype=torch.float64, device=e.device)
     nb = lib.am_stats_workspace_bytes(n, d)
     ws = _workspace(nb, e.device)
-    _call(lib, "am_colsum_f32", _ptr(e), n, d, _ld(e), _ptr(out), _ptr(ws), nb, _stream())
+    _call(lib, "am_colsum_f32", e.device, _ptr(e), n, d, _ld(e), _ptr(out), _ptr(ws), nb)
     return out
 
 
@@ -185,7 +226,7 @@ def scatter(e, mean):
     out = torch.empty((d, d), dtype=torch.float64, device=e.device)
     nb = lib.am_stats_workspace_bytes(n, d)
     ws = _workspace(nb, e.device)
-    _call(lib, "am_scatter_f32", _ptr(e), n, d, _ld(e), _ptr(mean), _ptr(out), _ptr(ws), nb, _stream())
+    _call(lib, "am_scatter_f32", e.device, _ptr(e), n, d, _ld(e), _ptr(mean), _ptr(out), _ptr(ws), nb)
     return out
 
 
@@ -194,10 +235,15 @@ def stats_merge(n1, mean1, cov1, n2, mean2, cov2, inplace=False):
     lib = _lib.load()
     mean1, cov1, mean2, cov2 = (_f64(t, "stats") for t in (mean1, cov1, mean2, cov2))
     d = mean1.numel()
+    # the C ABI sees raw pointers: a (1, 1) covariance (recompute_stats' n == 1 quirk) would be read and written as D x D
+    if mean2.numel() != d or tuple(cov1.shape) != (d, d) or tuple(cov2.shape) != (d, d):
+        raise ValueError(f"stats_merge: inconsistent shapes mean {tuple(mean1.shape)}/{tuple(mean2.shape)}, "
+                         f"cov {tuple(cov1.shape)}/{tuple(cov2.shape)}")
+    _same_device(mean1, cov1, mean2, cov2)
     om = mean1 if inplace else torch.empty_like(mean1)
     oc = cov1 if inplace else torch.empty_like(cov1)
-    _call(lib, "am_stats_merge_f64", int(n1), _ptr(mean1), _ptr(cov1), int(n2), _ptr(mean2), _ptr(cov2), d,
-                                      _ptr(om), _ptr(oc), _stream())
+    _call(lib, "am_stats_merge_f64", mean1.device, int(n1), _ptr(mean1), _ptr(cov1), int(n2), _ptr(mean2), _ptr(cov2), d,
+                                      _ptr(om), _ptr(oc))
     return om, oc
 
 
@@ -209,62 +255,71 @@ def frechet(mu_x, cov_x, mu_y, cov_y, max_iter=64, tol=1e-13):
     if cov_x.shape != (d, d) or cov_y.shape != (d, d) or mu_y.numel() != d:
         raise ValueError(f"inconsistent shapes: mu {tuple(mu_x.shape)}/{tuple(mu_y.shape)}, "
                          f"cov {tuple(cov_x.shape)}/{tuple(cov_y.shape)}")
+    _same_device(mu_x, cov_x, mu_y, cov_y)
     out = (ctypes.c_double * 4)()
     nb = lib.am_frechet_workspace_bytes(d)
     ws = _workspace(nb, mu_x.device)
-    _call(lib, "am_frechet_f64", _ptr(mu_x), _ptr(cov_x), _ptr(mu_y), _ptr(cov_y), d, int(max_iter), float(tol),
-                                  ctypes.cast(out, ctypes.c_void_p), _ptr(ws), nb, _stream())
+    _call(lib, "am_frechet_f64", mu_x.device, _ptr(mu_x), _ptr(cov_x), _ptr(mu_y), _ptr(cov_y), d, int(max_iter), float(tol),
+                                  ctypes.cast(out, ctypes.c_void_p), _ptr(ws), nb)
     return dict(fd=out[0], tr_sqrt=out[1], iters=int(out[2]), resid=out[3])
 
 
-class _FrechetJob:
-    """am_frechet_f64 running on a side stream from a helper thread (see frechet_async)."""
+class FrechetJob:
+    """A Frechet solve in flight on a side stream (frechet_async).  Nothing here blocks the host until .result()."""
 
-    def __init__(self, args, device):
-        import threading
-        self._out = None
-        self._err = None
-        main = torch.cuda.current_stream(device)
-        self._side = _SIDE_STREAMS.get(("fad", device.index))
+    def __init__(self, stats, max_iter, tol):
+        lib = _lib.load()
+        self._stats = stats                                  # keeps the operands alive
+        self._max_iter, self._tol = int(max_iter), float(tol)
+        dev = stats[0].device
+        self._d = stats[0].numel()
+        self._nb = lib.am_frechet_workspace_bytes(self._d)
+        main = torch.cuda.current_stream(dev)
+        self._side = _SIDE_STREAMS.get(("fad", dev.index))
         if self._side is None:
-            self._side = _SIDE_STREAMS[("fad", device.index)] = torch.cuda.Stream(device)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        self._side.wait_event(ready)                       # the statistics were produced on the caller's stream
-        for t in args:
-            if isinstance(t, torch.Tensor):
-                t.record_stream(self._side)
+            self._side = _SIDE_STREAMS[("fad", dev.index)] = torch.cuda.Stream(dev)
+        self._side.wait_stream(main)                         # the statistics were produced on the caller's stream
+        with torch.cuda.stream(self._side):
+            self._ws = _workspace(self._nb, dev)
+            self._out = torch.empty(8, dtype=torch.float64, device=dev)
+            self._next = 0
+            self._enqueue(lib.am_frechet_first_block())
+        for t in stats:
+            t.record_stream(self._side)
 
-        def run():
-            try:
-                torch.cuda.set_device(device)
-                with torch.cuda.stream(self._side):
-                    self._out = frechet(*args)
-            except BaseException as e:                     # re-raised in result()
-                self._err = e
-
-        self._thread = threading.Thread(target=run, name="am-frechet", daemon=True)
-        self._thread.start()
+    def _enqueue(self, n_iter):
+        lib = _lib.load()
+        mu_x, cov_x, mu_y, cov_y = self._stats
+        n_iter = min(int(n_iter), self._max_iter - self._next)
+        with torch.cuda.stream(self._side):
+            _call(lib, "am_frechet_enqueue_f64", mu_x.device, _ptr(mu_x), _ptr(cov_x), _ptr(mu_y), _ptr(cov_y), self._d,
+                  self._next, n_iter, self._max_iter, self._tol, _ptr(self._out), _ptr(self._ws), self._nb)
+        self._next += n_iter
 
     def result(self):
-        self._thread.join()
-        if self._err is not None:
-            raise self._err
-        return self._out
+        lib = _lib.load()
+        while True:
+            with torch.cuda.stream(self._side):
+                out = self._out.cpu().tolist()               # the one host read (synchronises the side stream only)
+            if int(out[4]) != 0 or self._next >= self._max_iter:
+                break
+            self._enqueue(lib.am_frechet_first_block())      # ill-conditioned product: another block of iterations
+        torch.cuda.current_stream(self._stats[0].device).wait_stream(self._side)
+        if int(out[4]) == 4:
+            raise _lib.HipLibraryError("am_frechet_enqueue_f64: non-finite covariance product or trace in Newton-Schulz")
+        return dict(fd=out[0], tr_sqrt=out[1], iters=int(out[2]), resid=out[3])
 
 
 def frechet_async(mu_x, cov_x, mu_y, cov_y, max_iter=64, tol=1e-13):
-    """frechet() on a side stream from a helper thread; .result() joins it.  The solver is host-driven (it polls its
-    convergence state), so overlapping it with other GPU work needs its own thread as well as its own stream."""
-    if os.environ.get("AM_FAD_OVERLAP", "1") == "0":
-        class _Done:
-            def __init__(self, out):
-                self._out = out
-
-            def result(self):
-                return self._out
-        return _Done(frechet(mu_x, cov_x, mu_y, cov_y, max_iter, tol))
-    return _FrechetJob((mu_x, cov_x, mu_y, cov_y, max_iter, tol), mu_x.device)
+    """frechet() enqueued on a side stream behind the work already queued on the current one; the kernels that the
+    caller launches next on its own stream overlap it.  The solver decides convergence on the device, so no helper thread
+    and no host polling are involved: .result() reads five doubles."""
+    stats = tuple(_f64(t, "stats") for t in (mu_x, cov_x, mu_y, cov_y))
+    d = stats[0].numel()
+    if stats[1].shape != (d, d) or stats[3].shape != (d, d) or stats[2].numel() != d:
+        raise ValueError("inconsistent shapes of the statistics")
+    _same_device(*stats)
+    return FrechetJob(stats, max_iter, tol)
 
 
 def apa_scalar(d_y_x, d_y_xp, d_x_xp):
@@ -281,9 +336,9 @@ def kd_poly(x, y, idx1, idx2, gamma, coef0, degree):
     out = torch.empty(s, dtype=torch.float64, device=x.device)
     nb = lib.am_kd_workspace_bytes(s, m)
     ws = _workspace(nb, x.device)
-    _call(lib, "am_kd_poly_f32", _ptr(x), x.shape[0], _ld(x), _ptr(y), y.shape[0], _ld(y), x.shape[1],
+    _call(lib, "am_kd_poly_f32", x.device, _ptr(x), x.shape[0], _ld(x), _ptr(y), y.shape[0], _ld(y), x.shape[1],
                                   _ptr(idx1), _ptr(idx2), s, m, float(gamma), float(coef0), int(degree),
-                                  _ptr(out), _ptr(ws), nb, _stream())
+                                  _ptr(out), _ptr(ws), nb)
     return out
 
 
@@ -296,8 +351,8 @@ def kd_rbf(x, y, idx1, idx2, sigma):
     out = torch.empty(s, dtype=torch.float64, device=x.device)
     nb = lib.am_kd_rbf_workspace_bytes(s, m)
     ws = _workspace(nb, x.device)
-    _call(lib, "am_kd_rbf_f32", _ptr(x), x.shape[0], _ld(x), _ptr(y), y.shape[0], _ld(y), x.shape[1], _ptr(idx1), _ptr(idx2),
-          s, m, float(sigma), _ptr(out), _ptr(ws), nb, _stream())
+    _call(lib, "am_kd_rbf_f32", x.device, _ptr(x), x.shape[0], _ld(x), _ptr(y), y.shape[0], _ld(y), x.shape[1], _ptr(idx1), _ptr(idx2),
+          s, m, float(sigma), _ptr(out), _ptr(ws), nb)
     return out
 
 
@@ -314,8 +369,8 @@ def knn_radii(x, k, columns=None):
     out = torch.empty(n, dtype=torch.float32, device=x.device)
     nb = lib.am_knn_workspace_bytes(n, y.shape[0], d, int(k))
     ws = _workspace(nb, x.device)
-    _call(lib, "am_knn_radii_f32", _ptr(x), n, _ld(x), _ptr(y), y.shape[0], _ld(y), d, int(k), _ptr(out),
-                                    _ptr(ws), nb, _stream())
+    _call(lib, "am_knn_radii_f32", x.device, _ptr(x), n, _ld(x), _ptr(y), y.shape[0], _ld(y), d, int(k), _ptr(out),
+                                    _ptr(ws), nb)
     return out
 
 
@@ -342,7 +397,7 @@ def knn_bounds(x_full, k, row0, nrows):
     out = torch.empty(int(nrows), dtype=torch.float32, device=x.device)
     nb = lib.am_knn_part_workspace_bytes(n, d, int(k))
     ws = _workspace(nb, x.device)
-    _call(lib, "am_knn_bounds_f32", _ptr(x), n, _ld(x), d, int(k), int(row0), int(nrows), _ptr(out), _ptr(ws), nb, _stream())
+    _call(lib, "am_knn_bounds_f32", x.device, _ptr(x), n, _ld(x), d, int(k), int(row0), int(nrows), _ptr(out), _ptr(ws), nb)
     return out
 
 
@@ -356,8 +411,8 @@ def knn_sym_part(x_full, k, part, nparts, bounds_sq):
     out = torch.empty((n, width), dtype=torch.float32, device=x.device)
     nb = lib.am_knn_part_workspace_bytes(n, d, int(k))
     ws = _workspace(nb, x.device)
-    _call(lib, "am_knn_sym_part_f32", _ptr(x), n, _ld(x), d, int(k), int(part), int(nparts), _ptr(bounds_sq), _ptr(out),
-          _ptr(ws), nb, _stream())
+    _call(lib, "am_knn_sym_part_f32", x.device, _ptr(x), n, _ld(x), d, int(k), int(part), int(nparts), _ptr(bounds_sq), _ptr(out),
+          _ptr(ws), nb)
     return out
 
 
@@ -371,8 +426,7 @@ def knn_lists_finish(lists, x_full, k):
     out = torch.empty(n, dtype=torch.float32, device=x.device)
     nb = 2 * (4 * (n + 64) + 512)
     ws = _workspace(nb, x.device)
-    _call(lib, "am_knn_lists_finish_f32", _ptr(lists), nparts, _ptr(x), n, _ld(x), d, int(k), _ptr(out), _ptr(ws), nb,
-          _stream())
+    _call(lib, "am_knn_lists_finish_f32", x.device, _ptr(lists), nparts, _ptr(x), n, _ld(x), d, int(k), _ptr(out), _ptr(ws), nb)
     return out
 
 
@@ -395,9 +449,9 @@ def prdc_counts(ref, cand, r_ref, r_cand, want_min=False):
     rmin = torch.empty(nr, dtype=torch.float32, device=ref.device) if want_min else None
     nb = lib.am_prdc_workspace_bytes(nr, nc, d)
     ws = _workspace(nb, ref.device)
-    _call(lib, "am_prdc_counts_f32", _ptr(ref), nr, _ld(ref), _ptr(cand), nc, _ld(cand), d, _ptr(r_ref),
+    _call(lib, "am_prdc_counts_f32", ref.device, _ptr(ref), nr, _ld(ref), _ptr(cand), nc, _ld(cand), d, _ptr(r_ref),
                                       _ptr(r_cand), _ptr(col), _ptr(rany), _ptr(rcov),
-                                      _ptr(rmin) if want_min else ctypes.c_void_p(None), _ptr(ws), nb, _stream())
+                                      _ptr(rmin) if want_min else ctypes.c_void_p(None), _ptr(ws), nb)
     return (col, rany, rcov, rmin) if want_min else (col, rany, rcov)
 
 
@@ -406,7 +460,7 @@ def prdc_reduce(col, rany, rcov):
     (#cols with count>0, #rows with any, sum of counts, #rows covered)."""
     lib = _lib.load()
     for t, name in ((col, "col_count"), (rany, "row_any"), (rcov, "row_cover")):
-        _require_cuda(t, name)
+        _require_cuda(t, name)                 # (empty row arrays are allowed: column totals only)
     # the C ABI takes raw pointers: hand it exactly the element types it reads
     col = col.to(torch.int32).contiguous()
     rany = rany.to(torch.uint8).contiguous()
@@ -414,5 +468,5 @@ def prdc_reduce(col, rany, rcov):
     if rcov.numel() != rany.numel():
         raise ValueError("row_any / row_cover lengths differ")
     out = torch.empty(4, dtype=torch.int64, device=col.device)
-    _call(lib, "am_prdc_reduce", _ptr(col), col.numel(), _ptr(rany), _ptr(rcov), rany.numel(), _ptr(out), _stream())
+    _call(lib, "am_prdc_reduce", col.device, _ptr(col), col.numel(), _ptr(rany), _ptr(rcov), rany.numel(), _ptr(out))
     return out

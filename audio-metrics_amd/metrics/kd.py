@@ -92,39 +92,35 @@ def _device_features(f):
     return f
 
 
+KNOWN_KERNELS = ("polynomial", "rbf")
+
+
 def kid_features_to_metric(features_1, features_2, **kwargs):
-    kernel_type = kwargs.get("kernel_type", "polynomial")
-    if kernel_type not in ("polynomial", "rbf"):
-        raise NotImplementedError(f'Unknown kernel_type "{kernel_type}"')
-    features_1, features_2 = _device_features(features_1), _device_features(features_2)
-    assert features_1.ndim == 2
-    assert features_2.ndim == 2
-    assert features_1.shape[1] == features_2.shape[1]
-
-    kid_subsets = kwargs.get("kid_subsets", KID_SUBSETS)
-    kid_subset_size = kwargs.get("kid_subset_size", KID_SUBSET_SIZE)
-    verbose = kwargs.get("verbose", False)
-    n_samples_1, n_samples_2 = len(features_1), len(features_2)
-    assert n_samples_1 and n_samples_2, "Cannot compute KID on empty features tensor"
-    n_samples = min(n_samples_1, n_samples_2)
-    if kid_subset_size >= n_samples:
-        new_ss = max(1, n_samples // 2)
-        if verbose:
-            logging.warning(f"Reducing KID subset size from {kid_subset_size} to {new_ss} "
-                            "to accommodate small sample size")
-        kid_subset_size = new_ss
-
-    gamma = kwargs.get("kid_gamma", KID_GAMMA)
-    if gamma is None:
-        gamma = 1.0 / features_1.shape[1]
-    idx1, idx2 = subset_indices(n_samples_1, n_samples_2, kid_subsets, kid_subset_size,
-                                kwargs.get("rng_seed", 1234))
-    dev = features_1.device
-    d1, d2 = torch.as_tensor(idx1).to(dev), torch.as_tensor(idx2).to(dev)
-    if kernel_type == "rbf":          # kd.py:136-140
-        mmds = ops.kd_rbf(features_1, features_2, d1, d2, kwargs.get("kid_sigma", KID_SIGMA))
+    """KD between two feature matrices; keyword options and their defaults as kd.py:128-156,176:
+    kid_subsets, kid_subset_size, kid_degree, kid_gamma, kid_coef0, kid_sigma, rng_seed, kernel_type, verbose."""
+    opt = dict(kernel_type="polynomial", kid_subsets=KID_SUBSETS, kid_subset_size=KID_SUBSET_SIZE, kid_degree=KID_DEGREE,
+               kid_gamma=KID_GAMMA, kid_coef0=KID_COEF0, kid_sigma=KID_SIGMA, rng_seed=1234, verbose=False)
+    opt.update(kwargs)
+    if opt["kernel_type"] not in KNOWN_KERNELS:
+        raise NotImplementedError('Unknown kernel_type "%s"' % opt["kernel_type"])
+    x1, x2 = _device_features(features_1), _device_features(features_2)
+    if x1.ndim != 2 or x2.ndim != 2 or x1.shape[1] != x2.shape[1]:
+        raise AssertionError(f"feature matrices of shapes {tuple(x1.shape)} and {tuple(x2.shape)} do not match")
+    n1, n2 = x1.shape[0], x2.shape[0]
+    if min(n1, n2) == 0:
+        raise AssertionError("Cannot compute KID on empty features tensor")
+    m = int(opt["kid_subset_size"])
+    if m >= min(n1, n2):                                   # kd.py:160-168: shrink to half of the smaller set
+        shrunk = max(1, min(n1, n2) // 2)
+        if opt["verbose"]:
+            logging.warning("Reducing KID subset size from %d to %d to accommodate small sample size", m, shrunk)
+        m = shrunk
+    idx1, idx2 = subset_indices(n1, n2, int(opt["kid_subsets"]), m, opt["rng_seed"])
+    d1, d2 = (torch.as_tensor(t).to(x1.device) for t in (idx1, idx2))
+    if opt["kernel_type"] == "rbf":                        # kd.py:136-140
+        mmds = ops.kd_rbf(x1, x2, d1, d2, opt["kid_sigma"])
     else:
-        mmds = ops.kd_poly(features_1, features_2, d1, d2, gamma, kwargs.get("kid_coef0", KID_COEF0),
-                           kwargs.get("kid_degree", KID_DEGREE))
-    mmds = mmds.cpu().numpy()
-    return {KEY_METRIC_KID_MEAN: float(np.mean(mmds)), KEY_METRIC_KID_STD: float(np.std(mmds))}
+        gamma = 1.0 / x1.shape[1] if opt["kid_gamma"] is None else opt["kid_gamma"]
+        mmds = ops.kd_poly(x1, x2, d1, d2, gamma, opt["kid_coef0"], opt["kid_degree"])
+    per_subset = mmds.cpu().numpy()
+    return {KEY_METRIC_KID_MEAN: float(np.mean(per_subset)), KEY_METRIC_KID_STD: float(np.std(per_subset))}

@@ -3,52 +3,47 @@
 
 The peak-based mixers are restated here in numpy.  The loudness-based ones (L0/L1/L2,
 BS.1770 gating + limiter) depend on pyloudnorm / numpy_audio_limiter, which are outside
-this build's scope; they are resolved lazily and raise a clear error when unavailable."""
+this build's scope: ``resolve_mix_function`` rejects them when the object is constructed."""
 from functools import partial
 
 import numpy as np
 
 
+def _peak(x, axis=None):
+    return np.max(np.abs(x), axis=axis)
+
+
 def mix_tracks_peak_preserve(audio, sr):
-    """Average the channels, then rescale to the peak of the original waveforms
-    (reference mix_functions.py:209-227)."""
-    assert audio.ndim == 2
-    if audio.shape[1] == 1:
-        return audio[:, 0]
-    peak = np.abs(audio).max()
-    if peak <= 1e-5:
-        return audio[:, 0]
-    mix = audio.mean(axis=1)
-    mix *= peak / np.abs(mix).max()
-    return mix
+    """Channel average rescaled to the largest peak of the input channels; a single channel, or (near-)silent input,
+    passes its first channel through (behaviour of mix_functions.py:209-227)."""
+    if audio.ndim != 2:
+        raise AssertionError("expected audio of shape [n_samples, channels]")
+    first = audio[:, 0]
+    if audio.shape[1] < 2:
+        return first
+    loudest = _peak(audio)
+    if not loudest > 1e-5:
+        return first
+    mono = np.mean(audio, axis=1)
+    return mono * (loudest / _peak(mono))
 
 
 def mix_tracks_peak_normalize(audio, sr, stem_db_red=0.0, out_db=0.0):
-    """Peak-normalise each channel (the stem `stem_db_red` dB below the context), sum,
-    and peak-normalise the mix to `out_db` dBFS (reference mix_functions.py:230-250)."""
-    assert audio.ndim == 2
-    out_gain = np.power(10.0, out_db / 20.0)
-    stem_gain = np.power(10.0, stem_db_red / 20.0)
-    if audio.shape[1] == 1:
-        mix = audio[:, 0]
+    """Every channel is scaled to unit peak - the stem (channel 1) `stem_db_red` dB lower than the context - then the
+    sum is brought to a peak of `out_db` dBFS (behaviour of mix_functions.py:230-250)."""
+    if audio.ndim != 2:
+        raise AssertionError("expected audio of shape [n_samples, channels]")
+
+    def from_db(db):
+        return 10.0 ** (db / 20.0)
+
+    if audio.shape[1] < 2:
+        mono = np.array(audio[:, 0], copy=True)
     else:
-        peaks = np.abs(audio).max(axis=0, keepdims=True)
-        peaks[0, 1] *= stem_gain
-        mix = (audio / peaks).sum(axis=1)
-    mix *= out_gain / np.abs(mix).max()
-    return mix
-
-
-def _loudness_mixer(stem_db_red, out_db):
-    def mix(audio, sr):
-        try:
-            import pyloudnorm  # noqa: F401
-        except ImportError as e:
-            raise ImportError("the loudness-based mix functions (L0/L1/L2) need `pyloudnorm`, which is not installed; "
-                              "pass mix_function='P0' (peak based) or your own callable f(audio[n,2], sr)->audio[n]") from e
-        raise NotImplementedError("BS.1770 loudness mixing is outside the scope of this build (SURVEY.md section 2 row 14)")
-    mix.stem_db_red, mix.out_db = stem_db_red, out_db
-    return mix
+        channel_peaks = _peak(audio, axis=0)[None, :]
+        channel_peaks[0, 1] = channel_peaks[0, 1] * from_db(stem_db_red)    # dividing by a smaller peak = boosting less
+        mono = np.sum(audio / channel_peaks, axis=1)
+    return mono * (from_db(out_db) / _peak(mono))
 
 
 MIX_FUNCTIONS = dict(
@@ -56,8 +51,27 @@ MIX_FUNCTIONS = dict(
     P0=partial(mix_tracks_peak_normalize, stem_db_red=-0, out_db=-3),
     P1=partial(mix_tracks_peak_normalize, stem_db_red=-3, out_db=-3),
     P2=partial(mix_tracks_peak_normalize, stem_db_red=-6, out_db=-3),
-    L0=_loudness_mixer(0, -20),
-    L1=_loudness_mixer(-3, -20),
-    L2=_loudness_mixer(-6, -20),
 )
+# Names the reference also registers (BS.1770 loudness + limiter, mix_functions.py:281-344).  They need pyloudnorm and
+# numpy_audio_limiter, which sit outside this build: asking for one is an error at
+# construction time, never in the middle of a stream.
+LOUDNESS_MIXERS = ("L0", "L1", "L2")
 DEFAULT_MIX_FUNCTION = "L0"
+
+
+def resolve_mix_function(name=None, needed=True):
+    """Registry lookup used by ``AudioMetrics``.  `needed` = the configuration mixes at all (APA requested)."""
+    if name is None:
+        name = DEFAULT_MIX_FUNCTION
+    if name in MIX_FUNCTIONS:
+        return MIX_FUNCTIONS[name]
+    if name not in LOUDNESS_MIXERS:
+        raise ValueError(f"Unknown mix_function {name}, must be one of {list(MIX_FUNCTIONS) + list(LOUDNESS_MIXERS)}")
+    message = (f"mix_function {name!r} is a BS.1770 loudness mixer (pyloudnorm + numpy_audio_limiter), which this build "
+               "does not provide; pass mix_function='P0' (peak based) or your own callable f(audio[n, 2], sr) -> audio[n]")
+    if needed:
+        raise ValueError(message)
+
+    def unavailable(audio, sr):               # only reachable if a caller mixes although APA was not requested
+        raise ValueError(message)
+    return unavailable

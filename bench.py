@@ -6,6 +6,7 @@ configs[2]), on N GPUs of one node.
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --config e2e          # BASELINE configs[4] shape: audio -> embedder -> APA + FAD (see run_e2e)
 
 A step is one COLD evaluation: both sets' statistics, the Frechet distance, the
 100 x 1000 kernel-distance subsets, both sets' k-NN radii and the membership
@@ -13,6 +14,10 @@ counts are all recomputed (nothing is cached between steps).  With N > 1 the row
 of both sets are sharded over the ranks (strong scaling: the problem is fixed) and
 the stats / gathered embeddings / radii / counts go through RCCL collectives.
 Rank 0 prints ONE JSON line.
+
+Inputs come from numpy's PCG64 (tests/golden/inputs.py: bench_pair), so the CPU oracle can reproduce them:
+tests/golden/bench_prdc.npz holds oracle.prdc_blocked's values for exactly these sets and the line's `result` is
+checked against it (`result_check`).
 """
 import argparse
 import json
@@ -20,22 +25,24 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 METRIC = "evaluate() embeddings/sec (FAD+KD+PRDC), 2×100k CLAP-512 sets, 1/2/4/8 GPUs"
 F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: bf16/f16 dense peak (v_mfma_f32_32x32x16_f16)
 
 
-def cpu_baseline(ref, cand, k, sample_rows=16000):
-    """The CPU oracle (a port of the reference's torch/numpy calls, oracle/) timed on
-    this host.  stats + FAD + KD run at the full size; PRDC materialises N x N
-    matrices in the reference (164 GB at 100k), so it is timed on a row subsample
-    and scaled by (N / sample)^2."""
+def cpu_baseline(ref, cand, k, prdc_rows=(10000, 20000, 40000)):
+    """The CPU oracle (a port of the reference's torch/numpy calls, oracle/) timed on this host.  stats + FAD + KD run at
+    the full size; PRDC materialises N x N matrices in the reference (164 GB at 100k), so it is timed on row subsamples
+    (10k / 20k / 40k), the growth exponent is fitted, and the full-size time is the 40k point scaled by
+    (N / 40k)^2."""
     import oracle
     # LAPACK geev (the reference's eigvals) and small-block cdist degrade badly with hundreds of
     # threads (measured on the 256-core GPU host: eigvals 477 s); cap at 32 and report the count used.
@@ -52,17 +59,30 @@ def cpu_baseline(ref, cand, k, sample_rows=16000):
     t0 = time.perf_counter()
     oracle.kid_from_features(cand, ref)
     t_kd = time.perf_counter() - t0
-    m = min(sample_rows, n)
-    t0 = time.perf_counter()
-    oracle.prdc_blocked(ref[:m], cand[:m], k, block=2048)
-    t_prdc_s = time.perf_counter() - t0
-    t_prdc = t_prdc_s * (n / m) ** 2
+    points = []
+    for m in prdc_rows:
+        m = min(m, n)
+        t0 = time.perf_counter()
+        oracle.prdc_blocked(ref[:m], cand[:m], k, block=2048)
+        points.append((m, time.perf_counter() - t0))
+        if m == n:
+            break
+    m_last, t_last = points[-1]
+    t_prdc = t_last * (n / m_last) ** 2
+    if len(points) > 1:
+        lx, ly = np.log([p[0] for p in points]), np.log([p[1] for p in points])
+        exponent = float(np.polyfit(lx, ly, 1)[0])
+    else:
+        exponent = 2.0
     total = t_stats + t_fad + t_kd + t_prdc
+    pts = ", ".join(f"{m}: {t:.2f}s" for m, t in points)
     return {
         "value": 2 * n / total, "unit": "embeddings/s", "cores": torch.get_num_threads(), "kind": "port",
+        "prdc_points_s": {str(m): t for m, t in points}, "prdc_fitted_exponent": exponent, "prdc_extrapolated_s": t_prdc,
         "sample": (f"oracle/ (torch-CPU port of the reference): stats {t_stats:.2f}s + FAD {t_fad:.2f}s + KD {t_kd:.2f}s "
-                   f"at full 2x{n}x{ref.shape[1]}; PRDC(k={k}) timed on 2x{m} rows ({t_prdc_s:.2f}s) and scaled by "
-                   f"(N/{m})^2 to {t_prdc:.0f}s because the reference's N x N matrices do not fit host RAM at 100k"),
+                   f"at full 2x{n}x{ref.shape[1]}; PRDC(k={k}) timed on 2 x {{{pts}}} rows (fitted growth N^{exponent:.2f}) "
+                   f"and the {m_last}-row point scaled by (N/{m_last})^2 to {t_prdc:.0f}s because the reference's N x N "
+                   f"matrices do not fit host RAM at 100k"),
     }
 
 
@@ -87,15 +107,48 @@ def warm_evaluate(am, ref, cand, k, steps):
             "what": "reference statistics and radii cached (second evaluate() against the same reference)", "result": res}
 
 
+def check_against_fixture(result, kind, n, d, k):
+    """`result` against oracle.prdc_blocked's values for the same numpy-seeded sets (tests/golden/bench_prdc.npz, written
+    by tests/golden/make_goldens.py bench in the build container; row blocks of the reference's own torch calls)."""
+    path = os.path.join(ROOT, "tests", "golden", "bench_prdc.npz")
+    tag = f"{kind}_k{k}"
+    if not (os.path.exists(path) and n == 100000 and d == 512):
+        return None
+    g = np.load(path, allow_pickle=False)
+    if f"{tag}/precision" not in g.files:
+        return None
+    diffs = {key: abs(result[key] - float(g[f"{tag}/{key}"])) for key in ("precision", "recall", "density", "coverage")}
+    # single distances differ in their last f32 bit between the two arithmetic orders: a few of the 1e10 strict
+    # comparisons flip.  1e-4 relative (north star) with a floor of five rows of the 100k.
+    ok = all(diffs[key] <= max(1e-4 * abs(float(g[f"{tag}/{key}"])), 5.0 / n) for key in diffs)
+    return {"fixture": f"tests/golden/bench_prdc.npz:{tag}", "abs_diff": diffs, "ok": bool(ok)}
+
+
+def timed_steps(step, fence, steps, warmup):
+    for _ in range(warmup):
+        result = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        result = step()
+    fence()
+    return time.perf_counter() - t0, result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=("evaluate", "e2e"), default="evaluate")
     ap.add_argument("--rows", type=int, default=100000, help="rows per set (default: the BASELINE config)")
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--nearest-k", type=int, default=5)
+    ap.add_argument("--data", choices=("randn", "clap"), default="randn",
+                    help="randn: SURVEY 8(d) C3 sets; clap: unit-norm rows with offsets 0.5 / 0.55 (CLAP-shaped)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--pairs", type=int, default=2000, help="--config e2e: audio pairs per side")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,6 +164,7 @@ def main():
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     if world > 1:
+        # dmabuf IPC is the only form the host driver supports (see the environment notes); harmless when already set
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -121,17 +175,7 @@ def main():
     from audio_metrics_amd import hip_ops as ops
     from audio_metrics_amd.distributed import evaluate_sharded, shard_bounds
     am._lib.load()                                       # no HIP library -> fail here, loudly
-
-    n, d, k = args.rows, args.dim, args.nearest_k
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0)                                   # same seed on every rank: identical full sets
-    ref = torch.randn(n, d, generator=gen, device=dev)
-    cand = torch.randn(n, d, generator=gen, device=dev) * 1.05 + 0.05
-    lo, hi = shard_bounds(n, world, rank)
-    ref_l, cand_l = ref[lo:hi], cand[lo:hi]              # this rank's row shard (as its embedder would produce)
-
-    def step():
-        return evaluate_sharded(ref_l, cand_l, metrics=("fad", "kd", "prdc"), nearest_k=k)
+    import inputs as gi
 
     def fence():
         torch.cuda.synchronize()
@@ -139,13 +183,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.config == "e2e":
+        run_e2e(args, am, dev, world, rank, fence)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    n, d, k = args.rows, args.dim, args.nearest_k
+    lo, hi = shard_bounds(n, world, rank)
+
+    def make_sets(kind):
+        ref_h, cand_h = gi.bench_pair(kind, n, d)        # same seed on every rank: identical full sets
+        return torch.as_tensor(ref_h).to(dev), torch.as_tensor(cand_h).to(dev)
+
+    ref, cand = make_sets(args.data)
+    ref_l, cand_l = ref[lo:hi], cand[lo:hi]              # this rank's row shard (as its embedder would produce)
+
+    def step():
+        return evaluate_sharded(ref_l, cand_l, metrics=("fad", "kd", "prdc"), nearest_k=k)
+
     for _ in range(args.warmup):
         result = step()
     fence()
-    # Two clocks over the timed region, both HIP events on the stream the kernels run on: KernelTimer brackets each
+    # Clocks over the timed region, all HIP events on the stream the kernels run on: KernelTimer brackets each
     # C-ABI entry point from the host side; the library's kernel clock brackets the two tile kernels themselves
     # (the durations `rocprofv3 --kernel-trace --stats` reports for them).
     ops.kernel_clock_enable(True)
+    ops.filter_stats_enable(dev, True)
     for kid in (ops.KERNEL_KNN, ops.KERNEL_PRDC_CROSS, ops.KERNEL_KNN_VERIFY, ops.KERNEL_PRDC_VERIFY):
         ops.kernel_clock_read(kid)                                                           # drop warm-up launches
     with ops.KernelTimer() as timer:
@@ -159,10 +224,29 @@ def main():
               (("knn", ops.KERNEL_KNN), ("cross", ops.KERNEL_PRDC_CROSS), ("knn_verify", ops.KERNEL_KNN_VERIFY),
                ("cross_verify", ops.KERNEL_PRDC_VERIFY))}
     ops.kernel_clock_enable(False)
+    filter_stats = ops.filter_stats_read(dev)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- other workloads SURVEY 8(d) asks for beside the headline one (never `value`): the filter kernels' speed depends
+    # on how many pairs their error bound cannot decide, i.e. on the data and on k
+    variants = {}
+    if world == 1 and not args.no_variants:
+        for name, kind, vk in (("clap_shaped_k5", "clap", 5), ("randn_k10", "randn", 10), ("clap_shaped_k10", "clap", 10)):
+            if (kind, vk) == (args.data, k):
+                continue
+            vr, vc = (ref, cand) if kind == args.data else make_sets(kind)
+            ops.filter_stats_read(dev)
+            dt, vres = timed_steps(lambda: evaluate_sharded(vr, vc, metrics=("fad", "kd", "prdc"), nearest_k=vk), fence, 3, 1)
+            stats = ops.filter_stats_read(dev)
+            variants[name] = {"ms_per_step": dt / 3 * 1e3, "embeddings_per_s": 3 * 2 * n / dt,
+                              "filter": per_step(stats, 4), "result": vres,
+                              "knn_path": ops.knn_path(n, n, d, vk), "prdc_path": ops.prdc_path(n, n, d),
+                              "result_check": check_against_fixture(vres, kind, n, d, vk)}
+            del vr, vc
+    ops.filter_stats_enable(dev, False)
 
     if rank == 0:
         rows_local = hi - lo
@@ -190,11 +274,10 @@ def main():
         kcalls, kms = kern[knn_entry]
         ccalls, cms = kern["am_prdc_counts_f32"]
         # ALGORITHMIC work of one launch (one dot product per (row, column) pair, no symmetry credit):
-        # 2 * rows_of_this_rank * N * D flop.  The symmetric forms (paths 1, 2) multiply a cyclic half of the tile
+        # 2 * rows_of_this_rank * N * D flop.  The symmetric forms (paths 1, 2, 3) multiply a cyclic half of the tile
         # pairs - self distances are bitwise symmetric - so they EXECUTE about half of it.
-        t_tiles = (n + 127) // 128
         flop_alg = 2.0 * rows_local * n * d
-        t_tiles = (n + 255) // 256 if knn_path == 3 else t_tiles
+        t_tiles = (n + 255) // 256 if knn_path == 3 else (n + 127) // 128
         knn_exec = ((t_tiles // 2 + 1) / t_tiles) if knn_path in (1, 2, 3) else 1.0
         try:                                                # PMC-derived HBM-side bytes per launch, recorded from profiles/
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
@@ -204,25 +287,29 @@ def main():
 
         def roof(kernel, path, ms, lps, exec_frac, entry, entry_ms):
             peak = peak_of[path]
-            achieved = flop_alg / (ms * 1e-3) / 1e12
-            return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            algorithmic = flop_alg / (ms * 1e-3) / 1e12
+            executed = algorithmic * exec_frac
+            # `frac` is the MATRIX-PIPE figure: flops the kernel really issues / time / peak.  The algorithmic rate (SURVEY
+            # 8(d) counts every (row, column) pair) is kept beside it; for the symmetric sweep it is about twice as high.
+            return {"bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak,
                     "traffic": traffic_table.get(kernel) if world == 1 else None,
                     "kernel": kernel, "mfma": mfma_of[path], "entry_point": entry, "launch_ms": ms, "launches_per_step": lps,
-                    "entry_ms": entry_ms, "flop_per_launch": flop_alg, "executed_flop_per_launch": flop_alg * exec_frac,
-                    "executed_frac": flop_alg * exec_frac / (ms * 1e-3) / 1e12 / peak}
+                    "entry_ms": entry_ms, "executed_flop_per_launch": flop_alg * exec_frac,
+                    "algorithmic_flop_per_launch": flop_alg, "algorithmic_tflops": algorithmic,
+                    "algorithmic_frac": algorithmic / peak}
 
         knn_roof = roof(knn_kernel, knn_path, knn_ms, knn_lps, knn_exec, knn_entry, kms / kcalls)
         cross_roof = roof(cross_kernel, cross_path, cross_ms, cross_lps, 1.0, "am_prdc_counts_f32", cms / ccalls)
         # dominant kernel = the one with the larger share of the step
         main, other = (knn_roof, cross_roof) if knn_ms * knn_lps >= cross_ms * cross_lps else (cross_roof, knn_roof)
         main["note"] = (
-            "achieved = algorithmic flops 2*rows*N*D of one launch / launch_ms (hipEvents around the kernel inside the "
-            "library, on its stream; compare rocprofv3's average for it); peak = dense MFMA peak of the instruction the "
-            "kernel issues.  Path 2/3 kernels are FILTERS: they evaluate every pair on the f16 matrix cores with a proven "
-            "error bound and queue the few pairs the bound cannot decide; those are re-evaluated with the exact f32 fmaf "
-            "chain (verify kernels, listed under other_kernels), so the outputs are bit-identical to the exact f32 "
-            "kernels'.  executed_frac = executed flops / launch_ms / peak is the MFMA-pipe utilisation (the symmetric "
-            "sweep executes ~half of the algorithmic pairs).")
+            "achieved = flops the kernel EXECUTES per launch (the symmetric k-NN sweep multiplies the cyclic half of the "
+            "tile pairs) / launch_ms (hipEvents around the kernel inside the library, on its stream; compare rocprofv3's "
+            "average for it); peak = dense MFMA peak of the instruction the kernel issues; algorithmic_* counts every "
+            "(row, column) pair as SURVEY 8(d) does.  Path 2/3 kernels are FILTERS: they evaluate every pair on the f16 "
+            "matrix cores with a proven error bound and queue the few pairs the bound cannot decide; those are "
+            "re-evaluated with the exact f32 fmaf chain (verify kernels, listed under other_kernels), so the outputs are "
+            "bit-identical to the exact f32 kernels'.")
         verify = {}
         for name, label in (("knn_verify", "knn_fast_verify_kernel"), ("cross_verify", "cross_verify_kernel")):
             launches, total = clocks[name]
@@ -245,18 +332,25 @@ def main():
             "config": {"workload": f"FAD+KD+PRDC(k={k}) cold evaluate() of 2x{n} CLAP-{d} f32 embedding sets resident in HBM "
                                    "(BASELINE.json configs[2])",
                        "n_ref": n, "n_cand": n, "dim": d, "nearest_k": k, "kd_subsets": 100, "kd_subset_size": 1000,
+                       "inputs": ("numpy PCG64 seed %d: reference randn, candidate randn*1.05+0.05" % gi.BENCH_SEED) if args.data == "randn"
+                                 else ("numpy PCG64 seed %d: unit-norm rows of randn+0.5 / randn+0.55 (CLAP-shaped)" % gi.BENCH_SEED),
                        "sharding": f"rows/{world}",
                        "arithmetic": "results are the exact f32 values (bit-identical to the f32-MFMA kernels); the PRDC tile "
                                      "kernels pre-filter on f16 MFMA with f32 accumulation where am_knn_path/am_prdc_path >= 2"},
             "roofline": main,
             "other_tile_kernel": other,
             "other_kernels": verify,
+            "filter": dict(per_step(filter_stats, args.steps), knn_path=knn_path, prdc_path=cross_path,
+                           note="per step: pairs the f16 filters queued / pairs evaluated exactly / rows or calls that fell "
+                                "back to the exact f32 kernels (am_filter_stats_enable)"),
             "kernels_ms_per_call": {name: tot / c for name, (c, tot) in sorted(kern.items())},
             "kernels_calls_per_step": {name: c / args.steps for name, (c, tot) in sorted(kern.items())},
-            "kernels_note": ("event-to-event time of each C-ABI entry point on its own stream; am_frechet_f64 runs from a helper "
-                             "thread on a side stream UNDER the PRDC kernels, so its own timeline is stretched (0.86 ms alone) and "
-                             "overlaps the others - the entries do not add up to ms_per_step"),
+            "kernels_note": ("event-to-event time of each C-ABI entry point on its own stream; am_frechet_enqueue_f64 only "
+                             "enqueues the solve on a side stream (it runs UNDER the PRDC kernels), so its entry is the "
+                             "enqueue time and the entries do not add up to ms_per_step"),
             "result": result,
+            "result_check": check_against_fixture(result, args.data, n, d, k),
+            "variants": variants,
         }
         if world == 1:
             out["warm"] = warm_evaluate(am, ref, cand, k, max(1, min(args.steps, 3)))
@@ -266,6 +360,85 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def per_step(stats, steps):
+    return {key: value / steps for key, value in stats.items()}
+
+
+def run_e2e(args, am, dev, world, rank, fence):
+    """BASELINE configs[4] shape: (context, stem) audio pairs -> embedder forward on this rank's GPU -> device-side
+    aggregation -> APA + FAD, one process per GPU with the statistics merged across ranks (distributed.merged_stats).
+    The embedder is `SyntheticEmbedder` (LAION-CLAP and its checkpoint cannot be installed here) - a torch module with
+    the embedder protocol; its forward is PyTorch-ROCm code and NOT part of the measured claim.  Reported: whole
+    add_reference + evaluate wall time, and the aggregation + metric share (everything but host audio synthesis/mixing
+    and the embedder forward)."""
+    import random
+    from audio_metrics_amd.embedders import SyntheticEmbedder
+    sr, seconds = 48000, 5
+    pairs = args.pairs
+    lo, hi = pairs * rank // world, pairs * (rank + 1) // world
+    rng = np.random.default_rng(1000 + rank)
+
+    def audio(count):
+        for _ in range(count):
+            yield rng.standard_normal((sr * seconds, 2)).astype(np.float32)
+
+    clock = {"forward": 0.0}
+
+    class Timed(SyntheticEmbedder):
+        def forward(self, data, sr=None):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            out = super().forward(data, sr)
+            torch.cuda.synchronize(dev)
+            clock["forward"] += time.perf_counter() - t0
+            return out
+
+    embedder = Timed(dim=512, sr=sr, device=dev)
+    group = dist.group.WORLD if world > 1 else None
+    metric = am.AudioMetrics(metrics=["apa", "fad"], embedder=embedder, mix_function="P0", device_indices=[dev.index],
+                             win_dur=float(seconds), process_group=group)
+    random.seed(1234 + rank)
+    host = {"t": 0.0}
+
+    def timed_source(count):
+        it = audio(count)
+        while True:
+            t0 = time.perf_counter()
+            try:
+                item = next(it)
+            except StopIteration:
+                return
+            host["t"] += time.perf_counter() - t0
+            yield item
+
+    fence()
+    t0 = time.perf_counter()
+    metric.add_reference(timed_source(hi - lo))
+    result = metric.evaluate(timed_source(hi - lo))
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, clock["forward"], host["t"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, fwd, synth = (float(v) for v in t.tolist())
+    else:
+        fwd, synth = clock["forward"], host["t"]
+    if rank == 0:
+        windows = 2 * pairs                       # reference + candidate pairs, one 5 s window each
+        print(json.dumps({
+            "metric": "APA+FAD end-to-end pairs/sec (audio -> embedder -> device aggregation -> metrics)",
+            "value": windows / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": 1, "warmup": 0,
+            "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"APA+FAD end-to-end, {pairs} reference + {pairs} candidate pairs of ({sr * seconds}, 2) f32 "
+                                   "randn audio at 48 kHz (BASELINE.json configs[4] shape, reduced pair count), "
+                                   "SyntheticEmbedder (NOT CLAP: laion_clap and its checkpoint are not installable here)",
+                       "pairs_per_side": pairs, "sharding": f"pairs/{world}", "mix_function": "P0"},
+            "breakdown_s": {"total": elapsed, "embedder_forward": fwd, "host_audio_synthesis": synth,
+                            "mix_batch_aggregate_metrics": elapsed - fwd - synth},
+            "result": result}), flush=True)
 
 
 if __name__ == "__main__":

@@ -83,14 +83,29 @@ int am_stats_merge_f64(int64_t n1, const double* mean1, const double* cov1,
  *   tr sqrt by a coupled Newton-Schulz iteration in f64 on the f64 matrix
  *   cores (the reference uses LAPACK eigvals); stops when |I - ZY|_F <
  *   tol*sqrt(D), when the trace stops growing (rank-deficient inputs) or at
- *   max_iter.  SYNCHRONISES `stream`.  out_host (HOST pointer, 4 doubles):
- *   { fd, tr_sqrt, iterations, final residual }.
+ *   max_iter.  The stopping rule runs on the device; the solve is a stream-
+ *   ordered chain of kernels with no host polling.
+ *   am_frechet_f64          enqueues blocks of am_frechet_first_block() iterations until the device-side stop code
+ *                           is set (one block for well-conditioned inputs) and SYNCHRONISES `stream` once per block.
+ *                           out_host (HOST pointer, 4 doubles): { fd, tr_sqrt, iterations, final residual }.
+ *   am_frechet_enqueue_f64  the asynchronous building block: enqueues iterations [first_iter, first_iter + n_iter)
+ *                           (first_iter == 0 starts the solve; the state lives in `ws`, which the caller keeps alive
+ *                           and passes again to continue) and a final kernel that writes out_dev (DEVICE pointer, 5
+ *                           doubles): { fd, tr_sqrt, iterations, residual, stop code } - stop code 0 = still running
+ *                           (enqueue the next block), 1 converged, 2 trace stalled, 3 zero product, 4 non-finite.
+ *                           Never synchronises: a caller can put the solve on a side stream under other work and read
+ *                           out_dev when it needs the value.
  * ------------------------------------------------------------------------- */
 size_t am_frechet_workspace_bytes(int D);
 int am_frechet_f64(const double* mu_x, const double* cov_x,
                    const double* mu_y, const double* cov_y, int D,
                    int max_iter, double tol, double* out_host,
                    void* ws, size_t ws_bytes, am_stream_t stream);
+int am_frechet_first_block(void);
+int am_frechet_enqueue_f64(const double* mu_x, const double* cov_x,
+                           const double* mu_y, const double* cov_y, int D,
+                           int first_iter, int n_iter, int max_iter, double tol, double* out_dev,
+                           void* ws, size_t ws_bytes, am_stream_t stream);
 
 /* A11 APA scalar combination (host arithmetic)  reference: apa.py:22-32 */
 double am_apa_f64(double d_y_x, double d_y_xp, double d_x_xp);
@@ -215,6 +230,19 @@ int am_kernel_clock_enable(int on);
 int am_kernel_clock_read(int kernel, int64_t* launches, double* total_ms);
 int am_knn_path(int64_t N, int64_t M, int D, int k, int self);
 int am_prdc_path(int64_t Nr, int64_t Nc, int D);
+
+/* ---- optional filter statistics (benchmark support) -------------------------------------------------
+ * What the f16 filter passes leave for the exact kernels is data dependent.  A caller hands the library a
+ * zero-initialised DEVICE buffer of AM_FILTER_STATS_SLOTS int64 (on the current device; NULL switches the feature
+ * off); every filter-form call of am_knn_radii_f32 / am_knn_sym_part_f32 / am_prdc_counts_f32 then ends with a one-
+ * workgroup kernel that ADDS to it, stream-ordered, no synchronisation:
+ *   [0] k-NN calls           [1] entries queued by the sweep (both directions)   [2] of those via the spill queue
+ *   [3] pairs evaluated exactly (after pruning)           [4] rows recomputed by the exact fix-up kernel
+ *   [5] membership calls     [6] pairs queued            [7] of those via the overflow queue
+ *   [8] membership calls handed to the exact kernel (queues overflowed / operands not scalable)
+ * The caller reads and clears the buffer itself. */
+#define AM_FILTER_STATS_SLOTS 16
+int am_filter_stats_enable(int64_t* device_slots);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,25 @@ PRDC_CASES = {
     "unit_8300_8200_128_k10": ("unit", 48, 8300, 8200, 128, 10),
 }
 
+# Sets large enough for the production f16 filter kernels (am_knn_path == am_prdc_path == 3: >= 32768 rows) and
+# still small enough for the reference's N x N formulation to fit this container's RAM (26 GB at 40k rows).
+PRDC_LARGE_CASES = {
+    "randn_33000_128_k5": ("randn", 141, 33000, 33000, 128, 5),
+    "randn_33000_128_k10": ("randn", 141, 33000, 33000, 128, 10),
+    "unit_33000_35000_128_k5": ("unit", 142, 33000, 35000, 128, 5),
+    "unit_33000_35000_128_k10": ("unit", 142, 33000, 35000, 128, 10),
+    "randn_40000_512_k5": ("randn", 143, 40000, 40000, 512, 5),
+    "unit_40000_512_k10": ("unit", 144, 40000, 40000, 512, 10),
+}
+
+# The headline benchmark's inputs (bench.py): numpy-seeded so that the CPU oracle can reproduce them.
+BENCH_SEED = 2026
+
+
+def bench_pair(kind, n, d, seed=BENCH_SEED):
+    """(reference, candidate) of bench.py: 'randn'  or 'clap' (unit-norm rows, offsets 0.5 / 0.55)."""
+    return pair("unit" if kind == "clap" else "randn", seed, n, n, d)
+
 
 # ---- end-to-end (A12/A13) case: synthetic (context, stem) pairs + a host-side numpy embedder
 E2E = dict(sr=16000, win_dur=1.0, n_ref=60, n_cand=50, seconds=3, dim=24, seed=77, random_seed=1234)

@@ -139,6 +139,50 @@ def gen_prdc():
     np.savez_compressed(os.path.join(HERE, "prdc.npz"), **out)
 
 
+def gen_prdc_large():
+    """Reference runs at sizes the HIP path serves with its production f16 filter kernels (>= 32768 rows).
+    Per case: radii, integer column counts, row flags and the four values of the reference's own prdc()."""
+    import gc
+    import time
+    out = {"versions": VERSIONS}
+    for name, (kind, seed, nr, nc, d, k) in gi.PRDC_LARGE_CASES.items():
+        t0 = time.time()
+        ref, cand = gi.pair(kind, seed, nr, nc, d)
+        a, b = amd(ref), amd(cand)
+        res = r_prdc.prdc(a, b, k)
+        for key, v in res.items():
+            out[f"{name}/{key}"] = v
+        r_ref, r_cand = a.radii[f"radii_{k}"], b.radii[f"radii_{k}"]
+        out[f"{name}/r_ref"] = r_ref.numpy()
+        out[f"{name}/r_cand"] = r_cand.numpy()
+        gc.collect()
+        dist = torch.cdist(a.embeddings, b.embeddings)
+        out[f"{name}/col_count"] = (dist < r_ref[:, None]).sum(dim=0).numpy().astype(np.int32)
+        out[f"{name}/row_any"] = (dist < r_cand[None, :]).any(dim=1).numpy()
+        out[f"{name}/row_cover"] = (dist.min(dim=1)[0] < r_ref).numpy()
+        del dist, a, b
+        gc.collect()
+        print("prdc_large", name, res, f"{time.time() - t0:.0f}s", flush=True)
+    np.savez_compressed(os.path.join(HERE, "prdc_large.npz"), **out)
+
+
+def gen_bench():
+    """oracle.prdc_blocked (row blocks of the reference's torch calls) on bench.py's own 2 x 100k x 512 inputs: the
+    reference's N x N formulation needs 164 GB there.  Stores the integer totals behind the four values."""
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import oracle
+    out = {"versions": VERSIONS}
+    for kind, k in (("randn", 5), ("clap", 10)):
+        t0 = time.time()
+        ref, cand = gi.bench_pair(kind, 100000, 512)
+        res = oracle.prdc_blocked(ref, cand, k, block=4096)
+        for key, v in res.items():
+            out[f"{kind}_k{k}/{key}"] = v
+        print("bench", kind, k, res, f"{time.time() - t0:.0f}s", flush=True)
+    np.savez_compressed(os.path.join(HERE, "bench_prdc.npz"), **out)
+
+
 def gen_apa():
     out = {"versions": VERSIONS}
     table = [(1.0, 2.0, 3.0), (2.0, 1.0, 3.0), (1.0, 5.0, 3.0), (5.0, 1.0, 3.0), (-1.0, 2.0, 3.0),

@@ -163,16 +163,22 @@ def test_bench_two_rank_launch(rows, dim):
     assert abs(out2["result"]["kernel_distance_mean"] - out1["result"]["kernel_distance_mean"]) <= 1e-9
 
 
-def test_overlapped_frechet_solve_gives_the_same_result(monkeypatch):
-    """evaluate_sharded runs the Frechet solve from a helper thread on a side stream under the PRDC kernels; switching
-    the overlap off must not change a single bit of any metric."""
+def test_overlapped_frechet_solve_gives_the_same_result():
+    """evaluate_sharded enqueues the Frechet solve on a side stream under the PRDC kernels (am_frechet_enqueue_f64: no
+    host polling, no helper thread); the synchronous entry point on the main stream must give the same bits, and the
+    other metrics must not change either."""
+    from audio_metrics_amd import hip_ops as ops
     from audio_metrics_amd.distributed import evaluate_sharded
     ref, cand = gi.pair("randn", 41, 6000, 5500, 96)
     dev = torch.device("cuda:0")
     r, c = torch.as_tensor(ref).to(dev), torch.as_tensor(cand).to(dev)
     with_overlap = [evaluate_sharded(r, c, nearest_k=3, kid_subsets=6, kid_subset_size=500) for _ in range(3)]
-    monkeypatch.setenv("AM_FAD_OVERLAP", "0")
-    without = evaluate_sharded(r, c, nearest_k=3, kid_subsets=6, kid_subset_size=500)
+
+    class SyncOps:                                  # the same library without the asynchronous entry point
+        def __getattr__(self, name):
+            if name == "frechet_async":
+                raise AttributeError(name)
+            return getattr(ops, name)
+    without = evaluate_sharded(r, c, nearest_k=3, kid_subsets=6, kid_subset_size=500, ops=SyncOps())
     for res in with_overlap:
         assert res == without
-

@@ -28,6 +28,15 @@ def dev(x):
     return torch.as_tensor(x).to("cuda:0")
 
 
+def knob_env(base, knobs):
+    """Environment of an A/B subprocess: development knobs exist only in the -DAM_DEV_KNOBS build of the library
+    (libaudio_metrics_hip_dev.so, selected with AM_HIP_LIBRARY=dev); a run WITHOUT knobs exercises the shipped library."""
+    env = dict(base, **knobs)
+    if any(key.startswith("AM_") for key in knobs):
+        env["AM_HIP_LIBRARY"] = "dev"
+    return env
+
+
 def amd_of(am, x, store=True, splits=None):
     d = am.AudioMetricsData(store)
     t = dev(x)
@@ -300,7 +309,7 @@ def test_knn_symmetric_fallbacks_agree():
     for extra in ({"AM_KNN_SYM_MIN_ROWS": "100000000"}, {}, {"AM_KNN_SYM_CAP": "2"}, {"AM_KNN_SYM_QCAP": "16"},
                   fast, dict(fast, AM_KNN_SYM_CAP="2"), dict(fast, AM_KNN_SYM_QCAP="16"),
                   dict(fast, AM_KNN_SYM_QCAP="16", AM_KNN_FAST_OVCAP="64")):
-        res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_knn.py")], env=dict(base, **extra),
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_knn.py")], env=knob_env(base, extra),
                              capture_output=True, text=True, timeout=600)
         m = re.search(r"radii sha1 ([0-9a-f]+)", res.stdout)
         assert m, res.stdout + res.stderr
@@ -323,7 +332,7 @@ def test_cross_kernel_schedules_agree():
     for extra in ({"AM_ENGINE_VARIANT": "0", "AM_PRDC_FAST": "0"}, {"AM_ENGINE_VARIANT": "35", "AM_PRDC_FAST": "0"},
                   {"AM_ENGINE_VARIANT": "99", "AM_PRDC_FAST": "0"}, {}):
         res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_cross.py")],
-                             env=dict(base, **extra), capture_output=True, text=True, timeout=600)
+                             env=knob_env(base, extra), capture_output=True, text=True, timeout=600)
         m = re.search(r"sha1 ([0-9a-f]+)", res.stdout)
         assert m, res.stdout + res.stderr
         outs.append(m.group(1))
@@ -342,7 +351,7 @@ def test_knn_filter_path_bit_identical_at_production_sizes(rows, dim, k):
     base = dict(os.environ, AB_ROWS=str(rows), AB_DIM=str(dim), AB_K=str(k), AB_REPS="1")
     outs = []
     for extra in ({"AM_KNN_FAST": "0"}, {}):
-        res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_knn.py")], env=dict(base, **extra),
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_knn.py")], env=knob_env(base, extra),
                              capture_output=True, text=True, timeout=600)
         m = re.search(r"radii sha1 ([0-9a-f]+)", res.stdout)
         assert m, res.stdout + res.stderr
@@ -367,7 +376,7 @@ def test_filter_paths_bit_identical_on_adversarial_data(data):
                                ("ab_cross.py", r"sha1 ([0-9a-f]+)", {"AM_PRDC_FAST": "0", "AM_KNN_FAST": "0"})):
         outs = []
         for extra in (off, {}):
-            res = subprocess.run([sys.executable, os.path.join(root, "tools", tool)], env=dict(base, **extra),
+            res = subprocess.run([sys.executable, os.path.join(root, "tools", tool)], env=knob_env(base, extra),
                                  capture_output=True, text=True, timeout=900)
             m = re.search(pattern, res.stdout)
             assert m, res.stdout + res.stderr
@@ -388,7 +397,7 @@ def test_membership_filter_survives_undecidable_inputs():
                 AB_WANT_MIN="1")
     outs = []
     for extra in ({"AM_PRDC_FAST": "0", "AM_KNN_FAST": "0"}, {}):
-        res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_cross.py")], env=dict(base, **extra),
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_cross.py")], env=knob_env(base, extra),
                              capture_output=True, text=True, timeout=900)
         m = re.search(r"sha1 ([0-9a-f]+)", res.stdout)
         assert m, res.stdout[-500:] + res.stderr[-1500:]
@@ -565,3 +574,56 @@ def test_kernel_clock_counts_tile_kernel_launches(am):
             ops.kernel_clock_read(7)
     finally:
         ops.kernel_clock_enable(False)
+
+
+# ----------------------------------------------------------------- regression tests for reviewer findings
+def test_single_row_recompute_then_merge(am):
+    """add(1 row) -> recompute_stats() leaves the reference's (1, 1) zero covariance (data.py:56); the next merge must
+    treat it as a D x D zero matrix, not hand an 8-byte buffer to a kernel that writes D*D doubles."""
+    import oracle
+    x = gi.randn(71, 40, 24, 1.2, 0.3)
+    d = am.AudioMetricsData(True)
+    o = oracle.OracleData(True)
+    d.add(dev(x[:1])); o.add(torch.as_tensor(x[:1]))
+    d.recompute_stats(); o.recompute_stats()
+    assert tuple(d.cov.shape) == (1, 1)
+    d.add(dev(x[1:33])); o.add(torch.as_tensor(x[1:33]))
+    other = am.AudioMetricsData(True)
+    other.add(dev(x[33:]))
+    d += other
+    o.merge(oracle.OracleData(True).add(torch.as_tensor(x[33:])))
+    assert d.n == o.n == 40 and tuple(d.cov.shape) == (24, 24)
+    np.testing.assert_allclose(d.mean.cpu().numpy(), o.mean.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(d.cov.cpu().numpy(), o.cov.numpy(), rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        am.hip_ops.stats_merge(3, d.mean, torch.zeros((1, 1), dtype=torch.float64, device="cuda:0"), 2, d.mean, d.cov)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_kernels_run_on_the_tensors_device_not_the_current_one(am):
+    """Tensors on cuda:1 while cuda:0 is the thread's current device: every entry point must launch on cuda:1's stream."""
+    from oracle import exact
+    torch.cuda.set_device(0)
+    x = gi.randn(72, 3000, 64)
+    y = gi.randn(73, 2500, 64, 1.1, 0.1)
+    a, b = am.AudioMetricsData(True, device="cuda:1"), am.AudioMetricsData(True, device="cuda:1")
+    a.add(torch.as_tensor(x).to("cuda:1"))
+    b.add(torch.as_tensor(y).to("cuda:1"))
+    assert a.cov.device.index == 1
+    res = am.prdc(a, b, 5)
+    want, _ = exact.prdc(x, y, 5)
+    assert res == want
+    assert abs(am.frechet_distance(a, b) - am.frechet_distance(a.to("cuda:0"), b.to("cuda:0"))) < 1e-9
+
+
+def test_frechet_enqueue_matches_blocking_call(am):
+    """am_frechet_enqueue_f64 (side stream, device-side stopping rule, no host polling) against am_frechet_f64, including
+    an ill-conditioned product that needs more than the first block of iterations."""
+    ops = am.hip_ops
+    for kind, d in (("randn", 128), ("decay", 128)):
+        ref, cand = gi.pair(kind, 81, 3000, 3000, d)
+        a, b = amd_of(am, cand, False), amd_of(am, ref, False)
+        sync = ops.frechet(a.mean, a.cov, b.mean, b.cov)
+        job = ops.frechet_async(a.mean, a.cov, b.mean, b.cov)
+        got = job.result()
+        assert got["fd"] == sync["fd"] and got["iters"] == sync["iters"], (kind, got, sync)

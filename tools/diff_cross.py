@@ -35,7 +35,7 @@ np.savez(sys.argv[1], col=col.cpu().numpy(), rany=rany.cpu().numpy(), rcov=rcov.
 out = {}
 for fast in ("0", "1"):
     fp = f"/tmp/diff_cross_{fast}.npz"
-    r = subprocess.run([sys.executable, "-c", CHILD, fp], env=dict(os.environ, AM_PRDC_FAST=fast), capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", CHILD, fp], env=dict(os.environ, AM_PRDC_FAST=fast, AM_HIP_LIBRARY="dev"), capture_output=True, text=True)
     if r.returncode != 0:
         print(r.stdout, r.stderr)
         sys.exit(1)

@@ -20,8 +20,8 @@ for case in range(n_cases):
     base = dict(os.environ, AB_ROWS=str(rows), AB_ROWS2=str(rows2), AB_DIM=str(dim), AB_K=str(k), AB_REPS="1", AB_DATA=data,
                 AB_SEED=str(rnd.randrange(1000)), AB_WANT_MIN=str(rnd.randrange(2)))
     line = f"case {case}: rows={rows}/{rows2} dim={dim} k={k} data={data} seed={base['AB_SEED']} want_min={base['AB_WANT_MIN']}"
-    for tool, pattern, off in (("ab_knn.py", r"radii sha1 ([0-9a-f]+)", {"AM_KNN_FAST": "0"}),
-                               ("ab_cross.py", r"sha1 ([0-9a-f]+)", {"AM_PRDC_FAST": "0", "AM_KNN_FAST": "0"})):
+    for tool, pattern, off in (("ab_knn.py", r"radii sha1 ([0-9a-f]+)", {"AM_KNN_FAST": "0", "AM_HIP_LIBRARY": "dev"}),
+                               ("ab_cross.py", r"sha1 ([0-9a-f]+)", {"AM_PRDC_FAST": "0", "AM_KNN_FAST": "0", "AM_HIP_LIBRARY": "dev"})):
         outs = []
         for extra in (off, {}):
             res = subprocess.run([sys.executable, os.path.join(root, "tools", tool)], env=dict(base, **extra),
