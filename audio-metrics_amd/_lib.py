@@ -63,7 +63,12 @@ _lib = None
 
 def library_path():
     """The shipped library; AM_HIP_LIBRARY=dev (tools and fallback-path tests only) selects the -DAM_DEV_KNOBS build."""
-    return DEV_LIB_PATH if os.environ.get("AM_HIP_LIBRARY") == "dev" else LIB_PATH
+    choice = os.environ.get("AM_HIP_LIBRARY", "")
+    if choice == "dev":
+        return DEV_LIB_PATH
+    if choice.endswith(".so"):                            # an experimental variant build (tools/ only)
+        return choice if os.path.isabs(choice) else os.path.join(os.path.dirname(LIB_PATH), choice)
+    return LIB_PATH
 
 
 def load():

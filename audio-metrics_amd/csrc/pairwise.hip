@@ -7,37 +7,13 @@
 // (torch.cdist's matmul form before the sqrt).  The reference's comparisons on
 // sqrt'ed values are reproduced exactly through per-row thresholds:
 //     sqrt_rn(d2) < R   <=>   d2 < T(R),  T(R) = min { t : sqrt_rn(t) >= R }.
-#include "am_common.h"
-#include "tile_engine.h"
-#include <stdlib.h>
+#include "pairwise_common.h"
 #include <algorithm>
 #include <vector>
 #include <cmath>
 #include <type_traits>
 
 namespace am {
-
-constexpr int EV_DEFAULT = EV_RSRC | EV_FRAGDB | EV_EARLY;   // the production schedule of the tile engine
-
-// Scaled f16 copies of the filter passes (pairwise_fast.h): a matrix whose largest |element| has the f32 bit pattern
-// `maxabs_bits` is multiplied by 2^half_scale_exp so that the largest element lands in [2^13, 2^14) - far from
-// f16 overflow (65504), and small elements far from f16's subnormal range.  Powers of two: the scaling is exact.
-__device__ __forceinline__ int half_scale_exp(unsigned maxabs_bits) {
-    if (maxabs_bits == 0u) return 0;
-    const int e = (int)((maxabs_bits >> 23) & 255u) - 127;          // floor(log2(max |x|)) for a normal maximum
-    const int ex = 13 - e;
-    return ex < -60 ? -60 : (ex > 60 ? 60 : ex);
-}
-__device__ __forceinline__ bool half_scale_ok(unsigned maxabs_bits) {   // finite, and the exponent was not clamped
-    if (maxabs_bits == 0u) return true;
-    const int e = (int)((maxabs_bits >> 23) & 255u) - 127;
-    return e != 128 && e != -127 && 13 - e >= -60 && 13 - e <= 60;
-}
-// the factor that turns the dot product of two scaled copies into -2 <x, y>:  -2 * 2^-(ex + ey)   (exact)
-__device__ __forceinline__ float half_unscale(unsigned maxabs_bits_x, unsigned maxabs_bits_y) {
-    const int s = half_scale_exp(maxabs_bits_x) + half_scale_exp(maxabs_bits_y);
-    return -2.f * __uint_as_float((unsigned)(127 - s) << 23);
-}
 
 // ------------------------------------------------------------------ row norms
 // |x|^2 in f32 with a fixed order (mirrored by oracle/exact_c): lane l of the
@@ -395,62 +371,6 @@ struct KnnSymEpilogue {
         }
     }
 };
-
-// Work item of the symmetric sweep (shared by the exact kernel and the f16 filter kernel of pairwise_fast.h).
-struct SymWork {
-    int W;              // column-tile window
-    int64_t pb;         // row block
-    int64_t qa;         // first Q tile of this block inside the window
-    int ntiles;         // 0: nothing of this window belongs to this block / this rank
-};
-
-__device__ __forceinline__ SymWork sym_work(int64_t T, int win_tiles, int nwin, int per_win, int part, int nparts) {
-    // Work item = (column-tile WINDOW, row block) over the CYCLIC HALF-RANGE pairing: block pb owns the tile
-    // pairs (pb, q) with (q - pb) mod T in 0 .. T/2.  All workgroups in flight stream the same window of Q
-    // tiles (L2 / Infinity-Cache reuse) with different row blocks.  Windows are swept in DESCENDING order: the
-    // lane-local tiles of block pb lie in the windows from the one holding pb upwards (plus, for the upper
-    // half of the blocks, a wrapped piece at the bottom), so when the window holding pb is reached - the one
-    // in which other blocks generate the mirrored candidates for pb's rows - pb has already published a
-    // bound over most of its half-range.
-    const int W = nwin - 1 - (int)(blockIdx.x / per_win);
-    const int64_t q0 = (int64_t)W * win_tiles;
-    const int64_t q1 = (q0 + win_tiles < T) ? q0 + win_tiles : T;
-    // Within a window, the row blocks that own ALL of its tiles (equal-sized work items, which therefore walk
-    // the window's Q tiles in lockstep and share them through L2) are issued first, the partial ones (blocks
-    // inside the window and blocks whose half-range ends inside it) last.
-    int r;
-    {
-        const int e = (int)(blockIdx.x % per_win);
-        const int wlen = (int)(q1 - q0);
-        const int full_lo = wlen - 1, full_hi = (int)(T / 2);          // r in [full_lo, full_hi]: pb <= q0, pb+noff >= q1
-        const int nfull = full_hi >= full_lo ? full_hi - full_lo + 1 : 0;
-        if (e < nfull) r = full_lo + e;
-        else if (e - nfull < full_lo) r = e - nfull;
-        else r = e + 1 - full_lo + full_lo;                            // = e + 1 ... beyond the full range
-        if (e >= nfull + full_lo) r = full_hi + 1 + (e - nfull - full_lo);
-    }
-    int64_t pb = (q1 - 1 - r) % T;
-    if (pb < 0) pb += T;
-    // offsets 0 .. T/2; for even T the antipodal offset belongs to the lower-numbered block only
-    int64_t noff = T / 2 + 1;
-    if ((T % 2) == 0 && pb >= T / 2) noff = T / 2;
-    // tiles q of the window with (q - pb) mod T < noff form one contiguous piece (window << T/2)
-    int64_t qa = pb > q0 ? pb : q0, qb = (pb + noff < q1) ? pb + noff : q1;          // q >= pb
-    if (qa >= qb) {                                                                   // wrapped: q < pb
-        qa = q0;
-        qb = (pb + noff - T < q1) ? pb + noff - T : q1;
-    }
-    const int ntiles = qb > qa ? (int)(qb - qa) : 0;
-    // multi-GPU: rank `part` of `nparts` owns the CONTIGUOUS range of row blocks with floor(pb*nparts/T) == part
-    // (see am_knn_sym_part_f32).  Not pb mod nparts: consecutive blockIdx map to consecutive pb, and ownership
-    // by residue would put every owned workgroup of a window on the same XCD (blockIdx % 8).
-    SymWork w;
-    w.W = W;
-    w.pb = pb;
-    w.qa = qa;
-    w.ntiles = (ntiles == 0 || (int)(pb * nparts / T) != part) ? 0 : ntiles;
-    return w;
-}
 
 template <int KCAP, bool KTAIL>
 __global__ void __launch_bounds__(ENGINE_THREADS, 2)
@@ -853,23 +773,6 @@ __global__ void __launch_bounds__(256) prdc_reduce_kernel(const int32_t* __restr
 }
 
 // ------------------------------------------------------------------ host side
-// Development knobs exist only in the A/B build (-DAM_DEV_KNOBS -> libaudio_metrics_hip_dev.so, loaded by the tools and
-// by the tests that force fallback paths).  In the shipped library every knob is its default, a compile-time constant:
-// no getenv, path selection is a pure function of the shapes, and the older engine schedules are not instantiated.
-#ifdef AM_DEV_KNOBS
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-static int engine_variant() {
-    static const int v = env_int("AM_ENGINE_VARIANT", EV_DEFAULT);
-    return v;
-}
-#else
-static constexpr int env_int(const char*, int dflt) { return dflt; }
-static constexpr int engine_variant() { return EV_DEFAULT; }
-#endif
-
 static int choose_chunks(int64_t p_rows, int64_t q_rows) {
     const int64_t row_blocks = ceil_div(p_rows, TB);
     const int64_t q_tiles = ceil_div(q_rows, TB);
@@ -993,7 +896,6 @@ using namespace am;
 
 // ---- k-NN planning (shared by the workspace query and the launcher) ---------------------------------
 namespace am { static bool knn_fast_enabled(int64_t N, int D); }   // pairwise_fast.h
-constexpr int KNN_WIDE_MAX_KCAP = 11;                     // list registers beside 128 accumulators: k <= 10 on the wide engine
 struct KnnPlan {
     int tile_rows;              // 128, or 256 when the f16 filter sweep runs on the wide engine
     bool sym;

@@ -1,0 +1,273 @@
+// Helpers shared by the two translation units of the PRDC path: pairwise.hip (exact f32 kernels, the 128-row f16 filter
+// kernels and every host entry point) and pairwise_wide.hip (the 256 x 256 f16 filter kernels of wide_engine.h, built
+// separately so that the two compile in parallel).
+#pragma once
+#include "am_common.h"
+#include "tile_engine.h"
+#include <stdlib.h>
+
+namespace am {
+
+constexpr int EV_DEFAULT = EV_RSRC | EV_FRAGDB | EV_EARLY;   // the production schedule of the tile engine
+constexpr int WIDE_TILE_ROWS = 256;                          // tile rows of the wide engine (wide_engine.h: WTB)
+
+// Development knobs exist only in the A/B build (-DAM_DEV_KNOBS -> libaudio_metrics_hip_dev.so, loaded by the tools and
+// by the tests that force fallback paths).  In the shipped library every knob is its default, a compile-time constant:
+// no getenv, path selection is a pure function of the shapes, and the older engine schedules are not instantiated.
+#ifdef AM_DEV_KNOBS
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static int engine_variant() {
+    static const int v = env_int("AM_ENGINE_VARIANT", EV_DEFAULT);
+    return v;
+}
+#else
+static constexpr int env_int(const char*, int dflt) { return dflt; }
+static constexpr int engine_variant() { return EV_DEFAULT; }
+#endif
+
+
+// Scaled f16 copies of the filter passes (pairwise_fast.h): a matrix whose largest |element| has the f32 bit pattern
+// `maxabs_bits` is multiplied by 2^half_scale_exp so that the largest element lands in [2^13, 2^14) - far from
+// f16 overflow (65504), and small elements far from f16's subnormal range.  Powers of two: the scaling is exact.
+__device__ __forceinline__ int half_scale_exp(unsigned maxabs_bits) {
+    if (maxabs_bits == 0u) return 0;
+    const int e = (int)((maxabs_bits >> 23) & 255u) - 127;          // floor(log2(max |x|)) for a normal maximum
+    const int ex = 13 - e;
+    return ex < -60 ? -60 : (ex > 60 ? 60 : ex);
+}
+__device__ __forceinline__ bool half_scale_ok(unsigned maxabs_bits) {   // finite, and the exponent was not clamped
+    if (maxabs_bits == 0u) return true;
+    const int e = (int)((maxabs_bits >> 23) & 255u) - 127;
+    return e != 128 && e != -127 && 13 - e >= -60 && 13 - e <= 60;
+}
+// the factor that turns the dot product of two scaled copies into -2 <x, y>:  -2 * 2^-(ex + ey)   (exact)
+__device__ __forceinline__ float half_unscale(unsigned maxabs_bits_x, unsigned maxabs_bits_y) {
+    const int s = half_scale_exp(maxabs_bits_x) + half_scale_exp(maxabs_bits_y);
+    return -2.f * __uint_as_float((unsigned)(127 - s) << 23);
+}
+
+
+// Work item of the symmetric sweep (shared by the exact kernel and the f16 filter kernel of pairwise_fast.h).
+struct SymWork {
+    int W;              // column-tile window
+    int64_t pb;         // row block
+    int64_t qa;         // first Q tile of this block inside the window
+    int ntiles;         // 0: nothing of this window belongs to this block / this rank
+};
+
+__device__ __forceinline__ SymWork sym_work(int64_t T, int win_tiles, int nwin, int per_win, int part, int nparts) {
+    // Work item = (column-tile WINDOW, row block) over the CYCLIC HALF-RANGE pairing: block pb owns the tile
+    // pairs (pb, q) with (q - pb) mod T in 0 .. T/2.  All workgroups in flight stream the same window of Q
+    // tiles (L2 / Infinity-Cache reuse) with different row blocks.  Windows are swept in DESCENDING order: the
+    // lane-local tiles of block pb lie in the windows from the one holding pb upwards (plus, for the upper
+    // half of the blocks, a wrapped piece at the bottom), so when the window holding pb is reached - the one
+    // in which other blocks generate the mirrored candidates for pb's rows - pb has already published a
+    // bound over most of its half-range.
+    const int W = nwin - 1 - (int)(blockIdx.x / per_win);
+    const int64_t q0 = (int64_t)W * win_tiles;
+    const int64_t q1 = (q0 + win_tiles < T) ? q0 + win_tiles : T;
+    // Within a window, the row blocks that own ALL of its tiles (equal-sized work items, which therefore walk
+    // the window's Q tiles in lockstep and share them through L2) are issued first, the partial ones (blocks
+    // inside the window and blocks whose half-range ends inside it) last.
+    int r;
+    {
+        const int e = (int)(blockIdx.x % per_win);
+        const int wlen = (int)(q1 - q0);
+        const int full_lo = wlen - 1, full_hi = (int)(T / 2);          // r in [full_lo, full_hi]: pb <= q0, pb+noff >= q1
+        const int nfull = full_hi >= full_lo ? full_hi - full_lo + 1 : 0;
+        if (e < nfull) r = full_lo + e;
+        else if (e - nfull < full_lo) r = e - nfull;
+        else r = e + 1 - full_lo + full_lo;                            // = e + 1 ... beyond the full range
+        if (e >= nfull + full_lo) r = full_hi + 1 + (e - nfull - full_lo);
+    }
+    int64_t pb = (q1 - 1 - r) % T;
+    if (pb < 0) pb += T;
+    // offsets 0 .. T/2; for even T the antipodal offset belongs to the lower-numbered block only
+    int64_t noff = T / 2 + 1;
+    if ((T % 2) == 0 && pb >= T / 2) noff = T / 2;
+    // tiles q of the window with (q - pb) mod T < noff form one contiguous piece (window << T/2)
+    int64_t qa = pb > q0 ? pb : q0, qb = (pb + noff < q1) ? pb + noff : q1;          // q >= pb
+    if (qa >= qb) {                                                                   // wrapped: q < pb
+        qa = q0;
+        qb = (pb + noff - T < q1) ? pb + noff - T : q1;
+    }
+    const int ntiles = qb > qa ? (int)(qb - qa) : 0;
+    // multi-GPU: rank `part` of `nparts` owns the CONTIGUOUS range of row blocks with floor(pb*nparts/T) == part
+    // (see am_knn_sym_part_f32).  Not pb mod nparts: consecutive blockIdx map to consecutive pb, and ownership
+    // by residue would put every owned workgroup of a window on the same XCD (blockIdx % 8).
+    SymWork w;
+    w.W = W;
+    w.pb = pb;
+    w.qa = qa;
+    w.ntiles = (ntiles == 0 || (int)(pb * nparts / T) != part) ? 0 : ntiles;
+    return w;
+}
+
+
+#ifdef AM_DEV_KNOBS
+// timing experiments of the A/B build (AM_WIDE_DBG, set by the launchers of pairwise_wide.hip): 1 = every tile of the wide
+// engine reads the first eight 256-row blocks (results meaningless), 2 = tile epilogues skipped (matrix pipeline only)
+static __constant__ int g_wide_dbg;
+// AM_WIDE_TRACE: s_memtime stamps of wave 0 / wave 4 of the first 64 workgroups, 96 stages x 6 points each (dev tool)
+static __constant__ unsigned long long* g_wide_trace;
+#endif
+
+constexpr unsigned FAST_COUNTED = 0x80000000u;                               // membership queue entry: the pair was already counted as certain
+constexpr unsigned FAST_BOTH = 0x80000000u;
+constexpr int FAST_ROW_OVERFLOW = 0x40000000;                                 // OR-ed into a row's entry count: > any cap, and the
+                                                                              // later +1's of the scatter cannot wrap it
+constexpr unsigned FAST_HOLE = 0xffffffffu;                                  // pair-list slot left unwritten (list full)
+
+// Lane / TBX / MT: geometry of the engine underneath - LaneInfo, 128, 2 (tile_engine.h) or WLane, 256, 4 (wide_engine.h)
+template <int KCAP, class Lane = LaneInfo, int TBX = TB, int MT = 2>
+struct KnnFastEpilogue {
+    const float* qnorm;
+    const float* thr;
+    int64_t n, pblock;
+    float* aux;                 // LDS [2][2][TBX] : |x_j|^2 and thr[j] of the tile
+    uint2* wgq;
+    float* wgv;                 // approximate value of each queued pair (pruning, knn_fast_prune_kernel)
+    int* qn;
+    int qcap;
+    uint2* ovq;                 // global spill queue for entries that do not fit their region
+    float* ovv;
+    unsigned long long* ovn;
+    int ovcap;
+    int* cnt;
+    int cap;
+    float dsc;                  // -2 / (operand scale)^2
+    unsigned prow[2];           // (row indices fit 32 bits: the filter path is limited to < 2^31 rows)
+    float xn[2], flt[2];        // xn = +inf for rows past the end: every approximate value is +inf and passes no test
+    float e2c, e2n;             // 2 E_i = e2c * |x_i|^2 + e2n  (recomputed per tile group: two registers less than keeping it)
+    float best[2][KCAP];        // ascending; the first KCAP - (k+1) slots are -inf pads, so best[KCAP-1] is the (k+1)-th smallest
+    float aux_n, aux_t;
+    const Lane& L;
+
+    __device__ __forceinline__ KnnFastEpilogue(const Lane& l) : L(l) {}
+    // entry into slot `slot` of this workgroup's region (slots are reserved per lane and accumulator tile by ONE LDS
+    // atomic in finish(): a returning atomic per entry - 16 dependent LDS round trips per tile group while the bounds are
+    // still loose - was the critical path of the epilogue: 34 000 of 68 000 cycles per tile in the first windows)
+    __device__ __forceinline__ void store_entry(int slot, unsigned a, unsigned b, bool both, float val) {
+        if (slot < qcap) {
+            wgq[slot] = make_uint2(a | (both ? FAST_BOTH : 0u), b);
+            wgv[slot] = val;
+        } else {
+            // Region full (rare: the regions hold 8x the expected survivors).  The 128-row short-list instantiation keeps a
+            // global spill queue; everywhere else the row(s) go straight to the exact fix-up kernel - this store is
+            // instantiated 128 times per tile, and a larger body here pushes the unrolled epilogue over the compiler's
+            // full-unroll budget (the accumulator array is then indexed dynamically and lands in scratch).
+            if constexpr (KCAP <= 6 && TBX != WIDE_TILE_ROWS) {
+                // (inputs the bound cannot decide send hundreds of millions of pairs here: neither the counter nor the
+                // per-row markers may wrap)
+                const unsigned long long s2 = atomicAdd(ovn, 1ull);          // 64-bit: cannot wrap
+                if (s2 < (unsigned long long)ovcap) {
+                    ovq[s2] = make_uint2(a | (both ? FAST_BOTH : 0u), b);
+                    ovv[s2] = val;
+                    return;
+                }
+            }
+            atomicOr(cnt + a, FAST_ROW_OVERFLOW);
+            if (both) atomicOr(cnt + b, FAST_ROW_OVERFLOW);
+        }
+    }
+    __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
+        if (L.tid < TBX) {
+            const int64_t j = qtile * TBX + L.tid;
+            aux_n = j < n ? qnorm[j] : INFINITY;
+            aux_t = j < n ? __hip_atomic_load(thr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+        }
+    }
+    __device__ __forceinline__ void aux_commit(int t) {
+        if (L.tid < TBX) {
+            aux[(t & 1) * 2 * TBX + L.tid] = aux_n;
+            aux[(t & 1) * 2 * TBX + TBX + L.tid] = aux_t;
+        }
+    }
+    __device__ __forceinline__ void finish(int t, int64_t qtile, f32x16 (&acc)[MT][2]) {
+        const float* a = aux + (t & 1) * 2 * TBX + L.wm * (MT * 32) + L.h * 4;
+        const bool mirror = qtile != pblock;                // the diagonal tile holds both directions itself
+#ifdef AM_DEV_KNOBS
+        if constexpr (TBX == WIDE_TILE_ROWS) {
+            if (g_wide_dbg & 2) return;                     // timing experiment: MFMA pipeline only
+        }
+#endif
+        const unsigned jbase = (unsigned)(qtile * TBX) + L.wm * (MT * 32) + L.h * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 yn[4], tq[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
+                tq[g4] = *reinterpret_cast<const f32x4*>(a + TBX + mt * 32 + g4 * 8);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float tmin = INFINITY, marg = INFINITY;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
+                    tmin = fminf(tmin, u);
+                    marg = fminf(marg, u - tq[reg >> 2][reg & 3]);
+                }
+                // the own-row bound is frozen for the 16 elements of this accumulator tile (a looser filter is always
+                // safe); the list - and with it the bound of the next tile - is updated behind the stores
+                const float pl = fminf(flt[nt], best[nt][KCAP - 1] + fmaf(e2c, xn[nt], e2n));
+                if (__any(tmin <= pl || (mirror && marg <= 0.f))) {
+                    unsigned own_bits = 0u, mir_bits = 0u;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
+                        own_bits |= (u <= pl) ? (1u << reg) : 0u;
+                        mir_bits |= (mirror && u <= tq[reg >> 2][reg & 3]) ? (1u << reg) : 0u;
+                    }
+                    const unsigned any_bits = own_bits | mir_bits;
+                    // The lane-local list only steers the filter (its (k+1)-th smallest bounds the row's final value from
+                    // above).  It takes ONE value per accumulator tile - the smallest of the sixteen - instead of every
+                    // queued one: a list over a subset of the row's values still bounds from above, two of a row's k+1
+                    // nearest neighbours practically never share a tile, and sixteen conditional insertions per tile were
+                    // a large part of the epilogue while the bounds are loose.
+                    const float vmin = tmin <= pl ? fmaxf(tmin, 0.f) : INFINITY;
+                    if (__any(vmin < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], vmin);
+                    // Queue slots: ONE LDS atomic per lane and accumulator tile reserves them (a returning atomic per
+                    // entry - sixteen dependent LDS round trips per tile - was the epilogue's critical path).  (Compacting
+                    // the entries of a register across the lanes with ballots so that the stores coalesce was measured
+                    // too: the sixteen extra ballots cost more than the scattered stores, 6.7 -> 7.4 ms per launch.)
+                    const int count = __popc(any_bits);
+                    int base = 0;
+                    if (count > 0) base = atomicAdd(qn, count);
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const unsigned bit = 1u << reg;
+                        if (__any((any_bits & bit) != 0u)) {                              // wave-uniform
+                            const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
+                            const unsigned j = jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3);
+                            const bool own = (own_bits & bit) != 0u, mir = (mir_bits & bit) != 0u;
+                            // filed under its own row, or (mirrored only) under row j
+                            if (own || mir)
+                                store_entry(base + __popc(any_bits & (bit - 1u)), own ? prow[nt] : j, own ? j : prow[nt], own && mir, u);
+                        }
+                    }
+                }
+            }
+        }
+    }
+};
+
+
+// ---- launchers of the 256 x 256 f16 filter kernels (pairwise_wide.hip) ------------------------------------------------
+constexpr int KNN_WIDE_MAX_KCAP = 11;                     // list registers beside 128 accumulators: k <= 10 on the wide engine
+int64_t wide_grouped_blocks(int64_t row_blocks, int nchunks, int grp_rows);
+int launch_cross_wide(bool want_min, unsigned blocks, const float* Rb, int64_t Nr, int64_t ldr, const float* rnorm, const float* rthr,
+                      const float* Cb, int64_t Nc, int64_t ldc, const float* cnorm, const float* cthr, int Dh, int nchunks,
+                      int grp_rows, const unsigned* maxn, unsigned* rmin_approx, unsigned* row_any, unsigned* row_cover,
+                      int32_t* col_count, uint2* wgq, int qcap, int* wgq_count, uint2* ovq, int* ov_count, int ovcap, int* fail,
+                      float fc, hipStream_t st);
+int launch_knn_wide(int kcap, unsigned nwg, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, float* thr, int Dh,
+                    int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
+                    uint2* wgq, float* wgv, int qcap, int* wgq_count, int part, int nparts, float fc, uint2* ovq, float* ovv,
+                    unsigned long long* ovn, int ovcap, hipStream_t st);
+
+}  // namespace am

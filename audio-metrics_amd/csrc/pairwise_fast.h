@@ -27,7 +27,6 @@
 //      computation (per row for the k-NN radii, for the whole call for the membership counts), as does a matrix
 //      whose M is not a finite number within 2^+-60.
 #pragma once
-#include "wide_engine.h"
 
 namespace am {
 
@@ -176,7 +175,6 @@ __device__ __forceinline__ float exact_pair_dot(const float* __restrict__ xs, co
 //                   a_ij* <= t_ij* + eps <= t_ij + eps <= max(a_ij, 0) + 2 eps for every j.
 // A queue entry is (i, j | COUNTED) - COUNTED = the pair was already counted as certain.  PRE = sampled
 // pre-pass (every qstride-th column tile): only m_i and the certain "any" flags are produced.
-constexpr unsigned FAST_COUNTED = 0x80000000u;
 constexpr int FAST_AUX_FLOATS = 6 * TB;                                    // LDS [2][3][128]
 constexpr size_t FAST_LDS_BYTES = (ENGINE_LDS_FLOATS + FAST_AUX_FLOATS) * sizeof(float) + 16;
 
@@ -394,235 +392,6 @@ __device__ __forceinline__ void cross_apply(float t, int64_t j, unsigned jflag, 
     }
 }
 
-// ---- the same filter on the 256 x 256 f16 engine (wide_engine.h): main pass only ---------------------------------
-constexpr int WIDE_AUX_WORDS = 6 * WTB;                                    // LDS [2][3][256]
-constexpr size_t WIDE_CROSS_LDS_BYTES = (WENGINE_LDS_WORDS + WIDE_AUX_WORDS) * sizeof(float) + 16;
-
-struct CrossWideEpilogue {
-    const float* qnorm;
-    const float* qthr;
-    int64_t nq;
-    float fc, rnmax_c;
-    float* aux;                 // LDS [2][3][256] : |c_j|^2, T'_j + E'_j, T'_j - E'_j of the tile
-    int32_t* col_count;
-    uint2* wgq;
-    int* qn;
-    int qcap;
-    uint2* ovq;
-    int* ov_count;
-    int ovcap;
-    int* fail;
-    int dbg;
-    float dsc;
-    int64_t prow[2];
-    float xn[2], thi[2], tlo[2], e2[2], m[2];
-    bool rowok[2], anyf[2], covf[2];
-    float aux_n, aux_hi, aux_lo;
-    const WLane& L;
-
-    __device__ __forceinline__ CrossWideEpilogue(const WLane& l) : L(l) {}
-    __device__ __forceinline__ void push(int64_t i, unsigned jflag) {
-        const int slot = atomicAdd(qn, 1);
-        if (slot < qcap) {
-            wgq[slot] = make_uint2((unsigned)i, jflag);
-        } else if (*reinterpret_cast<volatile int*>(fail) == 0) {   // (see CrossFastEpilogue::push)
-            const unsigned s2 = atomicAdd(reinterpret_cast<unsigned*>(ov_count), 1u);
-            if (s2 < (unsigned)ovcap) ovq[s2] = make_uint2((unsigned)i, jflag);
-            else *fail = 1;
-        }
-    }
-    __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
-        if (L.tid < WTB) {
-            const int64_t j = qtile * WTB + L.tid;
-            if (j < nq) {
-                const float e = fmaf(fc, qnorm[j], rnmax_c);
-                aux_n = qnorm[j];
-                aux_hi = qthr[j] + e;
-                aux_lo = qthr[j] - e;
-            } else {
-                aux_n = INFINITY;
-                aux_hi = -INFINITY;
-                aux_lo = -INFINITY;
-            }
-        }
-    }
-    __device__ __forceinline__ void aux_commit(int t) {
-        if (L.tid < WTB) {
-            float* d = aux + (t & 1) * 3 * WTB + L.tid;
-            d[0] = aux_n;
-            d[WTB] = aux_hi;
-            d[2 * WTB] = aux_lo;
-        }
-    }
-    template <bool WANT_MIN>
-    __device__ __forceinline__ void finish_impl(int t, int64_t qtile, f32x16 (&acc)[4][2]) {
-        const float* a = aux + (t & 1) * 3 * WTB + L.wm * 128 + L.h * 4;
-        const int64_t jbase = qtile * WTB + L.wm * 128 + L.h * 4;
-        if (dbg & 8) return;                                   // timing experiment: MFMA pipeline only
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            f32x4 yn[4], th[4];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
-                th[g4] = *reinterpret_cast<const f32x4*>(a + WTB + mt * 32 + g4 * 8);
-            }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                float tmin = INFINITY, marg = INFINITY;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
-                    tmin = fminf(tmin, u);
-                    marg = fminf(marg, u - th[reg >> 2][reg & 3]);
-                }
-                if constexpr (WANT_MIN) m[nt] = fminf(m[nt], fmaxf(tmin, 0.f));
-                const float prow_thr = WANT_MIN ? fmaxf(thi[nt], m[nt] + e2[nt]) : thi[nt];
-                if (__any(rowok[nt] && (tmin <= prow_thr || (!anyf[nt] && marg <= 0.f)))) {
-                    const float* alo = a + 2 * WTB + mt * 32;
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
-                        const int64_t j = jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3);
-                        const bool sure = rowok[nt] && u < tlo[nt];
-                        const unsigned long long mask = __ballot(sure);
-                        if (mask != 0ull && L.lane == 0) {               // lanes 0-31: column j, lanes 32-63: column j + 4
-                            const int lo = __popcll(mask & 0xffffffffull);
-                            const int hi = __popcll(mask >> 32);
-                            if (lo) atomicAdd(col_count + j - L.h * 4, lo);
-                            if (hi) atomicAdd(col_count + j - L.h * 4 + 4, hi);
-                        }
-                        covf[nt] = covf[nt] || sure;
-                        bool want = rowok[nt] && !sure && u <= thi[nt];
-                        if constexpr (WANT_MIN) want = want || (rowok[nt] && u <= m[nt] + e2[nt]);
-                        if (rowok[nt] && !anyf[nt] && u <= th[reg >> 2][reg & 3]) {
-                            if (u < alo[(reg >> 2) * 8 + (reg & 3)]) anyf[nt] = true;       // certain witness
-                            else want = true;                                             // ambiguous "any"
-                        }
-                        if (want) push(prow[nt], (unsigned)j | (sure ? FAST_COUNTED : 0u));
-                    }
-                }
-            }
-        }
-    }
-};
-
-template <bool WANT_MIN>
-struct CrossWideShim {
-    CrossWideEpilogue& e;
-    __device__ __forceinline__ void aux_issue(int t, int64_t q) { e.aux_issue(t, q); }
-    __device__ __forceinline__ void aux_commit(int t) { e.aux_commit(t); }
-    __device__ __forceinline__ void finish(int t, int64_t q, f32x16 (&acc)[4][2]) { e.template finish_impl<WANT_MIN>(t, q, acc); }
-};
-
-struct WideTiles {
-    int64_t q0;
-    __device__ __forceinline__ int64_t operator()(int t) const { return q0 + t; }
-};
-
-// work item = (256-row block, column chunk), XCD-grouped: block b runs on XCD b % 8; the 32 workgroups resident on an
-// XCD (one per CU) form a group of grp_rows row blocks x 32 / grp_rows chunks, so a group keeps grp_rows P blocks
-// (256 KB each) in the 4 MB L2 and fetches each Q tile once.
-struct WideWork {
-    int64_t rb, qtile0;
-    int ntiles;
-};
-static inline int64_t wide_grouped_blocks(int64_t row_blocks, int nchunks, int grp_rows) {
-    const int grp_chunks = 32 / grp_rows;
-    const int64_t groups = ceil_div(row_blocks, grp_rows) * ceil_div(nchunks, grp_chunks);
-    return ceil_div(groups, 8) * 8 * 32;
-}
-__device__ __forceinline__ WideWork wide_work(int64_t q_tiles, int nchunks, int64_t row_blocks, int grp_rows) {
-    const int grp_chunks = 32 / grp_rows;
-    const int64_t cgroups = (nchunks + grp_chunks - 1) / grp_chunks;
-    const int xcd = blockIdx.x & 7;
-    const int64_t seq = blockIdx.x >> 3;
-    const int64_t g = (seq >> 5) * 8 + xcd;
-    const int within = (int)(seq & 31);
-    WideWork w;
-    w.rb = (g / cgroups) * grp_rows + within / grp_chunks;
-    const int chunk = (int)((g % cgroups) * grp_chunks + within % grp_chunks);
-    w.qtile0 = 0;
-    w.ntiles = 0;
-    if (w.rb < row_blocks && chunk < nchunks) {
-        w.qtile0 = q_tiles * chunk / nchunks;
-        w.ntiles = (int)(q_tiles * (chunk + 1) / nchunks - w.qtile0);
-    }
-    return w;
-}
-
-template <bool WANT_MIN>
-__global__ void __launch_bounds__(WTHREADS, 1)
-cross_wide_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const float* __restrict__ rnorm,
-                  const float* __restrict__ rthr, const float* __restrict__ Cb, int64_t Nc, int64_t ldc,
-                  const float* __restrict__ cnorm, const float* __restrict__ cthr, int Dh, int nchunks, int grp_rows,
-                  const unsigned* __restrict__ maxn, unsigned* __restrict__ rmin_approx, unsigned* __restrict__ row_any,
-                  unsigned* __restrict__ row_cover, int32_t* __restrict__ col_count, uint2* __restrict__ wgq, int qcap,
-                  int* __restrict__ wgq_count, uint2* __restrict__ ovq, int* __restrict__ ov_count, int ovcap,
-                  int* __restrict__ fail, int dbg, float fc) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const WLane L;
-    const WideWork w = wide_work((Nc + WTB - 1) / WTB, nchunks, (Nr + WTB - 1) / WTB, grp_rows);
-    if (w.ntiles == 0) {
-        if (L.tid == 0) wgq_count[blockIdx.x] = 0;
-        return;
-    }
-    int* qn = reinterpret_cast<int*>(lds + WENGINE_LDS_WORDS + WIDE_AUX_WORDS);
-    if (L.tid == 0) *qn = 0;
-    const float gmax = fmaxf(__uint_as_float(maxn[0]), __uint_as_float(maxn[1]));
-    CrossWideEpilogue epi(L);
-    epi.fc = fc;
-    epi.qnorm = cnorm;
-    epi.qthr = cthr;
-    epi.nq = Nc;
-    epi.rnmax_c = fc * gmax;
-    epi.aux = lds + WENGINE_LDS_WORDS;
-    epi.col_count = col_count;
-    epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
-    epi.qn = qn;
-    epi.qcap = qcap;
-    epi.ovq = ovq;
-    epi.ov_count = ov_count;
-    epi.ovcap = ovcap;
-    epi.fail = fail;
-    epi.dbg = dbg;
-    epi.dsc = half_unscale(maxn[2], maxn[3]);
-    if (blockIdx.x == 0 && L.tid == 0 && !(half_scale_ok(maxn[2]) && half_scale_ok(maxn[3]))) *fail = 1;
-    const int64_t prow0 = w.rb * WTB;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int64_t i = prow0 + L.wn * 64 + nt * 32 + L.r;
-        const bool ok = i < Nr;
-        epi.prow[nt] = i;
-        epi.rowok[nt] = ok;
-        epi.xn[nt] = ok ? rnorm[i] : 0.f;
-        const float e = fc * ((ok ? rnorm[i] : 0.f) + gmax);
-        epi.thi[nt] = ok ? rthr[i] + e : -INFINITY;
-        epi.tlo[nt] = ok ? rthr[i] - e : -INFINITY;
-        epi.e2[nt] = 2.f * e;
-        epi.m[nt] = (WANT_MIN && ok) ? __uint_as_float(rmin_approx[i]) : INFINITY;
-        epi.anyf[nt] = ok ? (row_any[i] != 0u) : true;
-        epi.covf[nt] = false;
-    }
-    CrossWideShim<WANT_MIN> shim{epi};
-    wide_pipeline(Cb, Nc, ldc, WideTiles{w.qtile0}, Rb, Nr, ldr, prow0, w.ntiles, Dh, lds, L, shim);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const float mn = fminf(epi.m[nt], __shfl_xor(epi.m[nt], 32));
-        const int other = __shfl_xor((int)epi.anyf[nt], 32);
-        const int other_c = __shfl_xor((int)epi.covf[nt], 32);
-        const bool any = epi.anyf[nt] || other != 0;
-        const bool cov = epi.covf[nt] || other_c != 0;
-        if (L.h == 0 && epi.rowok[nt]) {
-            if constexpr (WANT_MIN) atomicMin(rmin_approx + epi.prow[nt], __float_as_uint(mn));
-            if (any) atomicOr(row_any + epi.prow[nt], 1u);
-            if (cov) atomicOr(row_cover + epi.prow[nt], 1u);
-        }
-    }
-    __syncthreads();
-    if (L.tid == 0) wgq_count[blockIdx.x] = *qn < qcap ? *qn : qcap;
-}
-
 // exact evaluation of the regions of cross_wide_kernel: one queued pair per thread, both rows from global memory
 __global__ void __launch_bounds__(256) cross_verify_regions_kernel(const float* __restrict__ R, int64_t ldr,
                                                                    const float* __restrict__ rnorm, const float* __restrict__ rthr,
@@ -813,7 +582,7 @@ static CrossFastPlan plan_cross_fast(int64_t Nr, int64_t Nc) {
         static const int wtarget = env_int("AM_WIDE_WG_TARGET", 6144);               // ~24 rounds of 256 CUs x 1 workgroup
         p.grp_rows = (wgrp == 1 || wgrp == 2 || wgrp == 4 || wgrp == 8 || wgrp == 16 || wgrp == 32) ? wgrp : 8;
         const int grp_chunks = 32 / p.grp_rows;
-        const int64_t rbw = ceil_div(Nr, WTB), qtw = ceil_div(Nc, WTB);
+        const int64_t rbw = ceil_div(Nr, WIDE_TILE_ROWS), qtw = ceil_div(Nc, WIDE_TILE_ROWS);
         int64_t want = std::max<int64_t>(ceil_div(wtarget, rbw), 1);
         want = ceil_div(want, grp_chunks) * grp_chunks;
         // at least ~8 column tiles per workgroup (row shards of a multi-GPU run would otherwise get 3-tile work items
@@ -903,20 +672,12 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
     AM_LAUNCH_CHECK();
     unsigned* rmin_or_null = want_min ? rmin : nullptr;
     if (p.wide) {
-        {
-            AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&cross_wide_kernel<true>), (int)WIDE_CROSS_LDS_BYTES));
-            AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&cross_wide_kernel<false>), (int)WIDE_CROSS_LDS_BYTES));
-        }
-        auto launch_wide = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3((unsigned)p.blocks), dim3(WTHREADS), WIDE_CROSS_LDS_BYTES, st, Rb, Nr, ldb / 2, rn, rt, Cb,
-                               Nc, ldb / 2, cn, ct, Dh, p.nchunks, p.grp_rows, b.maxn, b.rmin_approx, rany, rcov, col_count, b.wgq,
-                               p.qcap, b.wgq_count, b.ovq, b.ov_count, p.ovcap, fail, dbg, fast_c(D));
-        };
         clock_begin(AM_KERNEL_PRDC_CROSS, st);
-        if (want_min) launch_wide(&cross_wide_kernel<true>);
-        else launch_wide(&cross_wide_kernel<false>);
+        if ((rc = launch_cross_wide(want_min, (unsigned)p.blocks, Rb, Nr, ldb / 2, rn, rt, Cb, Nc, ldb / 2, cn, ct, Dh, p.nchunks,
+                                    p.grp_rows, b.maxn, b.rmin_approx, rany, rcov, col_count, b.wgq, p.qcap, b.wgq_count, b.ovq,
+                                    b.ov_count, p.ovcap, fail, fast_c(D), st)) != AM_OK)
+            return rc;
         clock_end(AM_KERNEL_PRDC_CROSS, st);
-        AM_LAUNCH_CHECK();
         clock_begin(AM_KERNEL_PRDC_VERIFY, st);
         hipLaunchKernelGGL(cross_verify_regions_kernel, dim3((unsigned)p.blocks), dim3(256), 0, st, R, ldr, rn, rt, C, ldc, cn, ct, D,
                            b.wgq, p.qcap, b.wgq_count, col_count, rmin_or_null, rany, rcov);
@@ -976,116 +737,6 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
 // queued pairs (knn_fast_scatter_kernel -> knn_fast_prune_kernel -> knn_fast_verify_kernel -> knn_fast_select_kernel).
 // Queue entry: (row a | FAST_BOTH, row b): the exact value t(a, b) is filed under row a, and under row b as well when
 // FAST_BOTH is set (a pair that passes the own-row test of a and the mirrored test of b is evaluated once).
-constexpr unsigned FAST_BOTH = 0x80000000u;
-constexpr int FAST_ROW_OVERFLOW = 0x40000000;                                 // OR-ed into a row's entry count: > any cap, and the
-                                                                              // later +1's of the scatter cannot wrap it
-constexpr unsigned FAST_HOLE = 0xffffffffu;                                  // pair-list slot left unwritten (list full)
-
-// Lane / TBX / MT: geometry of the engine underneath - LaneInfo, 128, 2 (tile_engine.h) or WLane, 256, 4 (wide_engine.h)
-template <int KCAP, class Lane = LaneInfo, int TBX = TB, int MT = 2>
-struct KnnFastEpilogue {
-    const float* qnorm;
-    const float* thr;
-    int64_t n, pblock;
-    float* aux;                 // LDS [2][2][TBX] : |x_j|^2 and thr[j] of the tile
-    uint2* wgq;
-    float* wgv;                 // approximate value of each queued pair (pruning, knn_fast_prune_kernel)
-    int* qn;
-    int qcap;
-    uint2* ovq;                 // global spill queue for entries that do not fit their region
-    float* ovv;
-    unsigned long long* ovn;
-    int ovcap;
-    int* cnt;
-    int cap;
-    float dsc;                  // -2 / (operand scale)^2
-    int64_t prow[2];
-    float xn[2], flt[2], e2[2];
-    bool rowok[2];
-    float best[2][KCAP];        // ascending; the first KCAP - (k+1) slots are -inf pads, so best[KCAP-1] is the (k+1)-th smallest
-    float aux_n, aux_t;
-    const Lane& L;
-
-    __device__ __forceinline__ KnnFastEpilogue(const Lane& l) : L(l) {}
-    __device__ __forceinline__ void push(int64_t a, int64_t b, bool both, float val) {
-        const int slot = atomicAdd(qn, 1);
-        if (slot < qcap) {
-            wgq[slot] = make_uint2((unsigned)a | (both ? FAST_BOTH : 0u), (unsigned)b);
-            wgv[slot] = val;
-        } else if constexpr (KCAP <= 6) {                   // region full: spill to the global queue
-            // (inputs the bound cannot decide send hundreds of millions of pairs here: neither the counter nor the
-            // per-row markers may wrap)
-            const unsigned long long s2 = atomicAdd(ovn, 1ull);          // 64-bit: cannot wrap
-            if (s2 < (unsigned long long)ovcap) {
-                ovq[s2] = make_uint2((unsigned)a | (both ? FAST_BOTH : 0u), (unsigned)b);
-                ovv[s2] = val;
-            } else {                                        // that one is full too: the row(s) go to the exact fix-up kernel
-                atomicOr(cnt + a, FAST_ROW_OVERFLOW);
-                if (both) atomicOr(cnt + b, FAST_ROW_OVERFLOW);
-            }
-        } else {
-            // longer lists (k > 5): no spill path - its extra live state tips these instantiations into scratch
-            // spills (measured: 12.7 -> 33 ms at k = 10); a full region sends the row(s) to the exact fix-up kernel
-            atomicOr(cnt + a, FAST_ROW_OVERFLOW);
-            if (both) atomicOr(cnt + b, FAST_ROW_OVERFLOW);
-        }
-    }
-    __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
-        if (L.tid < TBX) {
-            const int64_t j = qtile * TBX + L.tid;
-            aux_n = j < n ? qnorm[j] : INFINITY;
-            aux_t = j < n ? __hip_atomic_load(thr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
-        }
-    }
-    __device__ __forceinline__ void aux_commit(int t) {
-        if (L.tid < TBX) {
-            aux[(t & 1) * 2 * TBX + L.tid] = aux_n;
-            aux[(t & 1) * 2 * TBX + TBX + L.tid] = aux_t;
-        }
-    }
-    __device__ __forceinline__ void finish(int t, int64_t qtile, f32x16 (&acc)[MT][2]) {
-        const float* a = aux + (t & 1) * 2 * TBX + L.wm * (MT * 32) + L.h * 4;
-        const bool mirror = qtile != pblock;                // the diagonal tile holds both directions itself
-        const int64_t jbase = qtile * TBX + L.wm * (MT * 32) + L.h * 4;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            f32x4 yn[4], tq[4];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
-                tq[g4] = *reinterpret_cast<const f32x4*>(a + TBX + mt * 32 + g4 * 8);
-            }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                float tmin = INFINITY, marg = INFINITY;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
-                    tmin = fminf(tmin, u);
-                    marg = fminf(marg, u - tq[reg >> 2][reg & 3]);
-                }
-                float pl = fminf(flt[nt], best[nt][KCAP - 1] + e2[nt]);
-                if (__any(rowok[nt] && (tmin <= pl || (mirror && marg <= 0.f)))) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
-                        const int64_t j = jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3);
-                        const bool own = rowok[nt] && u <= pl;
-                        const bool mir = mirror && rowok[nt] && u <= tq[reg >> 2][reg & 3];
-                        if (own) push(prow[nt], j, mir, u);
-                        else if (mir) push(j, prow[nt], false, u);
-                        const float v = own ? fmaxf(u, 0.f) : INFINITY;
-                        if (__any(v < best[nt][KCAP - 1])) {
-                            list_insert<KCAP>(best[nt], v);
-                            pl = fminf(flt[nt], best[nt][KCAP - 1] + e2[nt]);
-                        }
-                    }
-                }
-            }
-        }
-    }
-};
-
 // Xb: f16 copy viewed as f32 words (ldh, Dh in words).  Same grid and work mapping as knn_sym_kernel.
 template <int KCAP>
 __global__ void __launch_bounds__(ENGINE_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -1124,10 +775,10 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int64_t i = sw.pb * TB + L.wn * 64 + nt * 32 + L.r;
-        epi.prow[nt] = i;
-        epi.rowok[nt] = i < N;
-        epi.xn[nt] = i < N ? xnorm[i] : 0.f;
-        epi.e2[nt] = 2.f * fc * ((i < N ? xnorm[i] : 0.f) + nmax);
+        epi.prow[nt] = (unsigned)i;
+        epi.xn[nt] = i < N ? xnorm[i] : INFINITY;
+        epi.e2c = 2.f * fc;
+        epi.e2n = 2.f * fc * nmax;
         epi.flt[nt] = i < N ? __hip_atomic_load(thr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = s < KCAP - k1 ? -INFINITY : INFINITY;
@@ -1164,90 +815,6 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
             }
             const float kthv = m[KCAP - 1];
             const float bound = kthv + 2.f * fc * (xnorm[i] + nmax);     // >= 0, so its bit pattern orders like the value
-            atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
-        }
-    }
-}
-
-// The same sweep on the 256 x 256 f16 engine (wide_engine.h): row blocks and column tiles of 256 rows, 512 threads.
-constexpr size_t KNN_WIDE_LDS_BYTES = (WENGINE_LDS_WORDS + 4 * WTB) * sizeof(float) + 16;
-
-template <int KCAP>
-__global__ void __launch_bounds__(WTHREADS, 1)
-knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float* __restrict__ xnorm, float* thr, int Dh,
-                int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
-                int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
-                int* __restrict__ wgq_count, int part, int nparts, float fc, uint2* __restrict__ ovq, float* __restrict__ ovv,
-                unsigned long long* __restrict__ ovn, int ovcap) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const WLane L;
-    const int64_t T = (N + WTB - 1) / WTB;
-    const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
-    if (sw.ntiles == 0) {
-        if (L.tid == 0) wgq_count[blockIdx.x] = 0;
-        return;
-    }
-    const float nmax = __uint_as_float(maxn[0]);
-    KnnFastEpilogue<KCAP, WLane, WTB, 4> epi(L);
-    epi.qnorm = xnorm;
-    epi.thr = thr;
-    epi.n = N;
-    epi.pblock = sw.pb;
-    epi.aux = lds + WENGINE_LDS_WORDS;
-    epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
-    epi.wgv = wgv + (int64_t)blockIdx.x * qcap;
-    epi.qn = reinterpret_cast<int*>(lds + WENGINE_LDS_WORDS + 4 * WTB);
-    epi.qcap = qcap;
-    epi.ovq = ovq;
-    epi.ovv = ovv;
-    epi.ovn = ovn;
-    epi.ovcap = ovcap;
-    epi.cnt = cnt;
-    epi.cap = cap;
-    epi.dsc = half_unscale(maxn[2], maxn[2]);
-    if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int64_t i = sw.pb * WTB + L.wn * 64 + nt * 32 + L.r;
-        epi.prow[nt] = i;
-        epi.rowok[nt] = i < N;
-        epi.xn[nt] = i < N ? xnorm[i] : 0.f;
-        epi.e2[nt] = 2.f * fc * ((i < N ? xnorm[i] : 0.f) + nmax);
-        epi.flt[nt] = i < N ? __hip_atomic_load(thr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
-#pragma unroll
-        for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = s < KCAP - k1 ? -INFINITY : INFINITY;
-    }
-    wide_pipeline(Xb, N, ldh, WideTiles{sw.qa}, Xb, N, ldh, sw.pb * WTB, sw.ntiles, Dh, lds, L, epi);
-    float* mg = lds;                                   // [256][4][KCAP]: the engine's buffers are free now
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        float* dst = mg + ((L.wn * 64 + nt * 32 + L.r) * 4 + (L.wm * 2 + L.h)) * KCAP;
-#pragma unroll
-        for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
-    }
-    __syncthreads();
-    if (L.tid == 0) wgq_count[blockIdx.x] = min(*epi.qn, qcap);
-    if (L.tid < WTB) {
-        const int64_t i = sw.pb * WTB + L.tid;
-        if (i < N) {
-            const float* src = mg + L.tid * 4 * KCAP;
-            float m[KCAP];
-#pragma unroll
-            for (int s = 0; s < KCAP; ++s) m[s] = src[s];
-            for (int s = KCAP; s < 4 * KCAP; ++s)
-                if (src[s] > -INFINITY) list_insert<KCAP>(m, src[s]);
-            float* out = partial + ((int64_t)sw.W * N + i) * KCAP;
-#pragma unroll
-            for (int s = 0; s < KCAP; ++s) __hip_atomic_store(out + s, m[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int w2 = sw.W + 1; w2 < nwin; ++w2) {
-                const float* src2 = partial + ((int64_t)w2 * N + i) * KCAP;
-                for (int s = 0; s < KCAP; ++s) {
-                    const float v = __hip_atomic_load(src2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v > -INFINITY) list_insert<KCAP>(m, v);
-                }
-            }
-            const float kthv = m[KCAP - 1];
-            const float bound = kthv + 2.f * fc * (xnorm[i] + nmax);
             atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
         }
     }
@@ -1537,17 +1104,15 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     AM_LAUNCH_CHECK();
     {
         AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_fast_kernel<KCAP>), (int)PAIRWISE_LDS_BYTES + 16));
-        if constexpr (KCAP <= KNN_WIDE_MAX_KCAP)
-            AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_wide_kernel<KCAP>), (int)KNN_WIDE_LDS_BYTES));
     }
     const int qcap = p.qcap;
     static const int ovcap = std::max(0, std::min(env_int("AM_KNN_FAST_OVCAP", KNN_FAST_OVCAP), KNN_FAST_OVCAP));   // (tests shrink it)
     clock_begin(AM_KERNEL_KNN, st);
-    if (p.tile_rows == WTB) {
-        if constexpr (KCAP <= KNN_WIDE_MAX_KCAP)
-            hipLaunchKernelGGL(knn_wide_kernel<KCAP>, dim3(nwg), dim3(WTHREADS), KNN_WIDE_LDS_BYTES, st, Xb, N, ldh, b.xn, thr, Dh,
-                               p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, f.wgv, qcap, b.wgq_count,
-                               part, nparts, fast_c(D), f.ovq, f.ovv, f.ovn, ovcap);
+    if (p.tile_rows == WIDE_TILE_ROWS) {
+        if ((rc = launch_knn_wide(KCAP, nwg, Xb, N, ldh, b.xn, thr, Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt,
+                                  p.cap, b.wgq, f.wgv, qcap, b.wgq_count, part, nparts, fast_c(D), f.ovq, f.ovv, f.ovn, ovcap,
+                                  st)) != AM_OK)
+            return rc;
     } else {
         hipLaunchKernelGGL(knn_fast_kernel<KCAP>, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st, Xb, N, ldh, b.xn,
                            thr, Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, f.wgv, qcap,

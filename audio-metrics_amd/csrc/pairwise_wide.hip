@@ -1,0 +1,396 @@
+// The 256 x 256 f16 FILTER kernels of the PRDC path (wide_engine.h): the membership filter cross_wide_kernel and the
+// symmetric k-NN sweep knn_wide_kernel, with their launchers.  Algorithms, error bound and queue protocol are documented
+// in pairwise_fast.h, which holds the 128-row forms of the same filters and everything that runs around these kernels.
+#include "pairwise_common.h"
+#include "wide_engine.h"
+#include <algorithm>
+
+namespace am {
+
+#ifdef AM_DEV_KNOBS
+static unsigned long long* g_trace_dev = nullptr;
+// AM_WIDE_DBG -> g_wide_dbg; AM_WIDE_TRACE=1 -> a trace buffer (64 workgroups x 2 waves x 96 stages x 6 stamps) that
+// am_wide_trace_read copies out.  Development aid of the A/B build only.
+static hipError_t set_wide_dev_symbols(hipStream_t st) {
+    const int wdbg = env_int("AM_WIDE_DBG", 0);
+    hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wide_dbg), &wdbg, sizeof(int), 0, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
+    if (env_int("AM_WIDE_TRACE", 0) && g_trace_dev == nullptr) {
+        e = hipMalloc(&g_trace_dev, 64 * 2 * 96 * 6 * sizeof(unsigned long long));
+        if (e != hipSuccess) return e;
+    }
+    if (g_trace_dev != nullptr) {
+        e = hipMemsetAsync(g_trace_dev, 0, 64 * 2 * 96 * 6 * sizeof(unsigned long long), st);
+        if (e != hipSuccess) return e;
+    }
+    return hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wide_trace), &g_trace_dev, sizeof(g_trace_dev), 0, hipMemcpyHostToDevice, st);
+}
+}  // namespace am
+extern "C" int am_wide_trace_read(unsigned long long* host, size_t count) {
+    if (am::g_trace_dev == nullptr) return -1;
+    return hipMemcpy(host, am::g_trace_dev, std::min<size_t>(count, 64 * 2 * 96 * 6) * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -6;
+}
+namespace am {
+#endif
+
+// ---- the same filter on the 256 x 256 f16 engine (wide_engine.h): main pass only ---------------------------------
+constexpr int WIDE_AUX_WORDS = 6 * WTB;                                    // LDS [2][3][256]
+constexpr size_t WIDE_CROSS_LDS_BYTES = (WENGINE_LDS_WORDS + WIDE_AUX_WORDS) * sizeof(float) + 16;
+
+struct CrossWideEpilogue {
+    const float* qnorm;
+    const float* qthr;
+    int64_t nq;
+    float fc, rnmax_c;
+    float* aux;                 // LDS [2][3][256] : |c_j|^2, T'_j + E'_j, T'_j - E'_j of the tile
+    int32_t* col_count;
+    uint2* wgq;
+    int* qn;
+    int qcap;
+    uint2* ovq;
+    int* ov_count;
+    int ovcap;
+    int* fail;
+    float dsc;
+    int64_t prow[2];
+    float xn[2], thi[2], tlo[2], e2[2], m[2];
+    bool rowok[2], anyf[2], covf[2];
+    float aux_n, aux_hi;
+    const WLane& L;
+
+    __device__ __forceinline__ CrossWideEpilogue(const WLane& l) : L(l) {}
+    __device__ __forceinline__ void push(int64_t i, unsigned jflag) {
+        const int slot = atomicAdd(qn, 1);
+        if (slot < qcap) {
+            wgq[slot] = make_uint2((unsigned)i, jflag);
+        } else if (*reinterpret_cast<volatile int*>(fail) == 0) {   // (see CrossFastEpilogue::push)
+            const unsigned s2 = atomicAdd(reinterpret_cast<unsigned*>(ov_count), 1u);
+            if (s2 < (unsigned)ovcap) ovq[s2] = make_uint2((unsigned)i, jflag);
+            else *fail = 1;
+        }
+    }
+    // loads only: the values are first used in aux_commit, after the stage's MFMAs (an arithmetic use here would park
+    // waves 0-3 on a full memory round trip at the start of the last stage of every tile)
+    __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
+        if (L.tid < WTB) {
+            const int64_t j = qtile * WTB + L.tid;
+            const bool in = j < nq;
+            aux_n = in ? qnorm[j] : INFINITY;               // a = +inf: never below anything
+            aux_hi = in ? qthr[j] : -INFINITY;
+        }
+    }
+    __device__ __forceinline__ void aux_commit(int t) {
+        if (L.tid < WTB) {
+            float* d = aux + (t & 1) * 3 * WTB + L.tid;
+            const bool in = aux_hi > -INFINITY;               // thresholds are >= 0; -inf marks a column past the end
+            const float e = fmaf(fc, aux_n, rnmax_c);
+            d[0] = aux_n;
+            d[WTB] = in ? aux_hi + e : -INFINITY;
+            d[2 * WTB] = in ? aux_hi - e : -INFINITY;
+        }
+    }
+    template <bool WANT_MIN>
+    __device__ __forceinline__ void finish_impl(int t, int64_t qtile, f32x16 (&acc)[4][2]) {
+        const float* a = aux + (t & 1) * 3 * WTB + L.wm * 128 + L.h * 4;
+        const int64_t jbase = qtile * WTB + L.wm * 128 + L.h * 4;
+#ifdef AM_DEV_KNOBS
+        if (g_wide_dbg & 2) return;                            // timing experiment: MFMA pipeline only
+#endif
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x4 yn[4], th[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
+                th[g4] = *reinterpret_cast<const f32x4*>(a + WTB + mt * 32 + g4 * 8);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float tmin = INFINITY, marg = INFINITY;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
+                    tmin = fminf(tmin, u);
+                    marg = fminf(marg, u - th[reg >> 2][reg & 3]);
+                }
+                if constexpr (WANT_MIN) m[nt] = fminf(m[nt], fmaxf(tmin, 0.f));
+                const float prow_thr = WANT_MIN ? fmaxf(thi[nt], m[nt] + e2[nt]) : thi[nt];
+                if (__any(rowok[nt] && (tmin <= prow_thr || (!anyf[nt] && marg <= 0.f)))) {
+                    const float* alo = a + 2 * WTB + mt * 32;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
+                        const int64_t j = jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3);
+                        const bool sure = rowok[nt] && u < tlo[nt];
+                        const unsigned long long mask = __ballot(sure);
+                        if (mask != 0ull && L.lane == 0) {               // lanes 0-31: column j, lanes 32-63: column j + 4
+                            const int lo = __popcll(mask & 0xffffffffull);
+                            const int hi = __popcll(mask >> 32);
+                            if (lo) atomicAdd(col_count + j - L.h * 4, lo);
+                            if (hi) atomicAdd(col_count + j - L.h * 4 + 4, hi);
+                        }
+                        covf[nt] = covf[nt] || sure;
+                        bool want = rowok[nt] && !sure && u <= thi[nt];
+                        if constexpr (WANT_MIN) want = want || (rowok[nt] && u <= m[nt] + e2[nt]);
+                        if (rowok[nt] && !anyf[nt] && u <= th[reg >> 2][reg & 3]) {
+                            if (u < alo[(reg >> 2) * 8 + (reg & 3)]) anyf[nt] = true;       // certain witness
+                            else want = true;                                             // ambiguous "any"
+                        }
+                        if (want) push(prow[nt], (unsigned)j | (sure ? FAST_COUNTED : 0u));
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <bool WANT_MIN>
+struct CrossWideShim {
+    CrossWideEpilogue& e;
+    __device__ __forceinline__ void aux_issue(int t, int64_t q) { e.aux_issue(t, q); }
+    __device__ __forceinline__ void aux_commit(int t) { e.aux_commit(t); }
+    __device__ __forceinline__ void finish(int t, int64_t q, f32x16 (&acc)[4][2]) { e.template finish_impl<WANT_MIN>(t, q, acc); }
+};
+
+struct WideTiles {
+    int64_t q0;
+    __device__ __forceinline__ int64_t operator()(int t) const { return q0 + t; }
+};
+
+// work item = (256-row block, column chunk), XCD-grouped: block b runs on XCD b % 8; the 32 workgroups resident on an
+// XCD (one per CU) form a group of grp_rows row blocks x 32 / grp_rows chunks, so a group keeps grp_rows P blocks
+// (256 KB each) in the 4 MB L2 and fetches each Q tile once.
+struct WideWork {
+    int64_t rb, qtile0;
+    int ntiles;
+};
+int64_t wide_grouped_blocks(int64_t row_blocks, int nchunks, int grp_rows) {
+    const int grp_chunks = 32 / grp_rows;
+    const int64_t groups = ceil_div(row_blocks, grp_rows) * ceil_div(nchunks, grp_chunks);
+    return ceil_div(groups, 8) * 8 * 32;
+}
+__device__ __forceinline__ WideWork wide_work(int64_t q_tiles, int nchunks, int64_t row_blocks, int grp_rows) {
+    const int grp_chunks = 32 / grp_rows;
+    const int64_t cgroups = (nchunks + grp_chunks - 1) / grp_chunks;
+    const int xcd = blockIdx.x & 7;
+    const int64_t seq = blockIdx.x >> 3;
+    const int64_t g = (seq >> 5) * 8 + xcd;
+    const int within = (int)(seq & 31);
+    WideWork w;
+    w.rb = (g / cgroups) * grp_rows + within / grp_chunks;
+    const int chunk = (int)((g % cgroups) * grp_chunks + within % grp_chunks);
+    w.qtile0 = 0;
+    w.ntiles = 0;
+    if (w.rb < row_blocks && chunk < nchunks) {
+        w.qtile0 = q_tiles * chunk / nchunks;
+        w.ntiles = (int)(q_tiles * (chunk + 1) / nchunks - w.qtile0);
+    }
+    return w;
+}
+
+template <bool WANT_MIN>
+__global__ void __launch_bounds__(WTHREADS, 1)
+cross_wide_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const float* __restrict__ rnorm,
+                  const float* __restrict__ rthr, const float* __restrict__ Cb, int64_t Nc, int64_t ldc,
+                  const float* __restrict__ cnorm, const float* __restrict__ cthr, int Dh, int nchunks, int grp_rows,
+                  const unsigned* __restrict__ maxn, unsigned* __restrict__ rmin_approx, unsigned* __restrict__ row_any,
+                  unsigned* __restrict__ row_cover, int32_t* __restrict__ col_count, uint2* __restrict__ wgq, int qcap,
+                  int* __restrict__ wgq_count, uint2* __restrict__ ovq, int* __restrict__ ov_count, int ovcap,
+                  int* __restrict__ fail, float fc) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const WLane L;
+    const WideWork w = wide_work((Nc + WTB - 1) / WTB, nchunks, (Nr + WTB - 1) / WTB, grp_rows);
+    if (w.ntiles == 0) {
+        if (L.tid == 0) wgq_count[blockIdx.x] = 0;
+        return;
+    }
+    int* qn = reinterpret_cast<int*>(lds + WENGINE_LDS_WORDS + WIDE_AUX_WORDS);
+    if (L.tid == 0) *qn = 0;
+    const float gmax = fmaxf(__uint_as_float(maxn[0]), __uint_as_float(maxn[1]));
+    CrossWideEpilogue epi(L);
+    epi.fc = fc;
+    epi.qnorm = cnorm;
+    epi.qthr = cthr;
+    epi.nq = Nc;
+    epi.rnmax_c = fc * gmax;
+    epi.aux = lds + WENGINE_LDS_WORDS;
+    epi.col_count = col_count;
+    epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
+    epi.qn = qn;
+    epi.qcap = qcap;
+    epi.ovq = ovq;
+    epi.ov_count = ov_count;
+    epi.ovcap = ovcap;
+    epi.fail = fail;
+    epi.dsc = half_unscale(maxn[2], maxn[3]);
+    if (blockIdx.x == 0 && L.tid == 0 && !(half_scale_ok(maxn[2]) && half_scale_ok(maxn[3]))) *fail = 1;
+    const int64_t prow0 = w.rb * WTB;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int64_t i = prow0 + L.wn * 64 + nt * 32 + L.r;
+        const bool ok = i < Nr;
+        epi.prow[nt] = i;
+        epi.rowok[nt] = ok;
+        epi.xn[nt] = ok ? rnorm[i] : 0.f;
+        const float e = fc * ((ok ? rnorm[i] : 0.f) + gmax);
+        epi.thi[nt] = ok ? rthr[i] + e : -INFINITY;
+        epi.tlo[nt] = ok ? rthr[i] - e : -INFINITY;
+        epi.e2[nt] = 2.f * e;
+        epi.m[nt] = (WANT_MIN && ok) ? __uint_as_float(rmin_approx[i]) : INFINITY;
+        epi.anyf[nt] = ok ? (row_any[i] != 0u) : true;
+        epi.covf[nt] = false;
+    }
+    CrossWideShim<WANT_MIN> shim{epi};
+    wide_pipeline(Cb, Nc, ldc, WideTiles{w.qtile0}, Rb, Nr, ldr, prow0, w.ntiles, Dh, lds, L, shim);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float mn = fminf(epi.m[nt], __shfl_xor(epi.m[nt], 32));
+        const int other = __shfl_xor((int)epi.anyf[nt], 32);
+        const int other_c = __shfl_xor((int)epi.covf[nt], 32);
+        const bool any = epi.anyf[nt] || other != 0;
+        const bool cov = epi.covf[nt] || other_c != 0;
+        if (L.h == 0 && epi.rowok[nt]) {
+            if constexpr (WANT_MIN) atomicMin(rmin_approx + epi.prow[nt], __float_as_uint(mn));
+            if (any) atomicOr(row_any + epi.prow[nt], 1u);
+            if (cov) atomicOr(row_cover + epi.prow[nt], 1u);
+        }
+    }
+    __syncthreads();
+    if (L.tid == 0) wgq_count[blockIdx.x] = *qn < qcap ? *qn : qcap;
+}
+
+
+int launch_cross_wide(bool want_min, unsigned blocks, const float* Rb, int64_t Nr, int64_t ldr, const float* rnorm, const float* rthr,
+                      const float* Cb, int64_t Nc, int64_t ldc, const float* cnorm, const float* cthr, int Dh, int nchunks,
+                      int grp_rows, const unsigned* maxn, unsigned* rmin_approx, unsigned* row_any, unsigned* row_cover,
+                      int32_t* col_count, uint2* wgq, int qcap, int* wgq_count, uint2* ovq, int* ov_count, int ovcap, int* fail,
+                      float fc, hipStream_t st) {
+    AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&cross_wide_kernel<true>), (int)WIDE_CROSS_LDS_BYTES));
+    AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&cross_wide_kernel<false>), (int)WIDE_CROSS_LDS_BYTES));
+#ifdef AM_DEV_KNOBS
+    AM_HIP_TRY(set_wide_dev_symbols(st));
+#endif
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(WTHREADS), WIDE_CROSS_LDS_BYTES, st, Rb, Nr, ldr, rnorm, rthr, Cb, Nc, ldc,
+                           cnorm, cthr, Dh, nchunks, grp_rows, maxn, rmin_approx, row_any, row_cover, col_count, wgq, qcap,
+                           wgq_count, ovq, ov_count, ovcap, fail, fc);
+    };
+    if (want_min) launch(&cross_wide_kernel<true>);
+    else launch(&cross_wide_kernel<false>);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+// The same sweep on the 256 x 256 f16 engine (wide_engine.h): row blocks and column tiles of 256 rows, 512 threads.
+constexpr size_t KNN_WIDE_LDS_BYTES = (WENGINE_LDS_WORDS + 4 * WTB) * sizeof(float) + 16;
+
+template <int KCAP>
+__global__ void __launch_bounds__(WTHREADS, 1)
+knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float* __restrict__ xnorm, float* thr, int Dh,
+                int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
+                int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
+                int* __restrict__ wgq_count, int part, int nparts, float fc, uint2* __restrict__ ovq, float* __restrict__ ovv,
+                unsigned long long* __restrict__ ovn, int ovcap) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const WLane L;
+    const int64_t T = (N + WTB - 1) / WTB;
+    const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
+    if (sw.ntiles == 0) {
+        if (L.tid == 0) wgq_count[blockIdx.x] = 0;
+        return;
+    }
+    const float nmax = __uint_as_float(maxn[0]);
+    KnnFastEpilogue<KCAP, WLane, WTB, 4> epi(L);
+    epi.qnorm = xnorm;
+    epi.thr = thr;
+    epi.n = N;
+    epi.pblock = sw.pb;
+    epi.aux = lds + WENGINE_LDS_WORDS;
+    epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
+    epi.wgv = wgv + (int64_t)blockIdx.x * qcap;
+    epi.qn = reinterpret_cast<int*>(lds + WENGINE_LDS_WORDS + 4 * WTB);
+    epi.qcap = qcap;
+    epi.ovq = ovq;
+    epi.ovv = ovv;
+    epi.ovn = ovn;
+    epi.ovcap = ovcap;
+    epi.cnt = cnt;
+    epi.cap = cap;
+    epi.dsc = half_unscale(maxn[2], maxn[2]);
+    if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int64_t i = sw.pb * WTB + L.wn * 64 + nt * 32 + L.r;
+        epi.prow[nt] = (unsigned)i;
+        epi.xn[nt] = i < N ? xnorm[i] : INFINITY;
+        epi.e2c = 2.f * fc;
+        epi.e2n = 2.f * fc * nmax;
+        epi.flt[nt] = i < N ? __hip_atomic_load(thr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = s < KCAP - k1 ? -INFINITY : INFINITY;
+    }
+    wide_pipeline(Xb, N, ldh, WideTiles{sw.qa}, Xb, N, ldh, sw.pb * WTB, sw.ntiles, Dh, lds, L, epi);
+    float* mg = lds;                                   // [256][4][KCAP]: the engine's buffers are free now
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float* dst = mg + ((L.wn * 64 + nt * 32 + L.r) * 4 + (L.wm * 2 + L.h)) * KCAP;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
+    }
+    __syncthreads();
+    if (L.tid == 0) wgq_count[blockIdx.x] = min(*epi.qn, qcap);
+    if (L.tid < WTB) {
+        const int64_t i = sw.pb * WTB + L.tid;
+        if (i < N) {
+            const float* src = mg + L.tid * 4 * KCAP;
+            float m[KCAP];
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) m[s] = src[s];
+            for (int s = KCAP; s < 4 * KCAP; ++s)
+                if (src[s] > -INFINITY) list_insert<KCAP>(m, src[s]);
+            float* out = partial + ((int64_t)sw.W * N + i) * KCAP;
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) __hip_atomic_store(out + s, m[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int w2 = sw.W + 1; w2 < nwin; ++w2) {
+                const float* src2 = partial + ((int64_t)w2 * N + i) * KCAP;
+                for (int s = 0; s < KCAP; ++s) {
+                    const float v = __hip_atomic_load(src2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v > -INFINITY) list_insert<KCAP>(m, v);
+                }
+            }
+            const float kthv = m[KCAP - 1];
+            const float bound = kthv + 2.f * fc * (xnorm[i] + nmax);
+            atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
+        }
+    }
+}
+
+
+template <int KCAP>
+static int launch_knn_wide_t(unsigned nwg, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, float* thr, int Dh,
+                             int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
+                             uint2* wgq, float* wgv, int qcap, int* wgq_count, int part, int nparts, float fc, uint2* ovq,
+                             float* ovv, unsigned long long* ovn, int ovcap, hipStream_t st) {
+    AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_wide_kernel<KCAP>), (int)KNN_WIDE_LDS_BYTES));
+#ifdef AM_DEV_KNOBS
+    AM_HIP_TRY(set_wide_dev_symbols(st));
+#endif
+    hipLaunchKernelGGL(knn_wide_kernel<KCAP>, dim3(nwg), dim3(WTHREADS), KNN_WIDE_LDS_BYTES, st, Xb, N, ldh, xnorm, thr, Dh, win_tiles,
+                       nwin, per_win, k1, maxn, partial, cnt, cap, wgq, wgv, qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+int launch_knn_wide(int kcap, unsigned nwg, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, float* thr, int Dh,
+                    int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
+                    uint2* wgq, float* wgv, int qcap, int* wgq_count, int part, int nparts, float fc, uint2* ovq, float* ovv,
+                    unsigned long long* ovn, int ovcap, hipStream_t st) {
+    if (kcap == 6)
+        return launch_knn_wide_t<6>(nwg, Xb, N, ldh, xnorm, thr, Dh, win_tiles, nwin, per_win, k1, maxn, partial, cnt, cap, wgq, wgv,
+                                    qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap, st);
+    AM_REQUIRE(kcap == 11, AM_ERR_UNSUPPORTED_K, "the wide k-NN sweep holds lists of 6 or 11 entries (got %d)", kcap);
+    return launch_knn_wide_t<11>(nwg, Xb, N, ldh, xnorm, thr, Dh, win_tiles, nwin, per_win, k1, maxn, partial, cnt, cap, wgq, wgv,
+                                 qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap, st);
+}
+
+}  // namespace am

@@ -26,6 +26,7 @@
 // Results feed error-bounded filters only, so the accumulation order inside the instruction is irrelevant.
 #pragma once
 #include "tile_engine.h"
+#include <type_traits>
 
 namespace am {
 
@@ -53,6 +54,9 @@ struct WLane {
 __device__ __forceinline__ TileRsrc make_wide_rsrc(const float* base, int64_t ld, int64_t n_rows, int64_t row0) {
     int64_t valid = n_rows - row0;
     valid = valid < 0 ? 0 : (valid > WTB ? WTB : valid);
+#ifdef AM_DEV_KNOBS
+    if ((g_wide_dbg & 1) && valid > 0) row0 = row0 % (8 * WTB);
+#endif
     const float* p = base + (valid > 0 ? row0 : 0) * ld;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(p) & 0xffffffffu));
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(p) >> 32));
@@ -75,6 +79,19 @@ __device__ __forceinline__ void wide_zero(f32x16 (&acc)[4][2]) {
 // Q, P: f16 matrices viewed as f32 words (ld and Dh in words, Dh % 32 == 0).  tmap(t) = index of the 256-row Q tile
 // that local tile t multiplies; P block = rows prow0 .. prow0 + 255.  Epi as in tile_engine.h:
 //   aux_issue(t, qtile) / aux_commit(t) : per-tile side data through LDS;  finish(t, qtile, acc[4][2])
+//
+// Schedule of one stage (k-slab g of 64 f16, four chunks c0..c3 of 8 MFMAs per wave).  An LDS-DMA piece costs its wave
+// ~60-180 issue cycles; eight of them in a row at the top of the stage - the obvious order - keep BOTH waves of every
+// SIMD off the matrix pipe right after each barrier.  The pieces of stage g+1 are therefore slipped in one per two MFMAs
+// during the first sixteen MFMAs of stage g (pinned with sched_barrier: the compiler would hoist them back to the top).
+// Measured with tools/ubench/stage_sched.hip / stream_prefetch.hip on random operands, 2 x 100 MB, the membership
+// kernel's sharing pattern: 1.88 -> ~1.6 us per stage.  (Carrying the last chunk of a stage across the barrier so that
+// its MFMAs cover the first fragment reads gains a further 6 % in the microbenchmark; in the real kernels - both of
+// them, also the membership filter at 225 registers - the two-path loop it needs (epilogue before / after the first
+// fragment reads) makes the register allocator spill 180-600 registers.  Instead the first MFMA pair of a stage starts
+// as soon as ITS three fragments are back and the reads of the second chunk go out behind it.)
+// LDS safety: stage g+1 is written into the buffer that stage g-1 was read from; every wave has finished those reads
+// (s_waitcnt lgkmcnt(0) of __syncthreads) before the barrier that ends stage g-1, and the pieces are issued after it.
 template <class TileMap, class Epi>
 __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64_t nq, int64_t ldq, const TileMap& tmap,
                                               const float* __restrict__ P, int64_t np, int64_t ldp, int64_t prow0,
@@ -84,25 +101,23 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
     const int wave = __builtin_amdgcn_readfirstlane(L.wave);
     const int srow = L.tid >> 3;                                   // 0..63 (+64 j)
     const int chunk = (L.tid & 7) ^ ((srow >> 1) & 7);             // 16-B chunk of the row this thread fetches into slot tid & 7
-    unsigned voq[4], vop[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        voq[j] = (unsigned)(((int64_t)(j * 64 + srow) * ldq + chunk * 4) * 4);
-        vop[j] = (unsigned)(((int64_t)(j * 64 + srow) * ldp + chunk * 4) * 4);
-    }
+    // byte offset of this thread's 16 B inside a 64-row group; the group's own offset (j * 64 rows) is wave-uniform and
+    // travels in the instruction's scalar offset (two address registers instead of eight)
+    const unsigned voq = (unsigned)(((int64_t)srow * ldq + chunk * 4) * 4), vop = (unsigned)(((int64_t)srow * ldp + chunk * 4) * 4);
+    const unsigned gq = (unsigned)(64 * ldq * 4), gp = (unsigned)(64 * ldp * 4);
     const TileRsrc prs = make_wide_rsrc(P, ldp, np, prow0);
     const int64_t q_tiles_total = (nq + WTB - 1) / WTB;
     auto qtile_of = [&](int t) -> int64_t { return t < ntiles ? tmap(t) : q_tiles_total; };   // past the end: empty descriptor
-    int ft = 0, fkt = 0;                                           // (tile, k-slab) of the next fetch
+    int ft = 0, fkt = 0;                                           // (tile, k-slab) of the stage being fetched
     TileRsrc qrs = make_wide_rsrc(Q, ldq, nq, qtile_of(0) * WTB);
-    auto issue = [&](int g) {
+    // piece j of the stage being fetched into buffer `buf`: even j -> 64 Q rows, odd j -> 64 P rows
+    auto piece = [&](int buf, int j) {
         const unsigned so = (unsigned)(fkt * WROW * 4);
-        float* s = lds + (g & 1) * WSTAGE_WORDS + wave * 8 * WROW;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            lds_direct_b128(qrs, s + j * 64 * WROW, voq[j], so);
-            lds_direct_b128(prs, s + WTILE_WORDS + j * 64 * WROW, vop[j], so);
-        }
+        float* s = lds + buf * WSTAGE_WORDS + wave * 8 * WROW;
+        if ((j & 1) == 0) lds_direct_b128(qrs, s + (j >> 1) * 64 * WROW, voq, so + (unsigned)(j >> 1) * gq);
+        else lds_direct_b128(prs, s + WTILE_WORDS + (j >> 1) * 64 * WROW, vop, so + (unsigned)(j >> 1) * gp);
+    };
+    auto advance_fetch = [&]() {
         if (++fkt == nk) {
             fkt = 0;
             ++ft;
@@ -120,67 +135,90 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
         f32x4 q[4], p[2];
     };
     auto frags = [&](const float* st, int c) {
-        Frags f;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) f.q[m] = *reinterpret_cast<const f32x4*>(st + qrow + m * 32 * WROW + coff[c]);
+        Frags f;                                                    // P first: every MFMA of the chunk needs one of them
 #pragma unroll
         for (int n = 0; n < 2; ++n) f.p[n] = *reinterpret_cast<const f32x4*>(st + prow + n * 32 * WROW + coff[c]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) f.q[m] = *reinterpret_cast<const f32x4*>(st + qrow + m * 32 * WROW + coff[c]);
         return f;
     };
     f32x16 acc[4][2];
     wide_zero(acc);
-    auto mm = [&](const Frags& f) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const f16x8 a = __builtin_bit_cast(f16x8, f.q[m]);
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, f.p[n]), acc[m][n], 0, 0, 0);
-        }
-    };
-    // first chunk of a tile: C = 0 as an inline constant instead of 128 register clears per tile
-    auto mm_first = [&](const Frags& f) {
+    // eight MFMAs of one chunk; FIRST: C = 0 as an inline constant (first chunk of a tile, no accumulator clears);
+    // DMA: pieces j0 .. j0+3 of the next stage follow the MFMA pairs
+    // (M_LO, M_HI are template arguments on purpose: with run-time bounds the accumulator array is indexed dynamically
+    // until the loop is unrolled, which is too late for it to be promoted to registers cleanly)
+    auto mm = [&](const Frags& f, bool first, bool dma, int buf, int j0, auto m_lo, auto m_hi) {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = decltype(m_lo)::value; m < decltype(m_hi)::value; ++m) {
             const f16x8 a = __builtin_bit_cast(f16x8, f.q[m]);
 #pragma unroll
             for (int n = 0; n < 2; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, f.p[n]), zero, 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, f.p[n]), first ? zero : acc[m][n], 0, 0, 0);
+            if (dma) piece(buf, j0 + m);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    issue(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) piece(0, j);
+    advance_fetch();
     epi.aux_issue(0, qtile_of(0));
     __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
     epi.aux_commit(0);
     __syncthreads();
 
+#ifdef AM_DEV_KNOBS
+    unsigned long long* trace = nullptr;
+    if (g_wide_trace != nullptr && blockIdx.x < 64 && (wave == 0 || wave == 4) && L.lane == 0)
+        trace = g_wide_trace + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 96 * 6;
+#define WIDE_STAMP(k) do { if (trace != nullptr && g < 96) trace[g * 6 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WIDE_STAMP(k) do { } while (0)
+#endif
     int t = 0, kt = 0;
     for (int g = 0; g < G; ++g) {
-        const bool last_k = (kt == nk - 1);
-        const int nt_ = last_k ? t + 1 : t;
-        const int nkt = last_k ? 0 : kt + 1;
-        if (g + 1 < G) issue(g + 1);
-        if (last_k) epi.aux_issue(nt_, qtile_of(nt_));
         const float* st = lds + (g & 1) * WSTAGE_WORDS;
+        const bool more = g + 1 < G;
+        WIDE_STAMP(0);
+        const bool last_k = kt == nk - 1;
+        const int nbuf = (g + 1) & 1;
+        if (last_k && t + 1 < ntiles) epi.aux_issue(t + 1, qtile_of(t + 1));   // early: covered by this stage's vmcnt(0)
+        // the first MFMA pair starts as soon as its three fragments are back; the reads of c1 go out behind it
         Frags f0 = frags(st, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt == 0) mm(f0, true, more, nbuf, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        else mm(f0, false, more, nbuf, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
         Frags f1 = frags(st, 1);
-        if (kt == 0) mm_first(f0);
-        else mm(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt == 0) mm(f0, true, more, nbuf, 0, std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
+        else mm(f0, false, more, nbuf, 0, std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
+        WIDE_STAMP(1);
         f0 = frags(st, 2);
-        mm(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f1, false, more, nbuf, 4, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        if (more) advance_fetch();
+        WIDE_STAMP(2);
         f1 = frags(st, 3);
-        mm(f0);
-        mm(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f0, false, false, 0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        mm(f1, false, false, 0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        WIDE_STAMP(3);
         if (last_k) {
             epi.finish(t, qtile_of(t), acc);
-            epi.aux_commit(nt_);
+            if (t + 1 < ntiles) epi.aux_commit(t + 1);
         }
+        WIDE_STAMP(4);
         __builtin_amdgcn_s_waitcnt(0x0F70);         // the slab of stage g+1 has landed in LDS
+        WIDE_STAMP(5);
         __syncthreads();
-        t = nt_;
-        kt = nkt;
+        if (last_k) {
+            kt = 0;
+            ++t;
+        } else {
+            ++kt;
+        }
     }
 }
 

@@ -1,0 +1,167 @@
+// Microbenchmark of the wide engine's k-slab stage (256 x 256 tile, 8 waves, 64 KB LDS-DMA fill of the NEXT stage, 24
+// ds_read_b128 + 32 v_mfma_f32_32x32x16_f16 per wave on the CURRENT one, one barrier per stage) under different
+// instruction schedules.  Data are meaningless; only the instruction mix, the LDS traffic and the fill traffic count.
+//   V0  today's order: 8 LDS-DMA pieces first, then fragments / MFMAs, vmcnt(0) + barrier
+//   V1  DMA pieces interleaved with the first 16 MFMAs (one piece per two MFMAs)
+//   V2  V1 + the last chunk's 8 MFMAs are carried across the barrier (they cover the first fragment reads)
+//   V3  V2 + SIMD partners (waves w, w + 4) issue their pieces in different halves of the stage
+// Build: hipcc --offload-arch=gfx950 -O3 stage_sched.hip -o stage_sched
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int WROW = 32, WTB = 256, TILE_WORDS = WTB * WROW, STAGE_WORDS = 2 * TILE_WORDS;
+
+struct Frags { f32x4 q[4], p[2]; };
+
+template <int V>
+__global__ void __launch_bounds__(512, 1) stage(const float* __restrict__ src, int64_t src_rows, int ld_words, int stages, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, r = lane & 31, h = lane >> 5;
+    const int srow = tid >> 3, chunk = (tid & 7) ^ ((srow >> 1) & 7);
+    const int sw = (r >> 1) & 7;
+    int coff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) coff[c] = ((2 * c + h) ^ sw) * 4;
+    const int qrow = (wm * 128 + r) * WROW, prow = TILE_WORDS + (wn * 64 + r) * WROW;
+    auto frags = [&](const float* st, int c) {
+        Frags f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) f.q[m] = *reinterpret_cast<const f32x4*>(st + qrow + m * 32 * WROW + coff[c]);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) f.p[n] = *reinterpret_cast<const f32x4*>(st + prow + n * 32 * WROW + coff[c]);
+        return f;
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    auto mma = [&](const Frags& f, int m, int n) {
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.q[m]), __builtin_bit_cast(f16x8, f.p[n]), acc[m][n], 0, 0, 0);
+    };
+    const int64_t nblk = src_rows / 512;
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned vo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vo[j] = (unsigned)(((j * 64 + srow) * ld_words + chunk * 4) * 4);
+    auto set_src = [&](int g) {
+        const int64_t blk = ((int64_t)blockIdx.x * 7 + (g >> 3) * 13) % nblk;
+        const float* base = src + (blk * 512) * (int64_t)ld_words + (g & 7) * 32;
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(512 * ld_words * 4 - (g & 7) * 128), 0x00020000);
+    };
+    auto piece = [&](int g, int j) {
+        float* st = lds + (g & 1) * STAGE_WORDS;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(st + (j * 64 + wave * 8) * 32), 16, (int)vo[j], 0, 0, 0);
+    };
+    auto mm = [&](const Frags& f) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { mma(f, m, 0); mma(f, m, 1); }
+    };
+    // 8 MFMAs with the DMA pieces j0 .. j0+3 of stage g slipped in after every second one
+    auto mm_dma = [&](const Frags& f, int g, int j0, bool on) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            mma(f, m, 0);
+            mma(f, m, 1);
+            if (on) piece(g, j0 + m);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    set_src(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) piece(0, j);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    Frags f0, f1;
+    if (V >= 2) f1 = frags(lds, 3);
+    for (int g = 0; g < stages; ++g) {
+        const float* st = lds + (g & 1) * STAGE_WORDS;
+        set_src(g + 1);
+        if (V == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) piece(g + 1, j);
+            f0 = frags(st, 0);
+            f1 = frags(st, 1);
+            mm(f0);
+            f0 = frags(st, 2);
+            mm(f1);
+            f1 = frags(st, 3);
+            mm(f0);
+            mm(f1);
+        } else if (V == 1) {
+            f0 = frags(st, 0);
+            f1 = frags(st, 1);
+            mm_dma(f0, g + 1, 0, true);
+            f0 = frags(st, 2);
+            mm_dma(f1, g + 1, 4, true);
+            f1 = frags(st, 3);
+            mm(f0);
+            mm(f1);
+        } else {
+            const bool early = (V == 2) || (wave < 4);
+            f0 = frags(st, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm_dma(f1, g + 1, 0, early);           // chunk 3 of the previous stage: operands already in registers
+            f1 = frags(st, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm_dma(f0, g + 1, 4, early);
+            f0 = frags(st, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mm_dma(f1, g + 1, 0, !early);
+            f1 = frags(st, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mm_dma(f0, g + 1, 4, !early);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+    float sink = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) sink += acc[a][b][5];
+    if (V >= 2) sink += f1.q[0].x;
+    if (sink == 12345.678f) out[0] = sink;
+}
+
+template <int V>
+static void run(const float* src, int64_t rows, int ld_words, float* out, int src_mb) {
+    const int stages = 4096;
+    const size_t lds_bytes = 2 * STAGE_WORDS * 4;
+    hipFuncSetAttribute((const void*)stage<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(stage<V>, dim3(256), dim3(512), lds_bytes, 0, src, rows, ld_words, 64, out);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(stage<V>, dim3(256), dim3(512), lds_bytes, 0, src, rows, ld_words, stages, out);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / stages;
+    printf("src %3d MB schedule V%d: %.3f us per stage -> %.0f TFLOP/s of 2500 (%.2f)\n", src_mb, V, us,
+           2.0 * 256 * 256 * 64 * 256 / us * 1e-6, 2.0 * 256 * 256 * 64 * 256 / us * 1e-6 / 2500.0);
+}
+
+int main() {
+    for (int src_mb : {16, 200}) {
+        const int ld_words = 256;
+        const int64_t rows = (int64_t)src_mb * 1024;
+        float *src, *out;
+        (void)hipMalloc(&src, rows * 1024);
+        (void)hipMalloc(&out, 4);
+        (void)hipMemset(src, 0x11, rows * 1024);
+        run<0>(src, rows, ld_words, out, src_mb);
+        run<1>(src, rows, ld_words, out, src_mb);
+        run<2>(src, rows, ld_words, out, src_mb);
+        run<3>(src, rows, ld_words, out, src_mb);
+        (void)hipFree(src); (void)hipFree(out);
+    }
+    return 0;
+}
