@@ -55,7 +55,7 @@ __device__ __forceinline__ TileRsrc make_wide_rsrc(const float* base, int64_t ld
     int64_t valid = n_rows - row0;
     valid = valid < 0 ? 0 : (valid > WTB ? WTB : valid);
 #ifdef AM_DEV_KNOBS
-    if ((g_wide_dbg & 1) && valid > 0) row0 = row0 % (8 * WTB);
+    if ((g_wide_dbg & 1) && valid > 0) row0 = row0 % (4 * WTB);   // four blocks per operand: 2 MB in all, L2 resident
 #endif
     const float* p = base + (valid > 0 ? row0 : 0) * ld;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(p) & 0xffffffffu));
@@ -177,33 +177,49 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
 #else
 #define WIDE_STAMP(k) do { } while (0)
 #endif
+    // The pieces of "the next stage" are issued unconditionally - also in the last stage, where the Q descriptor is empty
+    // (qtile_of past the end: zero records, no memory traffic) and the P slab lands in a buffer nobody reads before the
+    // final vmcnt(0) + barrier: with a run-time "is there a next stage" flag every piece sat in its own basic block and
+    // the waits at the block joins were conservative.  The only branch left in a stage is first slab of a tile (C = 0) /
+    // later slab, taken BEFORE the first fragment reads, so that the first MFMA pair waits for exactly its three
+    // fragments.  (Four straight-line stage variants - first x last - were tried: the accumulator live ranges across a
+    // four-way join make the register allocator spill 130-450 registers.)
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I4 = std::integral_constant<int, 4>;
     int t = 0, kt = 0;
     for (int g = 0; g < G; ++g) {
         const float* st = lds + (g & 1) * WSTAGE_WORDS;
-        const bool more = g + 1 < G;
-        WIDE_STAMP(0);
         const bool last_k = kt == nk - 1;
         const int nbuf = (g + 1) & 1;
+        WIDE_STAMP(0);
         if (last_k && t + 1 < ntiles) epi.aux_issue(t + 1, qtile_of(t + 1));   // early: covered by this stage's vmcnt(0)
-        // the first MFMA pair starts as soon as its three fragments are back; the reads of c1 go out behind it
-        Frags f0 = frags(st, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt == 0) mm(f0, true, more, nbuf, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-        else mm(f0, false, more, nbuf, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-        Frags f1 = frags(st, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt == 0) mm(f0, true, more, nbuf, 0, std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
-        else mm(f0, false, more, nbuf, 0, std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
+        Frags f0, f1;
+        if (kt == 0) {
+            f0 = frags(st, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(f0, true, true, nbuf, 0, I0{}, I1{});
+            f1 = frags(st, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(f0, true, true, nbuf, 0, I1{}, I4{});
+        } else {
+            f0 = frags(st, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(f0, false, true, nbuf, 0, I0{}, I1{});
+            f1 = frags(st, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(f0, false, true, nbuf, 0, I1{}, I4{});
+        }
         WIDE_STAMP(1);
         f0 = frags(st, 2);
         __builtin_amdgcn_sched_barrier(0);
-        mm(f1, false, more, nbuf, 4, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-        if (more) advance_fetch();
+        mm(f1, false, true, nbuf, 4, I0{}, I4{});
+        advance_fetch();
         WIDE_STAMP(2);
         f1 = frags(st, 3);
         __builtin_amdgcn_sched_barrier(0);
-        mm(f0, false, false, 0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-        mm(f1, false, false, 0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        mm(f0, false, false, 0, 0, I0{}, I4{});
+        mm(f1, false, false, 0, 0, I0{}, I4{});
         WIDE_STAMP(3);
         if (last_k) {
             epi.finish(t, qtile_of(t), acc);
