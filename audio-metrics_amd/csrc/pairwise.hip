@@ -904,6 +904,7 @@ struct KnnPlan {
     int cap;                    // candidate slots per row (symmetric path)
     int qcap;                   // entries of each workgroup's append region (symmetric path)
     int win_tiles, nwin, per_win;   // symmetric path: column-tile windows and row blocks per window
+    int64_t nwg;                    // workgroups of the symmetric sweep (nwin * per_win)
     int pre_windows;                // symmetric path: rows of this many top windows get a sampled bound
 };
 
@@ -925,6 +926,7 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
     p.pre_stride = stride;
     p.pre_chunks = 1;
     p.qcap = 0;
+    p.nwg = 0;
     p.pre_windows = pre_windows;
     if (!p.sym) {
         p.nchunks = choose_chunks(N, M);
@@ -954,6 +956,7 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
     p.win_tiles = (int)ceil_div(half, slices);
     p.nwin = (int)ceil_div(T, p.win_tiles);
     p.per_win = (int)std::min<int64_t>(T, half + p.win_tiles);   // row blocks that can own a tile of one window
+    p.nwg = (int64_t)p.nwin * p.per_win;
     // Which rows need a sampled bound?  A row relies on the bounds its own block published from the windows
     // above it; those exist once the windows that are `in_flight` ahead have finished.  With ~512 resident
     // workgroups (256 CUs x 2) about 512/per_win windows run concurrently: rows in the top in_flight+2 windows
@@ -992,7 +995,7 @@ static size_t carve_knn(Carver& c, int64_t N, int64_t M, const KnnPlan& p, KnnBu
         b.cnt = c.take<int>(N + 1);               // [N] = overflow counter
         b.ov_list = c.take<int>(N);
         b.ov_count = b.cnt ? b.cnt + N : nullptr;
-        const size_t nwg = (size_t)p.nwin * p.per_win;
+        const size_t nwg = (size_t)p.nwg;
         b.wgq = c.take<uint2>(nwg * p.qcap);
         b.wgq_count = c.take<int>(nwg);
     } else {

@@ -58,6 +58,31 @@ struct SymWork {
     int ntiles;         // 0: nothing of this window belongs to this block / this rank
 };
 
+// tiles of window W that belong to row block pb (cyclic half-range pairing; see sym_work)
+__device__ __forceinline__ SymWork sym_item(int64_t T, int win_tiles, int W, int64_t pb, int part, int nparts) {
+    const int64_t q0 = (int64_t)W * win_tiles;
+    const int64_t q1 = (q0 + win_tiles < T) ? q0 + win_tiles : T;
+    // offsets 0 .. T/2; for even T the antipodal offset belongs to the lower-numbered block only
+    int64_t noff = T / 2 + 1;
+    if ((T % 2) == 0 && pb >= T / 2) noff = T / 2;
+    // tiles q of the window with (q - pb) mod T < noff form one contiguous piece (window << T/2)
+    int64_t qa = pb > q0 ? pb : q0, qb = (pb + noff < q1) ? pb + noff : q1;          // q >= pb
+    if (qa >= qb) {                                                                   // wrapped: q < pb
+        qa = q0;
+        qb = (pb + noff - T < q1) ? pb + noff - T : q1;
+    }
+    const int ntiles = qb > qa ? (int)(qb - qa) : 0;
+    // multi-GPU: rank `part` of `nparts` owns the CONTIGUOUS range of row blocks with floor(pb*nparts/T) == part
+    // (see am_knn_sym_part_f32).  Not pb mod nparts: consecutive blockIdx map to consecutive pb, and ownership
+    // by residue would put every owned workgroup of a window on the same XCD (blockIdx % 8).
+    SymWork w;
+    w.W = W;
+    w.pb = pb;
+    w.qa = qa;
+    w.ntiles = (ntiles == 0 || (int)(pb * nparts / T) != part) ? 0 : ntiles;
+    return w;
+}
+
 __device__ __forceinline__ SymWork sym_work(int64_t T, int win_tiles, int nwin, int per_win, int part, int nparts) {
     // Work item = (column-tile WINDOW, row block) over the CYCLIC HALF-RANGE pairing: block pb owns the tile
     // pairs (pb, q) with (q - pb) mod T in 0 .. T/2.  All workgroups in flight stream the same window of Q
@@ -85,26 +110,14 @@ __device__ __forceinline__ SymWork sym_work(int64_t T, int win_tiles, int nwin, 
     }
     int64_t pb = (q1 - 1 - r) % T;
     if (pb < 0) pb += T;
-    // offsets 0 .. T/2; for even T the antipodal offset belongs to the lower-numbered block only
-    int64_t noff = T / 2 + 1;
-    if ((T % 2) == 0 && pb >= T / 2) noff = T / 2;
-    // tiles q of the window with (q - pb) mod T < noff form one contiguous piece (window << T/2)
-    int64_t qa = pb > q0 ? pb : q0, qb = (pb + noff < q1) ? pb + noff : q1;          // q >= pb
-    if (qa >= qb) {                                                                   // wrapped: q < pb
-        qa = q0;
-        qb = (pb + noff - T < q1) ? pb + noff - T : q1;
-    }
-    const int ntiles = qb > qa ? (int)(qb - qa) : 0;
-    // multi-GPU: rank `part` of `nparts` owns the CONTIGUOUS range of row blocks with floor(pb*nparts/T) == part
-    // (see am_knn_sym_part_f32).  Not pb mod nparts: consecutive blockIdx map to consecutive pb, and ownership
-    // by residue would put every owned workgroup of a window on the same XCD (blockIdx % 8).
-    SymWork w;
-    w.W = W;
-    w.pb = pb;
-    w.qa = qa;
-    w.ntiles = (ntiles == 0 || (int)(pb * nparts / T) != part) ? 0 : ntiles;
-    return w;
+    return sym_item(T, win_tiles, W, pb, part, nparts);
 }
+
+// (An XCD-aware order of these items for the 256-row engine - the 32 workgroups resident on an XCD = 8 consecutive row
+// blocks x 4 consecutive windows, 3 MB of operands per L2 instead of 8 MB - was built and measured at 100k x 512: same
+// bits, 15 % more queue entries because four windows are in flight per row block, 6.55 -> 6.63 ms per launch.  With
+// every operand read confined to 2 MB the sweep gains 8 % at most (AM_WIDE_DBG=1): the kernel is bound by its
+// per-stage issue pattern and by the clock its power draw allows, not by L2 misses.)
 
 
 #ifdef AM_DEV_KNOBS

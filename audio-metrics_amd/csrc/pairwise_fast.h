@@ -1052,7 +1052,7 @@ static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan&
     KnnFastBuffers f;
     f.xb = c.take<uint16_t>((size_t)N * half_ld(D));
     f.maxn = c.take<unsigned>(4);
-    f.wgv = c.take<float>((size_t)p.nwin * p.per_win * p.qcap);
+    f.wgv = c.take<float>((size_t)p.nwg * p.qcap);
     f.fidx = c.take<unsigned>((size_t)N * p.cap);
     f.cnt2 = c.take<int>(N + 2);                  // [N] = pair counter
     f.pair_count = f.cnt2 ? f.cnt2 + N : nullptr;
@@ -1097,7 +1097,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     AM_HIP_TRY(hipMemsetAsync(f.cnt2, 0, (size_t)(N + 2) * sizeof(int), st));
     AM_HIP_TRY(hipMemsetAsync(f.ovn, 0, sizeof(unsigned long long), st));
     // 2) symmetric filter sweep
-    const unsigned nwg = (unsigned)p.nwin * (unsigned)p.per_win;
+    const unsigned nwg = (unsigned)p.nwg;
     const int64_t nlist = (int64_t)p.nwin * N * KCAP;
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)ceil_div(nlist, 256)), dim3(256), 0, st,
                        reinterpret_cast<unsigned*>(b.partial), nlist, 0x7f800000u);

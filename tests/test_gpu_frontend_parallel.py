@@ -1,0 +1,136 @@
+"""N2: the embedder pool / device-side aggregation and the one-process-per-GPU form of ``AudioMetrics``.
+
+* several embedder replicas (one worker thread each, batches dealt round-robin, per-replica device-side aggregation,
+  Chan merge of the partial statistics) must give the single-replica results - exercised on one GPU by listing the same
+  device twice (the reference spreads replicas over GPUs the same way: util/gpu_parallel.py:20-118);
+* ``AudioMetrics(process_group=...)``: every rank feeds its shard of the audio, the metrics are reduced across ranks by
+  distributed.py - two ranks sharing cuda:0 over gloo (RCCL needs one GPU per rank);
+* an RCCL run of the same thing, skipped when the box has fewer than two GPUs (so that the first 8-GPU run is not also
+  the first RCCL run)."""
+import os
+import random
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make(am, metrics, **kw):
+    c = gi.E2E
+    return am.AudioMetrics(metrics=metrics, embedder=gi.NumpyEmbedder(c["dim"], c["sr"]), mix_function=gi.e2e_mix,
+                           win_dur=c["win_dur"], **kw)
+
+
+def _audio():
+    c = gi.E2E
+    return (gi.e2e_pairs(c["seed"], c["n_ref"], c["seconds"], c["sr"]),
+            gi.e2e_pairs(c["seed"] + 1, c["n_cand"], c["seconds"], c["sr"], stem_gain=1.3))
+
+
+def test_two_replicas_match_one():
+    import audio_metrics_amd as am
+    ref, cand = _audio()
+    results = []
+    for devices in ([0], [0, 0]):
+        random.seed(5)
+        m = _make(am, ["fad", "kd", "prdc", "apa"], device_indices=devices)
+        m.add_reference(ref)
+        results.append((m.evaluate(cand), m.stem_reference.n, m.stem_reference.embeddings.clone()))
+    (one, n1, rows1), (two, n2, rows2) = results
+    assert n1 == n2 and one.keys() == two.keys()
+    # the same rows reach the statistics, in a different (per-replica) order: row-order-free metrics agree closely, KD
+    # draws subsets by row index and therefore differs like any two index draws do
+    assert torch.equal(torch.sort(rows1.sum(1))[0], torch.sort(rows2.sum(1))[0])
+    for key in ("fad", "apa"):
+        assert abs(one[key] - two[key]) <= 1e-5 * max(1.0, abs(one[key])), (key, one[key], two[key])
+    for key in ("precision", "recall", "density", "coverage"):
+        assert one[key] == two[key], key
+
+
+def test_embedder_exception_reaches_the_caller():
+    import audio_metrics_amd as am
+
+    class Broken(gi.NumpyEmbedder):
+        def forward(self, data, sr=None):
+            raise RuntimeError("embedder failed")
+
+    c = gi.E2E
+    m = am.AudioMetrics(metrics=["fad"], embedder=Broken(c["dim"], c["sr"]), mix_function=gi.e2e_mix, win_dur=c["win_dur"],
+                        device_indices=[0, 0])
+    with pytest.raises(RuntimeError, match="embedder failed"):
+        m.add_reference([x[:, 1] for x in _audio()[0]])
+
+
+def _rank_worker(rank, world, port, backend, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    device = rank if backend == "nccl" else 0
+    torch.cuda.set_device(device)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import audio_metrics_amd as am
+    ref, cand = _audio()
+    ref, cand = [x[:, 1] for x in ref], [x[:, 1] for x in cand]          # stems only: no shuffled pairing across ranks
+    m = _make(am, ["fad", "kd", "prdc"], device_indices=[device], process_group=dist.group.WORLD)
+    m.add_reference(ref[rank::world])
+    res = m.evaluate(cand[rank::world])
+    out_q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_ranks(backend):
+    import audio_metrics_amd as am
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(world):
+        rank, res = q.get(timeout=300)
+        results[rank] = res
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0] == results[1]                       # every rank reports the same values
+    ref, cand = _audio()
+    ref, cand = [x[:, 1] for x in ref], [x[:, 1] for x in cand]
+    m = _make(am, ["fad", "kd", "prdc"])
+    m.add_reference(ref)
+    single = m.evaluate(cand)
+    assert results[0].keys() == single.keys()
+    for key in ("precision", "recall", "density", "coverage"):
+        assert results[0][key] == single[key], key         # integer counts do not depend on who holds which rows
+    assert abs(results[0]["fad"] - single["fad"]) <= 1e-5 * abs(single["fad"])
+
+
+def test_process_group_audio_metrics_two_ranks_gloo():
+    _run_ranks("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
+def test_process_group_audio_metrics_two_ranks_rccl():
+    _run_ranks("nccl")
