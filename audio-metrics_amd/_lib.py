@@ -46,6 +46,9 @@ SIGNATURES = {
     "am_prdc_counts_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P,
                                    _P, c_size_t, _P]),
     "am_prdc_reduce": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P]),
+    "am_eigh_workspace_bytes": (c_size_t, [c_int]),
+    "am_eigh_sym_f64": (c_int, [_P, c_int, _P, _P, c_int, _P, c_size_t, _P]),
+    "am_project_f64": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, c_int, _P, _P]),
     "am_kernel_clock_enable": (c_int, [c_int]),
     "am_kernel_clock_read": (c_int, [c_int, _P, _P]),
     "am_knn_path": (c_int, [c_int64, c_int64, c_int, c_int, c_int]),

@@ -247,6 +247,38 @@ def stats_merge(n1, mean1, cov1, n2, mean2, cov2, inplace=False):
     return om, oc
 
 
+# ------------------------------------------------------------------ PCA projection support
+def eigh_descending(a, max_sweeps=40):
+    """(eigenvalues f64[D] descending, eigenvectors f64[D, D] with row i = vector i) of a symmetric PSD matrix."""
+    lib = _lib.load()
+    a = _f64(a, "matrix")
+    d = a.shape[0]
+    if a.dim() != 2 or a.shape[1] != d:
+        raise ValueError(f"expected a square matrix, got {tuple(a.shape)}")
+    evals = torch.empty(d, dtype=torch.float64, device=a.device)
+    evecs = torch.empty((d, d), dtype=torch.float64, device=a.device)
+    nb = lib.am_eigh_workspace_bytes(d)
+    ws = _workspace(nb, a.device)
+    _call(lib, "am_eigh_sym_f64", a.device, _ptr(a), d, _ptr(evals), _ptr(evecs), int(max_sweeps), _ptr(ws), nb)
+    return evals, evecs
+
+
+def project(x, mean, components):
+    """(x - mean) @ components.T as f64 [N, p] (IncrementalPCA.transform)."""
+    lib = _lib.load()
+    x = as_matrix(x)
+    mean, components = _f64(mean, "mean"), _f64(components, "components")
+    n, d = x.shape
+    p = components.shape[0]
+    if mean.numel() != d or components.dim() != 2 or components.shape[1] != d:
+        raise ValueError(f"projection shapes do not match: x {tuple(x.shape)}, mean {tuple(mean.shape)}, components {tuple(components.shape)}")
+    _same_device(x, mean, components)
+    out = torch.empty((n, p), dtype=torch.float64, device=x.device)
+    if n > 0:
+        _call(lib, "am_project_f64", x.device, _ptr(x), n, _ld(x), d, _ptr(mean), _ptr(components), p, _ptr(out))
+    return out
+
+
 # ------------------------------------------------------------------ Frechet
 def frechet(mu_x, cov_x, mu_y, cov_y, max_iter=64, tol=1e-13):
     lib = _lib.load()

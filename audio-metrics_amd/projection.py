@@ -11,9 +11,10 @@ D x D Gram matrix of that same stacked matrix:
     G = C^T diag(s^2) C + sum (x - batch_mean)(x - batch_mean)^T + corr corr^T
 
 with the scatter term from the HIP stats kernel (f64 accumulation); singular values are the
-square roots of the eigenvalues.  The D x D eigendecomposition and the N x D by D x p projection
-are library calls on the device (hipSOLVER / hipBLASLt through torch) - they sit between the
-aggregation and the metric kernels, not on the hot path itself."""
+square roots of the eigenvalues.  The D x D eigendecomposition (am_eigh_sym_f64: one-sided Jacobi
+in f64) and the N x D by D x p projection (am_project_f64: f64 matrix cores) are this library's own
+kernels too; what is left to torch here is O(D^2) glue on device tensors (the rank-one correction,
+the sign convention, scalings)."""
 import numpy as np
 import torch
 
@@ -80,9 +81,8 @@ class IncrementalPCA:
             gram = (c.T * s2) @ c + scatter_b + torch.outer(corr, corr)
             rows = c.shape[0] + n_samples + 1
         gram = 0.5 * (gram + gram.T)
-        evals, evecs = torch.linalg.eigh(gram)                # ascending
-        evals = torch.flip(evals, dims=(0,)).clamp_min(0.0)
-        vt = torch.flip(evecs, dims=(1,)).T.contiguous()      # rows = right singular vectors, descending
+        evals, vt = ops.eigh_descending(gram)                 # descending; rows of vt = right singular vectors
+        evals = evals.clamp_min(0.0)
         # svd_flip(u_based_decision=False): the entry of largest magnitude in each row becomes positive
         idx = vt.abs().argmax(dim=1)
         signs = torch.sign(vt[torch.arange(vt.shape[0], device=vt.device), idx])
@@ -117,7 +117,7 @@ class IncrementalPCA:
     def transform(self, x):
         """(x - mean_) @ components_^T in f64 -> device tensor [n, n_components]."""
         x = self._to_device(x)
-        return (x.to(torch.float64) - self.mean_.to(x.device)) @ self.components_.to(x.device).T
+        return ops.project(x, self.mean_.to(x.device), self.components_.to(x.device))
 
     # ------------------------------------------------------------ state (reference projection.py:23-46)
     def __getstate__(self):

@@ -211,6 +211,23 @@ int am_prdc_reduce(const int32_t* col_count, int64_t Nc,
                    const uint8_t* row_any, const uint8_t* row_cover, int64_t Nr,
                    int64_t* out4, am_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * N1  PCA projection support                   reference: projection.py:6-46 (scikit-learn IncrementalPCA),
+ *                                                           audio_metrics.py:163-209
+ *   am_eigh_sym_f64  eigen-decomposition of a symmetric POSITIVE SEMI-DEFINITE D x D matrix (the Gram matrix of the
+ *                    stacked, centred batch whose SVD scikit-learn takes): evals[D] in DESCENDING order, evecs[D][D]
+ *                    with row i = eigenvector i (unit norm; sign not normalised - the caller applies scikit-learn's
+ *                    svd_flip).  One-sided Jacobi in f64; SYNCHRONISES `stream` once per sweep (fitting happens once
+ *                    per reference set, not per evaluate).  AM_ERR_NO_CONVERGENCE after max_sweeps (<= 0: 40).
+ *   am_project_f64   out[N][p] (f64) = (X[n][:] - mean[:]) . components[j][:]  - IncrementalPCA.transform - on the f64
+ *                    matrix cores; X is the N x D f32 embedding matrix, mean f64[D], components f64[p][D].
+ * ------------------------------------------------------------------------- */
+size_t am_eigh_workspace_bytes(int D);
+int am_eigh_sym_f64(const double* A, int D, double* evals, double* evecs, int max_sweeps,
+                    void* ws, size_t ws_bytes, am_stream_t stream);
+int am_project_f64(const float* X, int64_t N, int64_t ld, int D, const double* mean, const double* components, int p,
+                   double* out, am_stream_t stream);
+
 /* ---- optional kernel clock (benchmark support; bench.py's roofline) --------------------------------
  * When enabled, the library brackets every launch of the two tile kernels with a hipEvent pair recorded on
  * the caller's stream, so a benchmark can report the duration of exactly that kernel (the figure

@@ -627,3 +627,25 @@ def test_frechet_enqueue_matches_blocking_call(am):
         job = ops.frechet_async(a.mean, a.cov, b.mean, b.cov)
         got = job.result()
         assert got["fd"] == sync["fd"] and got["iters"] == sync["iters"], (kind, got, sync)
+
+
+def test_own_eigensolver_and_projection(am):
+    """am_eigh_sym_f64 (one-sided Jacobi) against numpy's eigh on Gram matrices of different shapes (odd size, rank
+    deficient, D = 512), and am_project_f64 against the f64 matrix product."""
+    ops = am.hip_ops
+    rng = np.random.default_rng(9)
+    for d, rows in ((7, 50), (24, 500), (129, 60), (512, 3000)):
+        x = rng.standard_normal((rows, d)) * np.logspace(0, -2, d)
+        g = x.T @ x
+        evals, evecs = ops.eigh_descending(torch.as_tensor(g).to("cuda:0"))
+        evals, evecs = evals.cpu().numpy(), evecs.cpu().numpy()
+        want = np.linalg.eigvalsh(g)[::-1]
+        np.testing.assert_allclose(evals, want, rtol=1e-9, atol=1e-10 * want[0])
+        assert np.all(np.diff(evals) <= 0)
+        np.testing.assert_allclose(evecs @ evecs.T, np.eye(d), atol=1e-10)                 # orthonormal rows
+        np.testing.assert_allclose(evecs @ g @ evecs.T, np.diag(evals), atol=1e-9 * want[0])
+    x = rng.standard_normal((1000, 70)).astype(np.float32)
+    mean = rng.standard_normal(70)
+    comp = rng.standard_normal((9, 70))
+    got = ops.project(torch.as_tensor(x).to("cuda:0"), torch.as_tensor(mean).to("cuda:0"), torch.as_tensor(comp).to("cuda:0"))
+    np.testing.assert_allclose(got.cpu().numpy(), (x.astype(np.float64) - mean) @ comp.T, rtol=1e-12, atol=1e-12)
