@@ -12,6 +12,7 @@
 //             fixed order (deterministic, no float atomics).
 #include "am_common.h"
 #include "tile_engine.h"
+#include <algorithm>
 
 namespace am {
 
@@ -81,7 +82,9 @@ __device__ __forceinline__ void tri_decode(int t, int T, int& tp, int& tq) {   /
     tq = tp + rem;
 }
 
-__global__ void __launch_bounds__(ENGINE_THREADS, 1)
+// (2 waves per SIMD: two workgroups per CU - 2 x 64 KB of LDS - cover each other's barriers, f64 flushes and load latency;
+// with one wave per SIMD every such stall idled the matrix pipe: 74 TF)
+__global__ void __launch_bounds__(ENGINE_THREADS, 2)
 scatter_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ld, int D, const double* __restrict__ mean,
                        int64_t rows_per_slab, int ntri, double* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float lds[4 * SC_SLAB];    // [2 stages][A slab, B slab]
@@ -250,7 +253,7 @@ static StatsPlan plan_stats(int64_t N, int D) {
     p.cs_blocks = (int)ceil_div(N, p.cs_rows);
     const int T = (int)ceil_div(D, TB);
     p.ntri = T * (T + 1) / 2;
-    int64_t s = ceil_div(768, p.ntri);                       // ~3 workgroups per CU
+    int64_t s = std::max<int64_t>(1024 / p.ntri, 1);         // just under two rounds of 256 CUs x 2 resident workgroups
     const int64_t max_s = ceil_div(N, SC_ROWS * SC_FLUSH);   // at least one full f32 chain per slab
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
