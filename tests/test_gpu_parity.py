@@ -424,27 +424,6 @@ def test_membership_filter_unequal_sets_bit_exact(am, n_ref, n_cand):
     assert np.array_equal(rcov.cpu().numpy().astype(bool), emin < r_ref)
 
 
-def test_knn_longer_lists_stay_fast(am):
-    """Regression guard: the k = 10 instantiation of the filter sweep (the drop-in API's default k) once spilled to scratch
-    memory after an unrelated change and ran 2.6x slower than it should; its time must stay within 2x of k = 5."""
-    import time
-    x = torch.randn(40000, 256, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(3))
-
-    def best_ms(k):
-        am.hip_ops.knn_radii(x, k)
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            am.hip_ops.knn_radii(x, k)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
-        return min(ts) * 1e3
-
-    t5, t10 = best_ms(5), best_ms(10)
-    assert t10 < 2.0 * t5 + 0.5, (t5, t10)
-
-
 # ----------------------------------------------------------------- PCA projection (n_pca)
 def test_incremental_pca_vs_reference(am, golden):
     """Device PCA against the reference's scikit-learn based IncrementalPCA: first fit, incremental update,
