@@ -278,6 +278,8 @@ int launch_cross_wide(bool want_min, unsigned blocks, const float* Rb, int64_t N
                       int grp_rows, const unsigned* maxn, unsigned* rmin_approx, unsigned* row_any, unsigned* row_cover,
                       int32_t* col_count, uint2* wgq, int qcap, int* wgq_count, uint2* ovq, int* ov_count, int ovcap, int* fail,
                       float fc, hipStream_t st);
+int launch_knn_wide_sample(int kcap, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, int Dh, int stride, int nchunks,
+                           const unsigned* maxn, float* partial, hipStream_t st);
 int launch_knn_wide(int kcap, unsigned nwg, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, float* thr, int Dh,
                     int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
                     uint2* wgq, float* wgv, int qcap, int* wgq_count, int part, int nparts, float fc, uint2* ovq, float* ovv,

@@ -1085,10 +1085,22 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
         hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, bounds_in, thr, b.xn, N, maxn, fast_c(D));
         AM_LAUNCH_CHECK();
     } else {
-        if ((rc = launch_knn_vt<KCAP, EV_FAST, false>(Xb, N, ldh, b.xn, Xb, N, ldh, b.xn, Dh, p.pre_chunks, p.pre_stride, b.partial,
-                                                      st, maxn)) != AM_OK)
+        int sample_chunks = p.pre_chunks;
+        if (p.tile_rows == WIDE_TILE_ROWS) {              // the sample pass on the 256-row engine: every pre_stride-th 256-row tile
+            // chunks per row block: the split that leaves the shortest schedule on 256 CUs (rounds x tiles per workgroup)
+            const int64_t rb = ceil_div(N, WIDE_TILE_ROWS), samples = ceil_div(rb, p.pre_stride);
+            int64_t best_cost = INT64_MAX;
+            for (int c = 1; c <= 8 && c <= samples; ++c) {
+                const int64_t cost = ceil_div(rb * c, 256) * ceil_div(samples, c);
+                if (cost < best_cost) { best_cost = cost; sample_chunks = c; }
+            }
+            if ((rc = launch_knn_wide_sample(KCAP, Xb, N, ldh, b.xn, Dh, p.pre_stride, sample_chunks, maxn, b.partial, st)) != AM_OK)
+                return rc;
+        } else if ((rc = launch_knn_vt<KCAP, EV_FAST, false>(Xb, N, ldh, b.xn, Xb, N, ldh, b.xn, Dh, p.pre_chunks, p.pre_stride,
+                                                             b.partial, st, maxn)) != AM_OK) {
             return rc;
-        hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.partial, N, p.pre_chunks,
+        }
+        hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.partial, N, sample_chunks,
                            k1, 1, thr);
         hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, thr, thr, b.xn, N, maxn, 2.f * fast_c(D));
         AM_LAUNCH_CHECK();

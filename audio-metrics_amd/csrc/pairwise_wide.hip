@@ -366,6 +366,126 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
 }
 
 
+// ---- sampled bound pass on the 256-row engine ---------------------------------------------------------------------
+// Every row needs an upper bound of its final (k+1)-th smallest value before the sweep starts.  It comes from every
+// `stride`-th column tile (the row's own columns included): per accumulator tile the smallest of the sixteen approximate
+// values goes into the lane's list - values of DISTINCT columns, so the (k+1)-th smallest of the merged lists bounds the
+// (k+1)-th smallest over the sample, and that the row's final value, from above.  (The 128-row engine did this pass at
+// 0.55 PF: 1.16 ms per set at 100k x 512.)
+template <int KCAP>
+struct KnnSampleEpilogue {
+    const float* qnorm;
+    int64_t n;
+    float* aux;                 // LDS [2][WTB] : |x_j|^2 of the tile
+    float dsc;
+    float xn[2];
+    float best[2][KCAP];        // ascending, +inf padded
+    float aux_n;
+    const WLane& L;
+    __device__ __forceinline__ KnnSampleEpilogue(const WLane& l) : L(l) {}
+    __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
+        if (L.tid < WTB) {
+            const int64_t j = qtile * WTB + L.tid;
+            aux_n = j < n ? qnorm[j] : INFINITY;
+        }
+    }
+    __device__ __forceinline__ void aux_commit(int t) {
+        if (L.tid < WTB) aux[(t & 1) * WTB + L.tid] = aux_n;
+    }
+    __device__ __forceinline__ void finish(int t, int64_t, f32x16 (&acc)[4][2]) {
+        const float* a = aux + (t & 1) * WTB + L.wm * 128 + L.h * 4;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x4 yn[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float tmin = INFINITY;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) tmin = fminf(tmin, fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]));
+                const float v = fmaxf(tmin, 0.f);
+                if (__any(v < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], v);
+            }
+        }
+    }
+};
+
+struct StridedTiles {
+    int64_t s0;
+    int stride;
+    __device__ __forceinline__ int64_t operator()(int t) const { return (s0 + t) * stride; }
+};
+
+constexpr size_t KNN_SAMPLE_LDS_BYTES = (WENGINE_LDS_WORDS + 2 * WTB) * sizeof(float);
+
+// partial[(chunk * N + i) * KCAP + s]: this chunk's smallest sampled values of row i (knn_merge_kernel combines the chunks)
+template <int KCAP>
+__global__ void __launch_bounds__(WTHREADS, 1)
+knn_wide_sample_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float* __restrict__ xnorm, int Dh, int stride,
+                       int nchunks, const unsigned* __restrict__ maxn, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const WLane L;
+    const int64_t T = (N + WTB - 1) / WTB;
+    const int64_t samples = (T + stride - 1) / stride;
+    const int64_t pb = blockIdx.x / nchunks;
+    const int chunk = blockIdx.x % nchunks;
+    const int64_t s0 = samples * chunk / nchunks, s1 = samples * (chunk + 1) / nchunks;
+    KnnSampleEpilogue<KCAP> epi(L);
+    epi.qnorm = xnorm;
+    epi.n = N;
+    epi.aux = lds + WENGINE_LDS_WORDS;
+    epi.dsc = half_unscale(maxn[2], maxn[2]);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int64_t i = pb * WTB + L.wn * 64 + nt * 32 + L.r;
+        epi.xn[nt] = i < N ? xnorm[i] : INFINITY;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = INFINITY;
+    }
+    if (s1 > s0) wide_pipeline(Xb, N, ldh, StridedTiles{s0, stride}, Xb, N, ldh, pb * WTB, (int)(s1 - s0), Dh, lds, L, epi);
+    __syncthreads();
+    float* mg = lds;                                   // [256][4][KCAP]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float* dst = mg + ((L.wn * 64 + nt * 32 + L.r) * 4 + (L.wm * 2 + L.h)) * KCAP;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
+    }
+    __syncthreads();
+    if (L.tid < WTB) {
+        const int64_t i = pb * WTB + L.tid;
+        if (i < N) {
+            const float* src = mg + L.tid * 4 * KCAP;
+            float m[KCAP];
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) m[s] = src[s];
+            for (int s = KCAP; s < 4 * KCAP; ++s) list_insert<KCAP>(m, src[s]);
+            float* out = partial + ((int64_t)chunk * N + i) * KCAP;
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) out[s] = m[s];
+        }
+    }
+}
+
+template <int KCAP>
+static int launch_knn_wide_sample_t(const float* Xb, int64_t N, int64_t ldh, const float* xnorm, int Dh, int stride, int nchunks,
+                                    const unsigned* maxn, float* partial, hipStream_t st) {
+    AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_wide_sample_kernel<KCAP>), (int)KNN_SAMPLE_LDS_BYTES));
+    const unsigned blocks = (unsigned)(ceil_div(N, WTB) * nchunks);
+    hipLaunchKernelGGL(knn_wide_sample_kernel<KCAP>, dim3(blocks), dim3(WTHREADS), KNN_SAMPLE_LDS_BYTES, st, Xb, N, ldh, xnorm, Dh, stride,
+                       nchunks, maxn, partial);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+int launch_knn_wide_sample(int kcap, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, int Dh, int stride, int nchunks,
+                           const unsigned* maxn, float* partial, hipStream_t st) {
+    if (kcap == 6) return launch_knn_wide_sample_t<6>(Xb, N, ldh, xnorm, Dh, stride, nchunks, maxn, partial, st);
+    AM_REQUIRE(kcap == 11, AM_ERR_UNSUPPORTED_K, "the wide sample pass holds lists of 6 or 11 entries (got %d)", kcap);
+    return launch_knn_wide_sample_t<11>(Xb, N, ldh, xnorm, Dh, stride, nchunks, maxn, partial, st);
+}
+
 template <int KCAP>
 static int launch_knn_wide_t(unsigned nwg, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, float* thr, int Dh,
                              int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
