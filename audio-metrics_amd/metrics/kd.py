@@ -55,32 +55,33 @@ def subset_indices_native(n_samples_1, n_samples_2, kid_subsets, kid_subset_size
     return idx1, idx2
 
 
-_NATIVE_DRAW_OK = None
+_NATIVE_DRAW_CHECKED = False
 
 
-def _native_draw_trusted():
-    """Once per process: the native draw must reproduce numpy on both of its branches (Floyd, tail shuffle) and across
-    consecutive draws - a numpy release that changes Generator.choice silently sends us back to the numpy calls."""
-    global _NATIVE_DRAW_OK
-    if _NATIVE_DRAW_OK is None:
-        try:
-            ok = True
-            for n1, n2, s, m, seed in ((20011, 777, 3, 37, 1234), (12000, 30000, 2, 700, 7)):
-                a = subset_indices_native(n1, n2, s, m, seed)
-                b = subset_indices_numpy(n1, n2, s, m, seed)
-                ok = ok and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-            _NATIVE_DRAW_OK = bool(ok)
-        except Exception:                         # missing symbol, unexpected generator state, ...
-            _NATIVE_DRAW_OK = False
-        if not _NATIVE_DRAW_OK:
-            logging.warning("am_kd_draw_indices does not reproduce numpy's Generator.choice here; using numpy")
-    return _NATIVE_DRAW_OK
+def _check_native_draw():
+    """Once per process: am_kd_draw_indices must reproduce numpy on both of its branches (Floyd, tail shuffle) and across
+    consecutive draws.  A numpy release that changes Generator.choice makes this a HARD error (no silent second path):
+    the KD values are defined by numpy's draw sequence (kd.py:176,185-186), and tests/test_kd_draw_cpu.py pins the numpy
+    versions the restatement has been checked against."""
+    global _NATIVE_DRAW_CHECKED
+    if _NATIVE_DRAW_CHECKED:
+        return
+    for n1, n2, s, m, seed in ((20011, 777, 3, 37, 1234), (12000, 30000, 2, 700, 7)):
+        a = subset_indices_native(n1, n2, s, m, seed)
+        b = subset_indices_numpy(n1, n2, s, m, seed)
+        if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])):
+            raise RuntimeError(f"am_kd_draw_indices does not reproduce numpy {np.__version__}'s Generator.choice; "
+                               "the kernel-distance subsets would differ from the reference's")
+    _NATIVE_DRAW_CHECKED = True
 
 
 def subset_indices(n_samples_1, n_samples_2, kid_subsets, kid_subset_size, rng_seed):
-    if _native_draw_trusted() and max(n_samples_1, n_samples_2) < 0xFFFFFFFF:
-        return subset_indices_native(n_samples_1, n_samples_2, kid_subsets, kid_subset_size, rng_seed)
-    return subset_indices_numpy(n_samples_1, n_samples_2, kid_subsets, kid_subset_size, rng_seed)
+    """The reference's index table (kd.py:176,185-186).  Row counts that do not fit 32 bits use numpy's own calls (the
+    native restatement covers numpy's 32-bit bounded-draw path only)."""
+    if max(n_samples_1, n_samples_2) >= 0xFFFFFFFF:
+        return subset_indices_numpy(n_samples_1, n_samples_2, kid_subsets, kid_subset_size, rng_seed)
+    _check_native_draw()
+    return subset_indices_native(n_samples_1, n_samples_2, kid_subsets, kid_subset_size, rng_seed)
 
 
 def _device_features(f):

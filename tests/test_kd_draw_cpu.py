@@ -24,8 +24,24 @@ def test_native_draw_equals_numpy(n1, n2, subsets, m, seed):
     assert np.array_equal(a1, b1) and np.array_equal(a2, b2)
 
 
+def test_numpy_version_is_one_the_restatement_was_checked_against():
+    """am_kd_draw_indices restates numpy's Generator.choice (Floyd / tail shuffle on Lemire-bounded 32-bit draws of PCG64) as
+    implemented in numpy 1.17 - 2.x.  A major version beyond that range must be re-checked (the equality tests above do it)
+    before this bound is raised; at run time a mismatch is a hard error, never a silent switch to numpy's own calls."""
+    major = int(np.__version__.split(".")[0])
+    assert 1 <= major <= 2, np.__version__
+
+
+def test_a_mismatch_is_a_hard_error(monkeypatch):
+    monkeypatch.setattr(kd, "_NATIVE_DRAW_CHECKED", False)
+    real = kd.subset_indices_numpy
+    monkeypatch.setattr(kd, "subset_indices_numpy", lambda *a: tuple(x + 1 for x in real(*a)))
+    with pytest.raises(RuntimeError, match="does not reproduce numpy"):
+        kd.subset_indices(5000, 5000, 2, 100, 1)
+    monkeypatch.setattr(kd, "_NATIVE_DRAW_CHECKED", False)
+
+
 def test_dispatch_uses_the_native_draw_and_matches_the_golden_first_draws():
-    assert kd._native_draw_trusted()
     i1, i2 = kd.subset_indices(100000, 100000, 2, 1000, 1234)
     # SURVEY 8(c), G3: first draws of default_rng(1234) at n = 100000
     assert i1[0, :8].tolist() == [57642, 95775, 28099, 5584, 88853, 71821, 71685, 94582]
