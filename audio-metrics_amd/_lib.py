@@ -46,6 +46,13 @@ SIGNATURES = {
     "am_prdc_counts_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P,
                                    _P, c_size_t, _P]),
     "am_prdc_reduce": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P]),
+    "am_prepared_half_ld": (c_int64, [c_int]),
+    "am_prepare_set_f32": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, _P]),
+    "am_knn_radii_prepared_f32": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int, _P, _P, c_size_t, _P]),
+    "am_knn_bounds_prepared_f32": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int, c_int64, c_int64, _P, _P, c_size_t, _P]),
+    "am_knn_sym_part_prepared_f32": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "am_prdc_counts_prepared_f32": (c_int, [_P, c_int64, c_int64, _P, _P, c_int64, c_int64, _P, c_int, _P, _P, _P, _P, _P, _P,
+                                            _P, c_size_t, _P]),
     "am_eigh_workspace_bytes": (c_size_t, [c_int]),
     "am_eigh_sym_f64": (c_int, [_P, c_int, _P, _P, c_int, _P, c_size_t, _P]),
     "am_project_f64": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, c_int, _P, _P]),
@@ -59,6 +66,11 @@ SIGNATURES = {
 
 class HipLibraryError(RuntimeError):
     pass
+
+
+class PreparedSetStruct(ctypes.Structure):
+    """am_prepared_set: a host struct of three device pointers."""
+    _fields_ = [("norms", c_void_p), ("stats", c_void_p), ("half", c_void_p)]
 
 
 _lib = None

@@ -1101,8 +1101,8 @@ static int run_knn(const float* X, int64_t N, int64_t ldx, const float* Y, int64
     return rc;
 }
 
-extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const float* Y, int64_t M, int64_t ldy,
-                                int D, int k, float* out_r, void* ws, size_t ws_bytes, am_stream_t stream) {
+static int knn_radii_impl(const float* X, int64_t N, int64_t ldx, const float* Y, int64_t M, int64_t ldy, int D, int k,
+                          float* out_r, void* ws, size_t ws_bytes, am_stream_t stream, const PreparedSet* prep) {
     int rc;
     if ((rc = check_matrix(X, N, ldx, D, "X")) != AM_OK) return rc;
     if ((rc = check_matrix(Y, M, ldy, D, "Y")) != AM_OK) return rc;
@@ -1127,15 +1127,15 @@ extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const fl
         fast = false;
     }
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
-    if ((rc = launch_norms(X, N, ldx, D, b.xn, st)) != AM_OK) return rc;
+    if ((rc = norms_of(prep, X, N, ldx, D, b.xn, st)) != AM_OK) return rc;
     if (!self && (rc = launch_norms(Y, M, ldy, D, b.yn, st)) != AM_OK) return rc;
     const int k1 = k + 1;
     if (fast) {                                    // f16 filter sweep + exact verification (pairwise_fast.h), same bits
         switch (p.kcap) {
-            case 6:  return run_knn_fast<6>(X, N, ldx, D, k1, p, b, fb, out_r, st);
-            case 11: return run_knn_fast<11>(X, N, ldx, D, k1, p, b, fb, out_r, st);
-            case 16: return run_knn_fast<16>(X, N, ldx, D, k1, p, b, fb, out_r, st);
-            default: return run_knn_fast<32>(X, N, ldx, D, k1, p, b, fb, out_r, st);
+            case 6:  return run_knn_fast<6>(X, N, ldx, D, k1, p, b, fb, out_r, st, 0, 1, nullptr, nullptr, prep);
+            case 11: return run_knn_fast<11>(X, N, ldx, D, k1, p, b, fb, out_r, st, 0, 1, nullptr, nullptr, prep);
+            case 16: return run_knn_fast<16>(X, N, ldx, D, k1, p, b, fb, out_r, st, 0, 1, nullptr, nullptr, prep);
+            default: return run_knn_fast<32>(X, N, ldx, D, k1, p, b, fb, out_r, st, 0, 1, nullptr, nullptr, prep);
         }
     }
     switch (p.kcap) {
@@ -1144,6 +1144,34 @@ extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const fl
         case 16: return run_knn<16>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
         default: return run_knn<32>(X, N, ldx, Y, M, ldy, D, k1, p, b, self, out_r, st);
     }
+}
+
+extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const float* Y, int64_t M, int64_t ldy,
+                                int D, int k, float* out_r, void* ws, size_t ws_bytes, am_stream_t stream) {
+    return knn_radii_impl(X, N, ldx, Y, M, ldy, D, k, out_r, ws, ws_bytes, stream, nullptr);
+}
+
+static bool prepared_ok(const am_prepared_set* p) { return p != nullptr && p->norms != nullptr && p->stats != nullptr && p->half != nullptr; }
+static PreparedSet prepared_of(const am_prepared_set* p) { return PreparedSet{p->norms, p->stats, p->half}; }
+
+extern "C" int64_t am_prepared_half_ld(int D) { return D < 1 ? 0 : half_ld(D); }
+
+extern "C" int am_prepare_set_f32(const float* X, int64_t N, int64_t ld, int D, float* norms, uint32_t* stats4, uint16_t* half,
+                                  am_stream_t stream) {
+    int rc;
+    if ((rc = check_matrix(X, N, ld, D, "X")) != AM_OK) return rc;
+    AM_REQUIRE(norms && stats4 && half, AM_ERR_BAD_ARG, "null output pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((rc = launch_norms(X, N, ld, D, norms, st)) != AM_OK) return rc;
+    AM_HIP_TRY(hipMemsetAsync(stats4, 0, 4 * sizeof(unsigned), st));
+    return launch_to_half(X, N, ld, D, norms, stats4, 0, half, st);
+}
+
+extern "C" int am_knn_radii_prepared_f32(const float* X, int64_t N, int64_t ldx, int D, const am_prepared_set* prepared, int k,
+                                         float* out_r, void* ws, size_t ws_bytes, am_stream_t stream) {
+    AM_REQUIRE(prepared_ok(prepared), AM_ERR_BAD_ARG, "prepared set has a null member");
+    const PreparedSet ps = prepared_of(prepared);
+    return knn_radii_impl(X, N, ldx, X, N, ldx, D, k, out_r, ws, ws_bytes, stream, &ps);
 }
 
 extern "C" int am_filter_stats_enable(int64_t* device_slots) {
@@ -1190,8 +1218,8 @@ extern "C" size_t am_knn_part_workspace_bytes(int64_t N, int D, int k) {
     return c.off;
 }
 
-extern "C" int am_knn_bounds_f32(const float* X, int64_t N, int64_t ld, int D, int k, int64_t row0, int64_t nrows,
-                                 float* out_bound_sq, void* ws, size_t ws_bytes, am_stream_t stream) {
+static int knn_bounds_impl(const float* X, int64_t N, int64_t ld, int D, int k, int64_t row0, int64_t nrows, float* out_bound_sq,
+                           void* ws, size_t ws_bytes, am_stream_t stream, const PreparedSet* prep) {
     int rc;
     if ((rc = check_matrix(X, N, ld, D, "X")) != AM_OK) return rc;
     AM_REQUIRE(out_bound_sq != nullptr, AM_ERR_BAD_ARG, "out_bound_sq is null");
@@ -1209,14 +1237,18 @@ extern "C" int am_knn_bounds_f32(const float* X, int64_t N, int64_t ld, int D, i
     uint16_t* xb = fast ? c.take<uint16_t>((size_t)N * half_ld(D)) : nullptr;
     unsigned* maxn = fast ? c.take<unsigned>(4) : nullptr;
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
-    if ((rc = launch_norms(X, N, ld, D, xn, st)) != AM_OK) return rc;
+    if ((rc = norms_of(prep, X, N, ld, D, xn, st)) != AM_OK) return rc;
     if (fast) {
         // f16 sample pass (pairwise_fast.h): kthA + E_i bounds the (k+1)-th smallest true value of the sample, hence of the row
         AM_HIP_TRY(hipMemsetAsync(maxn, 0, 4 * sizeof(unsigned), st));
-        if ((rc = launch_to_half(X, N, ld, D, xn, maxn, 0, xb, st)) != AM_OK) return rc;
-        AM_HIP_TRY(hipMemcpyAsync(maxn + 3, maxn + 2, sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+        if (prep != nullptr) {
+            hipLaunchKernelGGL(prepared_stats_kernel, dim3(1), dim3(64), 0, st, prep->stats, maxn, 0, 2, 3);
+        } else {
+            if ((rc = launch_to_half(X, N, ld, D, xn, maxn, 0, xb, st)) != AM_OK) return rc;
+            AM_HIP_TRY(hipMemcpyAsync(maxn + 3, maxn + 2, sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+        }
         const int64_t ldh = half_ld(D) / 2;
-        const float* Xb = reinterpret_cast<const float*>(xb);
+        const float* Xb = reinterpret_cast<const float*>(prep != nullptr ? prep->half : xb);
         auto go = [&](auto kcap_tag) -> int {
             constexpr int KC = decltype(kcap_tag)::value;
             int r2 = launch_knn_vt<KC, EV_FAST, false>(Xb + row0 * ldh, nrows, ldh, xn + row0, Xb, N, ldh, xn, (int)ldh, p.pre_chunks,
@@ -1253,8 +1285,20 @@ static int run_knn_part(const float* X, int64_t N, int64_t ld, int D, int k1, in
                                 b.wgq, p.qcap, b.wgq_count, b.ov_list, b.ov_count, nullptr, st, part, nparts, out_lists);
 }
 
-extern "C" int am_knn_sym_part_f32(const float* X, int64_t N, int64_t ld, int D, int k, int part, int nparts,
-                                   float* bounds_sq, float* out_lists, void* ws, size_t ws_bytes, am_stream_t stream) {
+extern "C" int am_knn_bounds_f32(const float* X, int64_t N, int64_t ld, int D, int k, int64_t row0, int64_t nrows,
+                                 float* out_bound_sq, void* ws, size_t ws_bytes, am_stream_t stream) {
+    return knn_bounds_impl(X, N, ld, D, k, row0, nrows, out_bound_sq, ws, ws_bytes, stream, nullptr);
+}
+extern "C" int am_knn_bounds_prepared_f32(const float* X, int64_t N, int64_t ld, int D, const am_prepared_set* prepared, int k,
+                                          int64_t row0, int64_t nrows, float* out_bound_sq, void* ws, size_t ws_bytes,
+                                          am_stream_t stream) {
+    AM_REQUIRE(prepared_ok(prepared), AM_ERR_BAD_ARG, "prepared set has a null member");
+    const PreparedSet ps = prepared_of(prepared);
+    return knn_bounds_impl(X, N, ld, D, k, row0, nrows, out_bound_sq, ws, ws_bytes, stream, &ps);
+}
+
+static int knn_sym_part_impl(const float* X, int64_t N, int64_t ld, int D, int k, int part, int nparts, float* bounds_sq,
+                             float* out_lists, void* ws, size_t ws_bytes, am_stream_t stream, const PreparedSet* prep) {
     int rc;
     if ((rc = check_matrix(X, N, ld, D, "X")) != AM_OK) return rc;
     AM_REQUIRE(bounds_sq && out_lists, AM_ERR_BAD_ARG, "null pointer");
@@ -1272,13 +1316,13 @@ extern "C" int am_knn_sym_part_f32(const float* X, int64_t N, int64_t ld, int D,
     KnnFastBuffers fb{};
     if (fast) fb = carve_knn_fast(c, N, D, p);
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
-    if ((rc = launch_norms(X, N, ld, D, b.xn, st)) != AM_OK) return rc;
+    if ((rc = norms_of(prep, X, N, ld, D, b.xn, st)) != AM_OK) return rc;
     if (fast) {                                    // f16 filter sweep of this rank's row blocks + exact verification
         switch (p.kcap) {
-            case 6:  return run_knn_fast<6>(X, N, ld, D, k + 1, p, b, fb, nullptr, st, part, nparts, bounds_sq, out_lists);
-            case 11: return run_knn_fast<11>(X, N, ld, D, k + 1, p, b, fb, nullptr, st, part, nparts, bounds_sq, out_lists);
-            case 16: return run_knn_fast<16>(X, N, ld, D, k + 1, p, b, fb, nullptr, st, part, nparts, bounds_sq, out_lists);
-            default: return run_knn_fast<32>(X, N, ld, D, k + 1, p, b, fb, nullptr, st, part, nparts, bounds_sq, out_lists);
+            case 6:  return run_knn_fast<6>(X, N, ld, D, k + 1, p, b, fb, nullptr, st, part, nparts, bounds_sq, out_lists, prep);
+            case 11: return run_knn_fast<11>(X, N, ld, D, k + 1, p, b, fb, nullptr, st, part, nparts, bounds_sq, out_lists, prep);
+            case 16: return run_knn_fast<16>(X, N, ld, D, k + 1, p, b, fb, nullptr, st, part, nparts, bounds_sq, out_lists, prep);
+            default: return run_knn_fast<32>(X, N, ld, D, k + 1, p, b, fb, nullptr, st, part, nparts, bounds_sq, out_lists, prep);
         }
     }
     switch (p.kcap) {
@@ -1287,6 +1331,18 @@ extern "C" int am_knn_sym_part_f32(const float* X, int64_t N, int64_t ld, int D,
         case 16: return run_knn_part<16>(X, N, ld, D, k + 1, part, nparts, bounds_sq, out_lists, p, b, st);
         default: return run_knn_part<32>(X, N, ld, D, k + 1, part, nparts, bounds_sq, out_lists, p, b, st);
     }
+}
+
+extern "C" int am_knn_sym_part_f32(const float* X, int64_t N, int64_t ld, int D, int k, int part, int nparts,
+                                   float* bounds_sq, float* out_lists, void* ws, size_t ws_bytes, am_stream_t stream) {
+    return knn_sym_part_impl(X, N, ld, D, k, part, nparts, bounds_sq, out_lists, ws, ws_bytes, stream, nullptr);
+}
+extern "C" int am_knn_sym_part_prepared_f32(const float* X, int64_t N, int64_t ld, int D, const am_prepared_set* prepared, int k,
+                                            int part, int nparts, float* bounds_sq, float* out_lists, void* ws, size_t ws_bytes,
+                                            am_stream_t stream) {
+    AM_REQUIRE(prepared_ok(prepared), AM_ERR_BAD_ARG, "prepared set has a null member");
+    const PreparedSet ps = prepared_of(prepared);
+    return knn_sym_part_impl(X, N, ld, D, k, part, nparts, bounds_sq, out_lists, ws, ws_bytes, stream, &ps);
 }
 
 template <int KCAP>
@@ -1333,10 +1389,10 @@ extern "C" size_t am_prdc_workspace_bytes(int64_t Nr, int64_t Nc, int D) {
     return c.off;
 }
 
-extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const float* C, int64_t Nc, int64_t ldc,
-                                  int D, const float* r_ref, const float* r_cand, int32_t* out_col_count,
-                                  uint8_t* out_row_any, uint8_t* out_row_cover, float* out_row_min, void* ws,
-                                  size_t ws_bytes, am_stream_t stream) {
+static int prdc_counts_impl(const float* R, int64_t Nr, int64_t ldr, const float* C, int64_t Nc, int64_t ldc, int D,
+                            const float* r_ref, const float* r_cand, int32_t* out_col_count, uint8_t* out_row_any,
+                            uint8_t* out_row_cover, float* out_row_min, void* ws, size_t ws_bytes, am_stream_t stream,
+                            const PreparedSet* prep_r, const PreparedSet* prep_c) {
     int rc;
     if ((rc = check_matrix(R, Nr, ldr, D, "R")) != AM_OK) return rc;
     if ((rc = check_matrix(C, Nc, ldc, D, "C")) != AM_OK) return rc;
@@ -1358,8 +1414,8 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
         fbuf = carve_cross_fast(c, Nr, Nc, D, fplan);
     }
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
-    if ((rc = launch_norms(R, Nr, ldr, D, rn, st)) != AM_OK) return rc;
-    if ((rc = launch_norms(C, Nc, ldc, D, cn, st)) != AM_OK) return rc;
+    if ((rc = norms_of(prep_r, R, Nr, ldr, D, rn, st)) != AM_OK) return rc;
+    if ((rc = norms_of(prep_c, C, Nc, ldc, D, cn, st)) != AM_OK) return rc;
     hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, r_ref, Nr, rt);
     hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)ceil_div(Nc, 256)), dim3(256), 0, st, r_cand, Nc, ct);
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, rmin, Nr, 0x7f800000u);
@@ -1373,7 +1429,7 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
         // The exact kernel is still launched behind it, but its workgroups return at once unless the filter path
         // raised its device-side fail flag (both queues overflowed).
         if ((rc = run_cross_fast(R, Nr, ldr, rn, rt, C, Nc, ldc, cn, ct, D, fplan, fbuf, out_col_count, rmin, rany, rcov,
-                                 out_row_min != nullptr, st)) != AM_OK)
+                                 out_row_min != nullptr, st, prep_r, prep_c)) != AM_OK)
             return rc;
         run_flag = fbuf.ov_count + 1;
     }
@@ -1402,6 +1458,24 @@ extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const
                        fast ? rcov : static_cast<unsigned*>(nullptr), run_flag, r_ref, Nr, out_row_min, out_row_any, out_row_cover);
     AM_LAUNCH_CHECK();
     return AM_OK;
+}
+
+extern "C" int am_prdc_counts_f32(const float* R, int64_t Nr, int64_t ldr, const float* C, int64_t Nc, int64_t ldc,
+                                  int D, const float* r_ref, const float* r_cand, int32_t* out_col_count,
+                                  uint8_t* out_row_any, uint8_t* out_row_cover, float* out_row_min, void* ws,
+                                  size_t ws_bytes, am_stream_t stream) {
+    return prdc_counts_impl(R, Nr, ldr, C, Nc, ldc, D, r_ref, r_cand, out_col_count, out_row_any, out_row_cover, out_row_min, ws,
+                            ws_bytes, stream, nullptr, nullptr);
+}
+extern "C" int am_prdc_counts_prepared_f32(const float* R, int64_t Nr, int64_t ldr, const am_prepared_set* prepared_r, const float* C,
+                                           int64_t Nc, int64_t ldc, const am_prepared_set* prepared_c, int D, const float* r_ref,
+                                           const float* r_cand, int32_t* out_col_count, uint8_t* out_row_any,
+                                           uint8_t* out_row_cover, float* out_row_min, void* ws, size_t ws_bytes,
+                                           am_stream_t stream) {
+    AM_REQUIRE(prepared_ok(prepared_r) && prepared_ok(prepared_c), AM_ERR_BAD_ARG, "prepared set has a null member");
+    const PreparedSet pr = prepared_of(prepared_r), pc = prepared_of(prepared_c);
+    return prdc_counts_impl(R, Nr, ldr, C, Nc, ldc, D, r_ref, r_cand, out_col_count, out_row_any, out_row_cover, out_row_min, ws,
+                            ws_bytes, stream, &pr, &pc);
 }
 
 extern "C" int am_prdc_reduce(const int32_t* col_count, int64_t Nc, const uint8_t* row_any, const uint8_t* row_cover,

@@ -145,6 +145,35 @@ static int launch_to_half(const float* X, int64_t N, int64_t ld, int D, const fl
     return AM_OK;
 }
 
+// ---- prepared sets (am_prepare_set_f32): what the entry points above derive from a set before their tile kernels run -
+// squared row norms, {largest squared norm, -, largest |element|, -} as bit patterns, and the scaled f16 copy - computed
+// once by the caller and handed to the *_prepared_* entry points (a row shard of a prepared set is the same three
+// pointers offset by the shard's first row; the statistics of the whole set remain valid bounds for the shard).
+struct PreparedSet {
+    const float* norms;
+    const unsigned* stats;        // [4] as written by launch_to_half(..., which = 0, ...)
+    const uint16_t* half;
+};
+
+// maxn[slot_norm] = stats[0], maxn[slot_abs] = stats[2]
+__global__ void prepared_stats_kernel(const unsigned* __restrict__ stats, unsigned* __restrict__ maxn, int slot_norm, int slot_abs,
+                                      int slot_abs2) {
+    if (threadIdx.x == 0) {
+        maxn[slot_norm] = stats[0];
+        maxn[slot_abs] = stats[2];
+        if (slot_abs2 >= 0) maxn[slot_abs2] = stats[2];
+    }
+}
+
+// the norms of a set: from the prepared set (a device-to-device copy of N floats) or computed
+static int norms_of(const PreparedSet* prep, const float* X, int64_t N, int64_t ld, int D, float* out, hipStream_t st) {
+    if (prep != nullptr) {
+        AM_HIP_TRY(hipMemcpyAsync(out, prep->norms, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return AM_OK;
+    }
+    return launch_norms(X, N, ld, D, out, st);
+}
+
 // The exact engine's value for one pair: f32 fmaf chain over the inner index in the order 8c+0, 8c+4, 8c+1, ...
 // (tile_engine.h, "K order"); xs = the row held in LDS, zero-padded to a multiple of 8.
 __device__ __forceinline__ float exact_pair_dot(const float* __restrict__ xs, const float* __restrict__ y, int D) {
@@ -637,18 +666,21 @@ static bool cross_fast_enabled(int64_t Nr, int64_t Nc, int D) {
 // to run after all.
 static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* rn, const float* rt, const float* C, int64_t Nc,
                           int64_t ldc, const float* cn, const float* ct, int D, const CrossFastPlan& p, const CrossFastBuffers& b,
-                          int32_t* col_count, unsigned* rmin, unsigned* rany, unsigned* rcov, bool want_min, hipStream_t st) {
+                          int32_t* col_count, unsigned* rmin, unsigned* rany, unsigned* rcov, bool want_min, hipStream_t st,
+                          const PreparedSet* prep_r = nullptr, const PreparedSet* prep_c = nullptr) {
     int rc;
     AM_HIP_TRY(hipMemsetAsync(b.maxn, 0, 4 * sizeof(unsigned), st));
     AM_HIP_TRY(hipMemsetAsync(b.ov_count, 0, 4 * sizeof(int), st));
-    if ((rc = launch_to_half(R, Nr, ldr, D, rn, b.maxn, 0, b.rb, st)) != AM_OK) return rc;
-    if ((rc = launch_to_half(C, Nc, ldc, D, cn, b.maxn, 1, b.cb, st)) != AM_OK) return rc;
+    if (prep_r != nullptr) hipLaunchKernelGGL(prepared_stats_kernel, dim3(1), dim3(64), 0, st, prep_r->stats, b.maxn, 0, 2, -1);
+    else if ((rc = launch_to_half(R, Nr, ldr, D, rn, b.maxn, 0, b.rb, st)) != AM_OK) return rc;
+    if (prep_c != nullptr) hipLaunchKernelGGL(prepared_stats_kernel, dim3(1), dim3(64), 0, st, prep_c->stats, b.maxn, 1, 3, -1);
+    else if ((rc = launch_to_half(C, Nc, ldc, D, cn, b.maxn, 1, b.cb, st)) != AM_OK) return rc;
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, b.rmin_approx, Nr, 0x7f800000u);
     AM_LAUNCH_CHECK();
     const int64_t ldb = half_ld(D);
     const int Dh = (int)(ldb / 2);
-    const float* Rb = reinterpret_cast<const float*>(b.rb);
-    const float* Cb = reinterpret_cast<const float*>(b.cb);
+    const float* Rb = reinterpret_cast<const float*>(prep_r != nullptr ? prep_r->half : b.rb);
+    const float* Cb = reinterpret_cast<const float*>(prep_c != nullptr ? prep_c->half : b.cb);
     int* fail = b.ov_count + 1;
     {
         const void* kernels[] = {reinterpret_cast<const void*>(&cross_fast_kernel<true, true>),
@@ -1069,16 +1101,20 @@ static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan&
 template <int KCAP>
 static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, const KnnPlan& p, const KnnBuffers& b,
                         const KnnFastBuffers& f, float* out_r, hipStream_t st, int part = 0, int nparts = 1,
-                        const float* bounds_in = nullptr, float* out_lists = nullptr) {
+                        const float* bounds_in = nullptr, float* out_lists = nullptr, const PreparedSet* prep = nullptr) {
     int rc;
     const int64_t ldh = half_ld(D) / 2;                              // row stride of the f16 copy in f32 words
     const int Dh = (int)ldh;
-    const float* Xb = reinterpret_cast<const float*>(f.xb);
+    const float* Xb = reinterpret_cast<const float*>(prep != nullptr ? prep->half : f.xb);
     unsigned* maxn = f.maxn;
     float* thr = b.thr;
     AM_HIP_TRY(hipMemsetAsync(maxn, 0, 4 * sizeof(unsigned), st));
-    if ((rc = launch_to_half(X, N, ld, D, b.xn, maxn, 0, f.xb, st)) != AM_OK) return rc;
-    AM_HIP_TRY(hipMemcpyAsync(maxn + 3, maxn + 2, sizeof(unsigned), hipMemcpyDeviceToDevice, st));   // both operands are X
+    if (prep != nullptr) {
+        hipLaunchKernelGGL(prepared_stats_kernel, dim3(1), dim3(64), 0, st, prep->stats, maxn, 0, 2, 3);
+    } else {
+        if ((rc = launch_to_half(X, N, ld, D, b.xn, maxn, 0, f.xb, st)) != AM_OK) return rc;
+        AM_HIP_TRY(hipMemcpyAsync(maxn + 3, maxn + 2, sizeof(unsigned), hipMemcpyDeviceToDevice, st));   // both operands are X
+    }
     // 1) filter bounds for every row from a sampled f16 pass of the general kernel (here a row's OWN entries are
     //    queued too, so - unlike in the exact symmetric kernel - every row needs a bound from the start)
     if (bounds_in != nullptr) {

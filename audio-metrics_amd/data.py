@@ -131,6 +131,18 @@ class AudioMetricsData:
             # reference quirk kept on purpose: a (1, 1) zero matrix, not (D, D) (data.py:56)
             self.cov = torch.zeros((1, 1), dtype=self.dtype, device=self.device)
 
+    def prepared(self):
+        """The PreparedSet of the stored rows (norms, maxima, scaled f16 copy), computed once per content: the k-NN sweep
+        and the membership counts of an evaluate() share it.  None without stored rows."""
+        rows = self.embeddings
+        if rows is None:
+            return None
+        rows = ops.as_matrix(rows)
+        cached = getattr(self, "_prepared", None)
+        if cached is None or not cached.matches(rows):
+            cached = self._prepared = ops.prepare(rows)
+        return cached
+
     def get_radii(self, k_neighbor):
         """k-NN radii of the stored rows, computed once per k and kept (like the reference's cache, data.py:60-66, an
         append does NOT invalidate it); None when no rows are stored."""
@@ -138,7 +150,7 @@ class AudioMetricsData:
         if slot not in self.radii:
             if self.embeddings is None:
                 return None
-            self.radii[slot] = ops.knn_radii(self.embeddings, int(k_neighbor))
+            self.radii[slot] = ops.knn_radii(self.embeddings, int(k_neighbor), prepared=self.prepared())
         return self.radii[slot]
 
     def _update_embeddings(self, embeddings):

@@ -186,7 +186,7 @@ def merged_stats(data, group=None, ops=None):
     return _Stats(n or None, mean, cov)
 
 
-def sharded_radii(local, full, counts, k, ops, world, rank, group):
+def sharded_radii(local, full, counts, k, ops, world, rank, group, prepared=None):
     """k-NN radii of a row-sharded set whose gathered copy `full` every rank holds.
     Returns (radii of this rank's rows, radii of all rows).  Wide, large sets take the partitioned symmetric
     kernel (half the tile pairs; rank r owns a contiguous range of the 128-row blocks; per-row lists all-gathered
@@ -195,13 +195,16 @@ def sharded_radii(local, full, counts, k, ops, world, rank, group):
     lo = sum(counts[:rank])
     hi = lo + counts[rank]
     if world > 1 and min(counts) > 0 and hasattr(ops, "knn_sym_part") and ops.knn_sym_eligible(n, d, k):
-        bounds = _all_gather_rows(ops.knn_bounds(full, k, lo, counts[rank]), counts, world, group)
-        lists = ops.knn_sym_part(full, k, rank, world, bounds)
+        extra = {} if prepared is None else {"prepared": prepared}
+        bounds = _all_gather_rows(ops.knn_bounds(full, k, lo, counts[rank], **extra), counts, world, group)
+        lists = ops.knn_sym_part(full, k, rank, world, bounds, **extra)
         all_lists = torch.empty((world, *lists.shape), dtype=lists.dtype, device=lists.device)
         _all_gather_into(all_lists.view(-1), lists.view(-1), world, group)
         r_full = ops.knn_lists_finish(all_lists, full, k)
         return r_full[lo:hi], r_full
-    if local.shape[0] > 0:
+    if world == 1 and prepared is not None:
+        r_local = ops.knn_radii(full, k, prepared=prepared)
+    elif local.shape[0] > 0:
         r_local = ops.knn_radii(local, k, columns=full)
     else:
         r_local = torch.empty(0, dtype=torch.float32, device=full.device)
@@ -250,11 +253,18 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
     prdc_pending = None
     if "prdc" in metrics:
         k = nearest_k
-        r_ref_l, _ = sharded_radii(ref_local, ref_full, ref_counts, k, ops, world, rank, group)
-        _, r_cand = sharded_radii(cand_local, cand_full, cand_counts, k, ops, world, rank, group)
+        # norms, maxima and scaled f16 copies of the two gathered sets: once per evaluate, shared by the k-NN entry points
+        # and the membership counts (the reference shard of this rank is a row range of the prepared reference set)
+        prepare = getattr(ops, "prepare", None)
+        prep_r = prepare(ref_full) if prepare is not None else None
+        prep_c = prepare(cand_full) if prepare is not None else None
+        r_ref_l, _ = sharded_radii(ref_local, ref_full, ref_counts, k, ops, world, rank, group, prep_r)
+        _, r_cand = sharded_radii(cand_local, cand_full, cand_counts, k, ops, world, rank, group, prep_c)
         packed = torch.zeros(n_cand + 2, dtype=torch.int32, device=dev)        # column counts | #rows any | #rows covered
         if ref_local.shape[0] > 0:
-            col, rany, rcov = ops.prdc_counts(ref_local, cand_full, r_ref_l, r_cand)
+            lo = sum(ref_counts[:rank])
+            extra = {} if prep_r is None else {"prepared_ref": prep_r.rows(lo, lo + ref_counts[rank]), "prepared_cand": prep_c}
+            col, rany, rcov = ops.prdc_counts(ref_local, cand_full, r_ref_l, r_cand, **extra)
             local_tot = ops.prdc_reduce(col, rany, rcov)
             packed[:n_cand] = col
             packed[n_cand:] = torch.stack((local_tot[1], local_tot[3])).to(torch.int32)

@@ -389,9 +389,41 @@ def kd_rbf(x, y, idx1, idx2, sigma):
 
 
 # ------------------------------------------------------------------ PRDC
-def knn_radii(x, k, columns=None):
+class PreparedSet:
+    """What every PRDC entry point derives from a set before its tile kernels run - squared row norms, their maximum, the
+    largest |element| and the scaled f16 copy (am_prepare_set_f32) - computed once and handed to the *_prepared_* entry
+    points.  `rows(lo, hi)` is the prepared form of a row shard (same statistics, offset pointers)."""
+
+    def __init__(self, norms, stats, half, ld_half, source):
+        self.norms, self.stats, self.half, self.ld_half = norms, stats, half, ld_half
+        self.source = source                      # (data_ptr, n, d) of the matrix it was prepared from
+
+    def matches(self, x):
+        return self.source == (x.data_ptr(), x.shape[0], x.shape[1])
+
+    def rows(self, lo, hi):
+        return PreparedSet(self.norms[lo:hi], self.stats, self.half[lo * self.ld_half:hi * self.ld_half], self.ld_half,
+                           (self.source[0] + 0, hi - lo, self.source[2]))
+
+    def struct(self):
+        return _lib.PreparedSetStruct(self.norms.data_ptr(), self.stats.data_ptr(), self.half.data_ptr())
+
+
+def prepare(x):
+    lib = _lib.load()
+    x = as_matrix(x)
+    n, d = x.shape
+    ldh = int(lib.am_prepared_half_ld(d))
+    norms = torch.empty(n, dtype=torch.float32, device=x.device)
+    stats = torch.empty(4, dtype=torch.int32, device=x.device)
+    half = torch.empty(n * ldh, dtype=torch.int16, device=x.device)
+    _call(lib, "am_prepare_set_f32", x.device, _ptr(x), n, _ld(x), d, _ptr(norms), _ptr(stats), _ptr(half))
+    return PreparedSet(norms, stats, half, ldh, (x.data_ptr(), n, d))
+
+
+def knn_radii(x, k, columns=None, prepared=None):
     """(k+1)-th smallest distance from each row of x to the rows of `columns`
-    (default: x itself) - prdc.py:4-14."""
+    (default: x itself) - prdc.py:4-14.  `prepared`: the PreparedSet of x (self-distance form only)."""
     lib = _lib.load()
     x = as_matrix(x)
     y = x if columns is None else as_matrix(columns, "columns")
@@ -401,6 +433,10 @@ def knn_radii(x, k, columns=None):
     out = torch.empty(n, dtype=torch.float32, device=x.device)
     nb = lib.am_knn_workspace_bytes(n, y.shape[0], d, int(k))
     ws = _workspace(nb, x.device)
+    if prepared is not None and columns is None:
+        ps = prepared.struct()
+        _call(lib, "am_knn_radii_prepared_f32", x.device, _ptr(x), n, _ld(x), d, ctypes.byref(ps), int(k), _ptr(out), _ptr(ws), nb)
+        return out
     _call(lib, "am_knn_radii_f32", x.device, _ptr(x), n, _ld(x), _ptr(y), y.shape[0], _ld(y), d, int(k), _ptr(out),
                                     _ptr(ws), nb)
     return out
@@ -421,7 +457,7 @@ def knn_sym_eligible(n, d, k):
     return bool(_lib.load().am_knn_sym_eligible(int(n), int(d), int(k)))
 
 
-def knn_bounds(x_full, k, row0, nrows):
+def knn_bounds(x_full, k, row0, nrows, prepared=None):
     """Squared upper bounds for rows [row0, row0+nrows) of the full set (column-sample pre-pass)."""
     lib = _lib.load()
     x = as_matrix(x_full)
@@ -429,11 +465,16 @@ def knn_bounds(x_full, k, row0, nrows):
     out = torch.empty(int(nrows), dtype=torch.float32, device=x.device)
     nb = lib.am_knn_part_workspace_bytes(n, d, int(k))
     ws = _workspace(nb, x.device)
+    if prepared is not None:
+        ps = prepared.struct()
+        _call(lib, "am_knn_bounds_prepared_f32", x.device, _ptr(x), n, _ld(x), d, ctypes.byref(ps), int(k), int(row0), int(nrows),
+              _ptr(out), _ptr(ws), nb)
+        return out
     _call(lib, "am_knn_bounds_f32", x.device, _ptr(x), n, _ld(x), d, int(k), int(row0), int(nrows), _ptr(out), _ptr(ws), nb)
     return out
 
 
-def knn_sym_part(x_full, k, part, nparts, bounds_sq):
+def knn_sym_part(x_full, k, part, nparts, bounds_sq, prepared=None):
     """This rank's share of the symmetric k-NN: [N, width] smallest entries per row (+inf padded)."""
     lib = _lib.load()
     x = as_matrix(x_full)
@@ -443,6 +484,11 @@ def knn_sym_part(x_full, k, part, nparts, bounds_sq):
     out = torch.empty((n, width), dtype=torch.float32, device=x.device)
     nb = lib.am_knn_part_workspace_bytes(n, d, int(k))
     ws = _workspace(nb, x.device)
+    if prepared is not None:
+        ps = prepared.struct()
+        _call(lib, "am_knn_sym_part_prepared_f32", x.device, _ptr(x), n, _ld(x), d, ctypes.byref(ps), int(k), int(part), int(nparts),
+              _ptr(bounds_sq), _ptr(out), _ptr(ws), nb)
+        return out
     _call(lib, "am_knn_sym_part_f32", x.device, _ptr(x), n, _ld(x), d, int(k), int(part), int(nparts), _ptr(bounds_sq), _ptr(out),
           _ptr(ws), nb)
     return out
@@ -462,7 +508,7 @@ def knn_lists_finish(lists, x_full, k):
     return out
 
 
-def prdc_counts(ref, cand, r_ref, r_cand, want_min=False):
+def prdc_counts(ref, cand, r_ref, r_cand, want_min=False, prepared_ref=None, prepared_cand=None):
     """col_count i32[Nc], row_any u8[Nr], row_cover u8[Nr] (prdc.py:34-48); with want_min=True also the row
     minimum f32[Nr] (not needed by any metric; costs extra)."""
     lib = _lib.load()
@@ -481,6 +527,12 @@ def prdc_counts(ref, cand, r_ref, r_cand, want_min=False):
     rmin = torch.empty(nr, dtype=torch.float32, device=ref.device) if want_min else None
     nb = lib.am_prdc_workspace_bytes(nr, nc, d)
     ws = _workspace(nb, ref.device)
+    if prepared_ref is not None and prepared_cand is not None:
+        pr, pc = prepared_ref.struct(), prepared_cand.struct()
+        _call(lib, "am_prdc_counts_prepared_f32", ref.device, _ptr(ref), nr, _ld(ref), ctypes.byref(pr), _ptr(cand), nc, _ld(cand),
+              ctypes.byref(pc), d, _ptr(r_ref), _ptr(r_cand), _ptr(col), _ptr(rany), _ptr(rcov),
+              _ptr(rmin) if want_min else ctypes.c_void_p(None), _ptr(ws), nb)
+        return (col, rany, rcov, rmin) if want_min else (col, rany, rcov)
     _call(lib, "am_prdc_counts_f32", ref.device, _ptr(ref), nr, _ld(ref), _ptr(cand), nc, _ld(cand), d, _ptr(r_ref),
                                       _ptr(r_cand), _ptr(col), _ptr(rany), _ptr(rcov),
                                       _ptr(rmin) if want_min else ctypes.c_void_p(None), _ptr(ws), nb)

@@ -13,7 +13,9 @@ def prdc(reference, candidate, nearest_k):
     """dict(precision, recall, density, coverage); arguments are
     ``AudioMetricsData``-like objects exposing ``embeddings`` and ``get_radii``."""
     radii = [side.get_radii(nearest_k) for side in (reference, candidate)]      # cached on the objects (data.py:60-66)
-    col_count, row_any, row_cover = ops.prdc_counts(reference.embeddings, candidate.embeddings, radii[0], radii[1])
+    prepared = [side.prepared() if hasattr(side, "prepared") else None for side in (reference, candidate)]
+    col_count, row_any, row_cover = ops.prdc_counts(reference.embeddings, candidate.embeddings, radii[0], radii[1],
+                                                    prepared_ref=prepared[0], prepared_cand=prepared[1])
     n_prec, n_rec, sum_cnt, n_cov = (int(v) for v in ops.prdc_reduce(col_count, row_any, row_cover).cpu().tolist())
     n_ref, n_cand = row_any.numel(), col_count.numel()
     # means of 0/1 (and integer) values in f64, as the reference's .double().mean()

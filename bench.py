@@ -252,8 +252,13 @@ def main():
         rows_local = hi - lo
         # Which form of the two PRDC tile kernels ran (am_knn_path / am_prdc_path: 0 exact general, 1 exact symmetric,
         # 2 / 3 f16 filter sweep (128 / 256-row engine) + exact f32 verification of the undecided pairs).
-        part_form = "am_knn_sym_part_f32" in kern
-        knn_entry = "am_knn_sym_part_f32" if part_form else "am_knn_radii_f32"
+        def entry(*names):                        # the plain or the prepared-set form of an entry point, whichever ran
+            return next((n for n in names if n in kern), names[0])
+
+        part_form = "am_knn_sym_part_f32" in kern or "am_knn_sym_part_prepared_f32" in kern
+        knn_entry = (entry("am_knn_sym_part_prepared_f32", "am_knn_sym_part_f32") if part_form
+                     else entry("am_knn_radii_prepared_f32", "am_knn_radii_f32"))
+        cross_entry = entry("am_prdc_counts_prepared_f32", "am_prdc_counts_f32")
         knn_path = ops.knn_path(n, n, d, k) if (world == 1 or part_form) else 0
         cross_path = ops.prdc_path(rows_local, n, d)
         knn_kernel = {0: "knn_partial_kernel", 1: "knn_sym_kernel", 2: "knn_fast_kernel", 3: "knn_wide_kernel"}[knn_path]
@@ -270,9 +275,9 @@ def main():
             return ms / calls, calls / args.steps
 
         knn_ms, knn_lps = per_launch("knn", knn_entry)
-        cross_ms, cross_lps = per_launch("cross", "am_prdc_counts_f32")
+        cross_ms, cross_lps = per_launch("cross", cross_entry)
         kcalls, kms = kern[knn_entry]
-        ccalls, cms = kern["am_prdc_counts_f32"]
+        ccalls, cms = kern[cross_entry]
         # ALGORITHMIC work of one launch (one dot product per (row, column) pair, no symmetry credit):
         # 2 * rows_of_this_rank * N * D flop.  The symmetric forms (paths 1, 2, 3) multiply a cyclic half of the tile
         # pairs - self distances are bitwise symmetric - so they EXECUTE about half of it.
@@ -299,7 +304,7 @@ def main():
                     "algorithmic_frac": algorithmic / peak}
 
         knn_roof = roof(knn_kernel, knn_path, knn_ms, knn_lps, knn_exec, knn_entry, kms / kcalls)
-        cross_roof = roof(cross_kernel, cross_path, cross_ms, cross_lps, 1.0, "am_prdc_counts_f32", cms / ccalls)
+        cross_roof = roof(cross_kernel, cross_path, cross_ms, cross_lps, 1.0, cross_entry, cms / ccalls)
         # dominant kernel = the one with the larger share of the step
         main, other = (knn_roof, cross_roof) if knn_ms * knn_lps >= cross_ms * cross_lps else (cross_roof, knn_roof)
         main["note"] = (

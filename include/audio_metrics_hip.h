@@ -186,6 +186,39 @@ int am_knn_lists_finish_f32(const float* lists, int nparts, const float* X, int6
                             float* out_r, void* ws, size_t ws_bytes, am_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Prepared sets.  Every PRDC entry point first derives from each set its squared row norms, their maximum, the largest
+ * |element| and - for the f16 filter forms - a scaled f16 copy (0.14 ms per 100k x 512 set and call).  An evaluate() calls
+ * three to four entry points per set (more per rank in the partitioned multi-GPU form): am_prepare_set_f32 computes the
+ * three pieces ONCE into caller-owned device buffers
+ *     norms  float[N]                     squared row norms (the summation order of the k-NN kernels)
+ *     stats4 uint32[4]                    { largest squared norm, 0, largest |element|, 0 } as f32 bit patterns
+ *     half   uint16[N * am_prepared_half_ld(D)]   f16 copy scaled by an exact power of two, rows zero-padded
+ * and the *_prepared_* variants below take them instead of recomputing (same results, bit for bit).  A ROW SHARD of a
+ * prepared set is the same struct with `norms` and `half` advanced to the shard's first row (the statistics of the
+ * whole set remain valid bounds for the shard).  The struct is a HOST struct of DEVICE pointers.
+ * ------------------------------------------------------------------------- */
+typedef struct am_prepared_set {
+    const float* norms;
+    const uint32_t* stats;
+    const uint16_t* half;
+} am_prepared_set;
+int64_t am_prepared_half_ld(int D);
+int am_prepare_set_f32(const float* X, int64_t N, int64_t ld, int D, float* norms, uint32_t* stats4, uint16_t* half,
+                       am_stream_t stream);
+int am_knn_radii_prepared_f32(const float* X, int64_t N, int64_t ldx, int D, const am_prepared_set* prepared, int k,
+                              float* out_r, void* ws, size_t ws_bytes, am_stream_t stream);          /* Y == X */
+int am_knn_bounds_prepared_f32(const float* X, int64_t N, int64_t ld, int D, const am_prepared_set* prepared, int k,
+                               int64_t row0, int64_t nrows, float* out_bound_sq, void* ws, size_t ws_bytes, am_stream_t stream);
+int am_knn_sym_part_prepared_f32(const float* X, int64_t N, int64_t ld, int D, const am_prepared_set* prepared, int k,
+                                 int part, int nparts, float* bounds_sq, float* out_lists, void* ws, size_t ws_bytes,
+                                 am_stream_t stream);
+int am_prdc_counts_prepared_f32(const float* R, int64_t Nr, int64_t ldr, const am_prepared_set* prepared_r,
+                                const float* C, int64_t Nc, int64_t ldc, const am_prepared_set* prepared_c, int D,
+                                const float* r_ref, const float* r_cand,
+                                int32_t* out_col_count, uint8_t* out_row_any, uint8_t* out_row_cover, float* out_row_min,
+                                void* ws, size_t ws_bytes, am_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * A10  hypersphere membership counts            reference: prdc.py:34-48
  *   With d(i,j) the distance between reference row i and candidate row j:
  *   out_col_count[j] = #{ i : d(i,j) < r_ref[i] }             (precision, density)

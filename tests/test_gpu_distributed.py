@@ -156,7 +156,7 @@ def test_bench_two_rank_launch(rows, dim):
     assert out2["roofline"]["frac"] > 0
     if rows >= 8192 and dim >= 128:
         tiles = [out2["roofline"], out2["other_tile_kernel"]]
-        assert any(t["entry_point"] == "am_knn_sym_part_f32" for t in tiles)
+        assert any(t["entry_point"] in ("am_knn_sym_part_f32", "am_knn_sym_part_prepared_f32") for t in tiles)
     for key in ("precision", "recall", "density", "coverage"):
         assert out2["result"][key] == out1["result"][key], key
     assert abs(out2["result"]["fad"] - out1["result"]["fad"]) <= 1e-5 * abs(out1["result"]["fad"])

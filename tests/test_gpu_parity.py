@@ -628,3 +628,28 @@ def test_own_eigensolver_and_projection(am):
     comp = rng.standard_normal((9, 70))
     got = ops.project(torch.as_tensor(x).to("cuda:0"), torch.as_tensor(mean).to("cuda:0"), torch.as_tensor(comp).to("cuda:0"))
     np.testing.assert_allclose(got.cpu().numpy(), (x.astype(np.float64) - mean) @ comp.T, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("rows,dim,k", [(2000, 64, 5), (9000, 128, 3), (33000, 128, 5)])
+def test_prepared_sets_change_no_bit(am, rows, dim, k):
+    """am_prepare_set_f32 + the *_prepared_* entry points (norms, maxima and scaled f16 copy computed once and shared)
+    against the plain entry points: exact general kernel, exact symmetric kernel and the f16 filter forms; also a row
+    shard of a prepared reference set, and the partitioned k-NN."""
+    ops = am.hip_ops
+    x, y = dev(gi.randn(201, rows, dim)), dev(gi.randn(202, rows - 37, dim, 1.05, 0.05))
+    px, py = ops.prepare(x), ops.prepare(y)
+    rx, ry = ops.knn_radii(x, k), ops.knn_radii(y, k)
+    assert torch.equal(rx, ops.knn_radii(x, k, prepared=px)) and torch.equal(ry, ops.knn_radii(y, k, prepared=py))
+    plain = ops.prdc_counts(x, y, rx, ry)
+    shared = ops.prdc_counts(x, y, rx, ry, prepared_ref=px, prepared_cand=py)
+    assert all(torch.equal(a, b) for a, b in zip(plain, shared))
+    lo, hi = rows // 3, rows // 3 + rows // 2                      # a row shard of the prepared reference set
+    part = ops.prdc_counts(x[lo:hi], y, rx[lo:hi], ry, prepared_ref=px.rows(lo, hi), prepared_cand=py)
+    want = ops.prdc_counts(x[lo:hi], y, rx[lo:hi], ry)
+    assert all(torch.equal(a, b) for a, b in zip(part, want))
+    if ops.knn_sym_eligible(rows, dim, k):
+        nparts = 3
+        bounds = torch.cat([ops.knn_bounds(x, k, rows * p // nparts, rows * (p + 1) // nparts - rows * p // nparts, prepared=px)
+                            for p in range(nparts)])
+        lists = torch.stack([ops.knn_sym_part(x, k, p, nparts, bounds, prepared=px) for p in range(nparts)])
+        assert torch.equal(ops.knn_lists_finish(lists, x, k), rx)
