@@ -37,7 +37,16 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
         const int cg = cg0 + my_cg;
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         if (cg < cgs && my_r < rpar) {
-            for (int64_t row = r0 + my_r; row < r1; row += rpar) {
+            // four loads in flight per thread (one at a time left the pass latency-bound at 3.5 TB/s); the sums keep their order
+            int64_t row = r0 + my_r;
+            for (; row + 3 * rpar < r1; row += 4 * rpar) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = load_k4(X + (row + u * rpar) * ld, cg * 4, D);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
+            }
+            for (; row < r1; row += rpar) {
                 const f32x4 v = load_k4(X + row * ld, cg * 4, D);
                 s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
             }
@@ -59,19 +68,33 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
     }
 }
 
-// out[d] = (sum_b partial[b][d]) * scale.  One workgroup per 64 columns; its 4 waves split the partial rows and
-// combine through LDS in a fixed order (deterministic).
+// out[d] = (sum_b partial[b][d]) * scale.  One workgroup per 16 columns; sixteen threads per column split the partial rows
+// (eight loads in flight each) and combine through LDS in a fixed order (deterministic).
+constexpr int CSR_COLS = 16, CSR_PARTS = 16;
 __global__ void __launch_bounds__(256) colsum_reduce_kernel(const double* __restrict__ partial, int nblocks, int D,
                                                             double scale, double* __restrict__ out) {
-    __shared__ double red[4][64];
-    const int d = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int part = threadIdx.x >> 6;
+    __shared__ double red[CSR_PARTS][CSR_COLS];
+    const int c = threadIdx.x % CSR_COLS, part = threadIdx.x / CSR_COLS;
+    const int d = blockIdx.x * CSR_COLS + c;
     double s = 0;
-    if (d < D)
-        for (int b = part; b < nblocks; b += 4) s += partial[(int64_t)b * D + d];
-    red[part][threadIdx.x & 63] = s;
+    if (d < D) {
+        int b = part;
+        for (; b + 7 * CSR_PARTS < nblocks; b += 8 * CSR_PARTS) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + u * CSR_PARTS) * D + d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nblocks; b += CSR_PARTS) s += partial[(int64_t)b * D + d];
+    }
+    red[part][c] = s;
     __syncthreads();
-    if (part == 0 && d < D) out[d] = (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) * scale;
+    if (part == 0 && d < D) {
+        double t = red[0][c];
+        for (int q = 1; q < CSR_PARTS; ++q) t += red[q][c];
+        out[d] = t * scale;
+    }
 }
 
 // ------------------------------------------------------------ centred scatter
@@ -84,6 +107,7 @@ __device__ __forceinline__ void tri_decode(int t, int T, int& tp, int& tq) {   /
 
 // (2 waves per SIMD: two workgroups per CU - 2 x 64 KB of LDS - cover each other's barriers, f64 flushes and load latency;
 // with one wave per SIMD every such stall idled the matrix pipe: 74 TF)
+template <bool FULLD>                               // D is a multiple of the tile width: no column masks
 __global__ void __launch_bounds__(ENGINE_THREADS, 2)
 scatter_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ld, int D, const double* __restrict__ mean,
                        int64_t rows_per_slab, int ntri, double* __restrict__ partial) {
@@ -103,34 +127,56 @@ scatter_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ld, int D
     const int colA = tp * TB + sc4, colB = tq * TB + sc4;
     f32x4 muA, muB;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        muA[e] = (colA + e < D) ? (float)mean[colA + e] : 0.f;
-        muB[e] = (colB + e < D) ? (float)mean[colB + e] : 0.f;
+    for (int e = 0; e < 4; ++e) {                   // (clamped index: eight independent loads instead of eight branches)
+        muA[e] = (float)mean[colA + e < D ? colA + e : D - 1];
+        muB[e] = (float)mean[colB + e < D ? colB + e : D - 1];
     }
+    // issue(): the eight loads of the next stage, nothing else - the values are first touched in commit(), after the
+    // stage's MFMAs.  (Centring them right behind each load, as the first version did, made the compiler wait for every
+    // load in turn: eight exposed memory round trips per stage, 47 % of the wave time parked, 43 % matrix-pipe busy.)
+    // Rows past the slab and column groups past the row are read from a valid address and masked in commit().
     f32x4 ra[4], rb[4];
-    auto centred = [&](const float* row, int col, const f32x4& mu) {
-        f32x4 v = load_k4(row, col, D);
-        if (row != nullptr) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (col + e < D) ? v[e] - mu[e] : 0.f;
-        }
-        return v;
-    };
+    // one buffer descriptor per stage (its 32 rows; rows past the slab's end read as zero in hardware): each thread keeps
+    // two constant 32-bit offsets and the row group travels in the scalar offset - no 64-bit address arithmetic per load,
+    // and no limit on the slab's size in bytes
+    const unsigned voA = (unsigned)((srow * ld + (colA + 3 < ld ? colA : 0)) * 4);
+    const unsigned voB = (unsigned)((srow * ld + (colB + 3 < ld ? colB : 0)) * 4);
+    const unsigned row_bytes = (unsigned)(ld * 4);
     auto issue = [&](int st) {
+        const int64_t row0 = r0 + (int64_t)st * SC_ROWS;
+        const int64_t left = r1 - row0;
+        const float* p0 = X + row0 * ld;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(p0) & 0xffffffffu));
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(p0) >> 32));
+        const unsigned bytes = __builtin_amdgcn_readfirstlane((unsigned)((left < SC_ROWS ? left : SC_ROWS) * ld * 4));
+        TileRsrc xr;
+        xr.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((static_cast<uintptr_t>(hi) << 32) | lo), 0, (int)bytes, 0x00020000);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int64_t row = r0 + (int64_t)st * SC_ROWS + q * 8 + srow;
-            const float* p = row < r1 ? X + row * ld : nullptr;
-            ra[q] = centred(p, colA, muA);
-            rb[q] = centred(p, colB, muB);
+            ra[q] = rsrc_load(xr, voA, (unsigned)(q * 8) * row_bytes);
+            rb[q] = rsrc_load(xr, voB, (unsigned)(q * 8) * row_bytes);
         }
+    };
+    const bool fullA = colA + 3 < D, fullB = colB + 3 < D;
+    auto centre = [&](const f32x4& v, const f32x4& mu, int col, bool full, bool row_ok) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (row_ok && (full || col + e < D)) ? v[e] - mu[e] : 0.f;
+        return o;
     };
     auto commit = [&](int st) {
         float* s = lds + (st & 1) * 2 * SC_SLAB + srow * SC_LD + sc4;
+        const bool whole = r0 + (int64_t)(st + 1) * SC_ROWS <= r1;       // wave-uniform: every row of the stage exists
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<f32x4*>(s + q * 8 * SC_LD) = ra[q];
-            *reinterpret_cast<f32x4*>(s + SC_SLAB + q * 8 * SC_LD) = rb[q];
+            if (FULLD && whole) {                                          // the common case: plain subtractions
+                *reinterpret_cast<f32x4*>(s + q * 8 * SC_LD) = ra[q] - muA;
+                *reinterpret_cast<f32x4*>(s + SC_SLAB + q * 8 * SC_LD) = rb[q] - muB;
+                continue;
+            }
+            const bool row_ok = whole || r0 + (int64_t)st * SC_ROWS + q * 8 + srow < r1;
+            *reinterpret_cast<f32x4*>(s + q * 8 * SC_LD) = centre(ra[q], muA, colA, fullA, row_ok);
+            *reinterpret_cast<f32x4*>(s + SC_SLAB + q * 8 * SC_LD) = centre(rb[q], muB, colB, fullB, row_ok);
         }
     };
 
@@ -190,21 +236,33 @@ scatter_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ld, int D
             }
 }
 
-// out[p][q] = scale * sum_slab partial[slab][tri(p,q)][...]; lower tiles mirror the upper ones
-__global__ void scatter_reduce_kernel(const double* __restrict__ partial, int nslabs, int ntri, int D, double scale,
-                                      double* __restrict__ out) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const int p = blockIdx.y;
-    if (q >= D) return;
+// out = scale * sum_slab partial[slab]: one thread per element of an upper-triangular tile; it writes out[p][q] and, for
+// an off-diagonal tile, the mirrored out[q][p] (each partial element is read once: the first version computed every
+// output element on its own and read the off-diagonal tiles twice)
+__global__ void __launch_bounds__(256) scatter_reduce_kernel(const double* __restrict__ partial, int nslabs, int ntri, int D, double scale,
+                                                             double* __restrict__ out) {
     const int T = (D + TB - 1) / TB;
-    int a = p, b = q;
-    if (a / TB > b / TB) { a = q; b = p; }
-    const int tp = a / TB, tq = b / TB;
-    const int tri = tp * T - tp * (tp - 1) / 2 + (tq - tp);
-    const double* src = partial + (int64_t)tri * (TB * TB) + (a % TB) * TB + (b % TB);
+    const int tri = blockIdx.y;
+    int tp, tq;
+    tri_decode(tri, T, tp, tq);
+    const int e = blockIdx.x * 256 + threadIdx.x;              // element of the 128 x 128 tile, row-major
+    const int a = tp * TB + e / TB, b = tq * TB + e % TB;
+    if (a >= D || b >= D) return;
+    const double* src = partial + (int64_t)tri * (TB * TB) + e;
+    const int64_t step = (int64_t)ntri * (TB * TB);
     double s = 0;
-    for (int sl = 0; sl < nslabs; ++sl) s += src[(int64_t)sl * ntri * (TB * TB)];
-    out[(int64_t)p * D + q] = s * scale;
+    int sl = 0;
+    for (; sl + 7 < nslabs; sl += 8) {             // eight loads in flight, summed in slab order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(sl + u) * step];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; sl < nslabs; ++sl) s += src[sl * step];
+    s *= scale;
+    out[(int64_t)a * D + b] = s;
+    if (tp != tq) out[(int64_t)b * D + a] = s;
 }
 
 __global__ void zero_f64_kernel(double* __restrict__ p, int64_t n) {
@@ -253,7 +311,8 @@ static StatsPlan plan_stats(int64_t N, int D) {
     p.cs_blocks = (int)ceil_div(N, p.cs_rows);
     const int T = (int)ceil_div(D, TB);
     p.ntri = T * (T + 1) / 2;
-    int64_t s = std::max<int64_t>(1024 / p.ntri, 1);         // just under two rounds of 256 CUs x 2 resident workgroups
+    int64_t s = std::max<int64_t>(512 / p.ntri, 1);          // one round of 256 CUs x 2 resident workgroups (the kernel is bound by the
+                                                             // matrix pipe; more slabs only add partial tiles to write and reduce)
     const int64_t max_s = ceil_div(N, SC_ROWS * SC_FLUSH);   // at least one full f32 chain per slab
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -282,7 +341,7 @@ static int run_colsum(const float* X, int64_t N, int D, int64_t ld, double scale
                       const StatsPlan& p, hipStream_t st) {
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.cs_blocks), dim3(256), 0, st, X, N, ld, D, p.cs_rows, partial);
     AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)ceil_div(D, 64)), dim3(256), 0, st, partial, p.cs_blocks, D,
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)ceil_div(D, CSR_COLS)), dim3(256), 0, st, partial, p.cs_blocks, D,
                        scale, out);
     AM_LAUNCH_CHECK();
     return AM_OK;
@@ -290,10 +349,14 @@ static int run_colsum(const float* X, int64_t N, int D, int64_t ld, double scale
 
 static int run_scatter(const float* X, int64_t N, int D, int64_t ld, const double* mean, double scale, double* out,
                        double* partial, const StatsPlan& p, hipStream_t st) {
-    hipLaunchKernelGGL(scatter_partial_kernel, dim3((unsigned)(p.ntri * p.nslabs)), dim3(ENGINE_THREADS), 0, st, X, N, ld,
-                       D, mean, p.slab_rows, p.ntri, partial);
+    if (D % TB == 0)
+        hipLaunchKernelGGL(scatter_partial_kernel<true>, dim3((unsigned)(p.ntri * p.nslabs)), dim3(ENGINE_THREADS), 0, st, X, N, ld,
+                           D, mean, p.slab_rows, p.ntri, partial);
+    else
+        hipLaunchKernelGGL(scatter_partial_kernel<false>, dim3((unsigned)(p.ntri * p.nslabs)), dim3(ENGINE_THREADS), 0, st, X, N, ld,
+                           D, mean, p.slab_rows, p.ntri, partial);
     AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scatter_reduce_kernel, dim3((unsigned)ceil_div(D, 128), (unsigned)D), dim3(128), 0, st, partial,
+    hipLaunchKernelGGL(scatter_reduce_kernel, dim3((unsigned)(TB * TB / 256), (unsigned)p.ntri), dim3(256), 0, st, partial,
                        p.nslabs, p.ntri, D, scale, out);
     AM_LAUNCH_CHECK();
     return AM_OK;

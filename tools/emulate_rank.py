@@ -18,7 +18,7 @@ gen = torch.Generator(device="cuda").manual_seed(0)
 ref = torch.randn(n, d, generator=gen, device="cuda")
 cand = torch.randn(n, d, generator=gen, device="cuda") * 1.05 + 0.05
 
-for world in (1, 2, 4, 8):
+for world in [int(w) for w in os.environ.get("AB_WORLDS", "1,2,4,8").split(",")]:
     rows = n // world
     pre = {}
     for name, x in (("ref", ref), ("cand", cand)):
@@ -28,23 +28,28 @@ for world in (1, 2, 4, 8):
     mean_r, mean_c = ref.double().mean(0), cand.double().mean(0)
 
     def step():
+        # the order of distributed.evaluate_sharded: statistics of the own rows, Frechet solve enqueued on a side stream,
+        # both sets prepared once (norms, maxima, f16 copy), radii, membership counts of the own reference rows, KD share
+        for x, mean in ((ref, mean_r), (cand, mean_c)):
+            ops.colsum(x[:rows])
+            ops.scatter(x[:rows], mean)
+        cov_r = ops.scatter(ref, mean_r) / (n - 1)              # (stand-ins for the all-reduced covariances; subtracted below)
+        cov_c = ops.scatter(cand, mean_c) / (n - 1)
+        job = ops.frechet_async(mean_c, cov_c, mean_r, cov_r)
+        prep = {"ref": ops.prepare(ref), "cand": ops.prepare(cand)}
         radii = {}
         for name, x in (("ref", ref), ("cand", cand)):
             bounds, lists, _ = pre[name]
-            ops.knn_bounds(x, k, 0, rows)                       # own rows (the all-gathered result is `bounds`)
-            mine = ops.knn_sym_part(x, k, 0, world, bounds)     # own share (the all-gathered result is `lists`)
+            ops.knn_bounds(x, k, 0, rows, prepared=prep[name])                      # own rows (the all-gathered result is `bounds`)
+            ops.knn_sym_part(x, k, 0, world, bounds, prepared=prep[name])           # own share (the all-gathered result is `lists`)
             radii[name] = ops.knn_lists_finish(lists, x, k)
-        col, rany, rcov = ops.prdc_counts(ref[:rows], cand, radii["ref"][:rows], radii["cand"])
+        col, rany, rcov = ops.prdc_counts(ref[:rows], cand, radii["ref"][:rows], radii["cand"],
+                                          prepared_ref=prep["ref"].rows(0, rows), prepared_cand=prep["cand"])
         tot = ops.prdc_reduce(col, rany, rcov)
         idx1, idx2 = subset_indices(n, n, 100, 1000, 1234)
         part = ops.kd_poly(cand, ref, ops.upload_host_array(idx1[0::world], dev), ops.upload_host_array(idx2[0::world], dev),
                            1.0 / d, 1, 3)
-        for x, mean in ((ref, mean_r), (cand, mean_c)):
-            ops.colsum(x[:rows])
-            ops.scatter(x[:rows], mean)
-        cov_r = ops.scatter(ref, mean_r) / (n - 1)
-        cov_c = ops.scatter(cand, mean_c) / (n - 1)
-        return ops.frechet(mean_c, cov_c, mean_r, cov_r)["fd"], part.cpu(), int(tot[0])
+        return job.result()["fd"], part.cpu(), int(tot[0])
 
     step()
     torch.cuda.synchronize()
