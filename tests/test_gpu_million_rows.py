@@ -1,0 +1,74 @@
+"""BASELINE configs[3] - 2 x 1M x 512 embeddings - on ONE GPU (upstream quotes it for 8; the row-sharded form of the same
+calls is covered at smaller sizes in test_gpu_distributed.py).  No oracle finishes at this size, so the checks are the
+size-independent properties of the domain (reference src/audio_metrics/metrics/prdc.py:4-50):
+
+  * role swap: precision(ref, cand) == recall(cand, ref) and vice versa, coverage / density keep their ranges - the two
+    evaluations run the membership filter with the operands exchanged (different tiles, queues and thresholds);
+  * the k-NN radii of 512 random rows against a brute-force torch evaluation of those rows (f32 noise of the matmul form);
+  * precision's definition on 256 random candidate rows, recounted with torch from the radii;
+  * no row and no call fell back to the exact kernels (the production path at this size is the f16 filter path 3)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+N, D, K = 1_000_000, 512, 5
+
+
+@pytest.fixture(scope="module")
+def am():
+    import audio_metrics_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    audio_metrics_amd._lib.load()
+    return audio_metrics_amd
+
+
+def test_million_row_sets_on_one_gpu(am):
+    ops = am.hip_ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    ref = torch.randn(N, D, generator=gen, device=dev)
+    cand = torch.randn(N, D, generator=gen, device=dev) * 1.03 + 0.02
+    assert ops.knn_path(N, N, D, K) == 3 and ops.prdc_path(N, N, D) == 3
+    a, b = am.AudioMetricsData(True), am.AudioMetricsData(True)
+    a.add(ref)
+    b.add(cand)
+    ops.filter_stats_enable("cuda:0", True)
+    fwd = am.prdc(a, b, K)                       # (reference set, candidate set)
+    bwd = am.prdc(b, a, K)
+    stats = ops.filter_stats_read("cuda:0")
+    ops.filter_stats_enable("cuda:0", False)
+    assert stats["prdc_fallback_calls"] == 0 and stats["knn_fallback_rows"] == 0, stats
+    assert fwd["precision"] == bwd["recall"] and fwd["recall"] == bwd["precision"], (fwd, bwd)
+    for res in (fwd, bwd):
+        assert 0.0 < res["precision"] < 1.0 and 0.0 < res["recall"] < 1.0 and 0.0 < res["coverage"] <= 1.0 and res["density"] > 0.0
+
+    # radii of random rows: (k+1)-th smallest squared distance to the own set (the row itself included), sqrt'ed as the
+    # reference does (prdc.py:12-13 on torch.cdist)
+    r_ref = a.get_radii(K)
+    rows = torch.randint(0, N, (512,), generator=torch.Generator().manual_seed(5)).to(dev)
+    q = ref[rows].double()
+    best = torch.full((rows.numel(), K + 1), float("inf"), dtype=torch.float64, device=dev)
+    for lo in range(0, N, 125_000):
+        blk = ref[lo:lo + 125_000].double()
+        d2 = (q * q).sum(1, keepdim=True) + (blk * blk).sum(1)[None, :] - 2.0 * q @ blk.T
+        best = torch.cat([best, d2], dim=1).topk(K + 1, dim=1, largest=False).values
+    want = best[:, K].clamp_min(0).sqrt().float()
+    torch.testing.assert_close(r_ref[rows], want, rtol=3e-5, atol=1e-6)
+
+    # precision, recounted for random candidate rows: row j counts when some reference row i has d(i, j) <= radius_i
+    cols = torch.randint(0, N, (256,), generator=torch.Generator().manual_seed(6)).to(dev)
+    c = cand[cols].double()
+    inside = torch.zeros(cols.numel(), dtype=torch.bool, device=dev)
+    margin = torch.full((cols.numel(),), float("inf"), dtype=torch.float64, device=dev)
+    for lo in range(0, N, 125_000):
+        blk = ref[lo:lo + 125_000].double()
+        d = ((blk * blk).sum(1, keepdim=True) + (c * c).sum(1)[None, :] - 2.0 * blk @ c.T).clamp_min(0).sqrt()
+        gap = d - r_ref[lo:lo + 125_000, None].double()
+        inside |= (gap <= 0).any(0)
+        margin = torch.minimum(margin, gap.abs().min(0).values)
+    col, _, _ = ops.prdc_counts(ref, cand, r_ref, b.get_radii(K), prepared_ref=a.prepared(), prepared_cand=b.prepared())
+    got = col[cols] > 0
+    decided = margin > 1e-4                      # rows whose nearest boundary is closer than f32 noise can fall either way
+    assert bool((got == inside)[decided].all()), int((got != inside)[decided].sum())
+    assert abs(float((col > 0).double().mean()) - fwd["precision"]) < 1e-12
