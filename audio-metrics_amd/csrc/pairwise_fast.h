@@ -32,8 +32,21 @@ namespace am {
 
 constexpr int EV_FAST = EV_DEFAULT | EV_F16 | EV_LDS;       // 128-row engine, f16 operands, LDS-direct fills (no ds_write: the store path bounds the staged form)
 constexpr int FAST_MAX_DIM = 4096;                                            // fast_c's derivation holds up to here
+// Mantissa bits dropped from the f16 copies (round to nearest even on the bit pattern, after the f32 -> f16 rounding):
+// the matrix cores draw less power on operands with fewer significant bits and the chip, which runs these kernels at its
+// power limit (1.8-1.9 GHz), clocks higher.  An element then carries |d| <= u = 2^-(11-n) + 2^-11 instead of 2^-11, and the
+// first term of fast_c becomes 2u + u^2.
+constexpr int FAST_DROP_BITS = 0;
+static inline int half_drop_bits() {
+    static const int n = std::min(std::max(env_int("AM_HALF_DROP_BITS", FAST_DROP_BITS), 0), 6);
+    return n;
+}
 static inline float fast_c(int D) {
-    return 0.0009765625f + 1.9073486328125e-06f + 2.98023223876953125e-08f * sqrtf((float)D) + (float)D * 4.76837158203125e-07f;
+    const int n = half_drop_bits();
+    const float rest = 1.9073486328125e-06f + 2.98023223876953125e-08f * sqrtf((float)D) + (float)D * 4.76837158203125e-07f;
+    if (n == 0) return 0.0009765625f + rest;
+    const float u = ldexpf(1.f, -(11 - n)) + ldexpf(1.f, -11);
+    return 2.f * u + u * u + rest;
 }
 constexpr int FAST_LDH_ALIGN = 64;                                            // f16 row stride: whole 128-B slabs
 
@@ -66,7 +79,7 @@ __global__ void __launch_bounds__(256) maxabs_bits_kernel(const float* __restric
 
 // ---- scaled f32 -> f16 copy (RNE), zero-padded to ldh columns; one thread per 8 elements
 __global__ void __launch_bounds__(256) to_half_kernel(const float* __restrict__ X, int64_t N, int64_t ld, int D, int64_t ldh,
-                                                      const unsigned* __restrict__ maxabs_bits, uint16_t* __restrict__ Xh) {
+                                                      const unsigned* __restrict__ maxabs_bits, uint16_t* __restrict__ Xh, int drop) {
     const int64_t per_row = ldh / 8;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = idx / per_row;
@@ -74,7 +87,14 @@ __global__ void __launch_bounds__(256) to_half_kernel(const float* __restrict__ 
     const float sc = __uint_as_float((unsigned)(127 + half_scale_exp(*maxabs_bits)) << 23);
     const int c = (int)(idx % per_row) * 8;
     const f32x4 a = load_k4(X + row * ld, c, D), b = load_k4(X + row * ld, c + 4, D);
-    auto h = [&](float v) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(v * sc)); };
+    auto h = [&](float v) {
+        unsigned b = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(v * sc));
+        if (drop > 0) {                               // RNE on the magnitude bits (a carry into the exponent is the right value)
+            const unsigned mag = b & 0x7fffu;
+            b = (b & 0x8000u) | ((mag + (1u << (drop - 1)) - 1u + ((mag >> drop) & 1u)) & ~((1u << drop) - 1u));
+        }
+        return b;
+    };
     uint4 o;
     o.x = h(a.x) | (h(a.y) << 16);
     o.y = h(a.z) | (h(a.w) << 16);
@@ -140,7 +160,7 @@ static int launch_to_half(const float* X, int64_t N, int64_t ld, int D, const fl
                        stats + 2 + which);
     const int64_t threads = N * (ldh / 8);
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, X, N, ld, D, ldh,
-                       stats + 2 + which, Xh);
+                       stats + 2 + which, Xh, half_drop_bits());
     AM_LAUNCH_CHECK();
     return AM_OK;
 }

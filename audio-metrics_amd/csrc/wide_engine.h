@@ -30,6 +30,7 @@
 
 namespace am {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int WTB = 256;                              // tile rows of either operand
 constexpr int WTHREADS = 512;
 constexpr int WROW = 32;                              // LDS row: 32 words = 128 B = 64 f16
@@ -173,7 +174,11 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
             const f16x8 a = __builtin_bit_cast(f16x8, f.q[m]);
 #pragma unroll
             for (int n = 0; n < 2; ++n)
+#ifdef AM_WIDE_BF16
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.q[m]), __builtin_bit_cast(bf16x8, f.p[n]), first ? zero : acc[m][n], 0, 0, 0);
+#else
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, f.p[n]), first ? zero : acc[m][n], 0, 0, 0);
+#endif
 #ifndef AM_WIDE_SPLIT_ROLES
             if (dma) piece(buf, j0 + m);
 #endif

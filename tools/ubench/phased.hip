@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <string.h>
 
 namespace am {
 struct KeepEpilogue {
@@ -47,8 +48,17 @@ int main() {
         for (auto& v : h) {
             s = s * 1664525u + 1013904223u;
             const float f = ((s >> 8) & 0xffff) / 65536.f - 0.5f;
+#ifdef AM_WIDE_BF16
+            unsigned u;
+            memcpy(&u, &f, 4);
+            v = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);          // bf16, round to nearest even
+#else
             _Float16 q = (_Float16)f;
             v = *reinterpret_cast<uint16_t*>(&q);
+#ifdef UB_DROP_BITS
+            v &= (uint16_t)~((1u << UB_DROP_BITS) - 1u);
+#endif
+#endif
         }
         float *x, *out;
         (void)hipMalloc(&x, h.size() * 2);
