@@ -11,7 +11,10 @@ LIB_PATH = os.path.join(LIB_DIR, "libaudio_metrics_hip.so")
 # A/B build of the same sources with -DAM_DEV_KNOBS: environment-variable knobs, older engine schedules and debug dumps.
 # Never loaded by the product path; tools/ and the tests that force fallback paths ask for it with AM_HIP_LIBRARY=dev.
 DEV_LIB_PATH = os.path.join(LIB_DIR, "libaudio_metrics_hip_dev.so")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
+# -pragma-unroll-threshold: the epilogues of the 256 x 256 filter kernels are `#pragma unroll` loops over 128 accumulator
+# registers; past the default budget (16384) the compiler leaves a loop rolled, indexes the accumulator array dynamically and
+# puts it in scratch (576 bytes per lane, 10x slower kernels)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-mllvm", "-pragma-unroll-threshold=65536"]
 
 
 def _hipcc():

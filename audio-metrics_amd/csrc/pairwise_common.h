@@ -218,23 +218,42 @@ struct KnnFastEpilogue {
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                float tmin = INFINITY, marg = INFINITY;
+                // Fast path: per group of four accumulator registers (four columns) the smallest value and the smallest margin
+                // against the columns' bounds.  The row's own norm is added to the minima, not to every element (the extra
+                // rounding is one of those fast_c's 2^-19 term pays for).
+                float tmin4[4], marg4[4];
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
-                    tmin = fminf(tmin, u);
-                    marg = fminf(marg, u - tq[reg >> 2][reg & 3]);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float tm = INFINITY, mg = INFINITY;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = fmaf(dsc, acc[mt][nt][g4 * 4 + e], yn[g4][e]);
+                        tm = fminf(tm, t);
+                        mg = fminf(mg, t - tq[g4][e]);
+                    }
+                    tmin4[g4] = tm + xn[nt];
+                    marg4[g4] = mg + xn[nt];
                 }
+                const float tmin = fminf(fminf(tmin4[0], tmin4[1]), fminf(tmin4[2], tmin4[3]));
                 // the own-row bound is frozen for the 16 elements of this accumulator tile (a looser filter is always
                 // safe); the list - and with it the bound of the next tile - is updated behind the stores
                 const float pl = fminf(flt[nt], best[nt][KCAP - 1] + fmaf(e2c, xn[nt], e2n));
-                if (__any(tmin <= pl || (mirror && marg <= 0.f))) {
+                bool hit[4];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) hit[g4] = __any(tmin4[g4] <= pl || (mirror && marg4[g4] <= 0.f));     // wave-uniform
+                if (hit[0] || hit[1] || hit[2] || hit[3]) {
+                    // the element-wise tests only for the register groups that have a candidate at all
                     unsigned own_bits = 0u, mir_bits = 0u;
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
-                        own_bits |= (u <= pl) ? (1u << reg) : 0u;
-                        mir_bits |= (mirror && u <= tq[reg >> 2][reg & 3]) ? (1u << reg) : 0u;
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        if (!hit[g4]) continue;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int reg = g4 * 4 + e;
+                            const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[g4][e]);
+                            own_bits |= (u <= pl) ? (1u << reg) : 0u;
+                            mir_bits |= (mirror && u <= tq[g4][e]) ? (1u << reg) : 0u;
+                        }
                     }
                     const unsigned any_bits = own_bits | mir_bits;
                     // The lane-local list only steers the filter (its (k+1)-th smallest bounds the row's final value from

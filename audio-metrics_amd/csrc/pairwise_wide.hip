@@ -116,7 +116,9 @@ struct CrossWideEpilogue {
         }
     }
 #endif
-    template <bool WANT_MIN>
+    // NEED_ANY = false: every row of this block already has its "any" witness - the column-threshold test (one subtraction
+    // and half a min3 per accumulator element, and the threshold loads) is not compiled in
+    template <bool WANT_MIN, bool NEED_ANY>
     __device__ __forceinline__ void finish_impl(int t, int64_t qtile, f32x16 (&acc)[4][2]) {
         const float* a = aux + (t & 1) * 3 * WTB + L.wm * 128 + L.h * 4;
         const int64_t jbase = qtile * WTB + L.wm * 128 + L.h * 4;
@@ -129,39 +131,70 @@ struct CrossWideEpilogue {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
-                th[g4] = *reinterpret_cast<const f32x4*>(a + WTB + mt * 32 + g4 * 8);
+                if constexpr (NEED_ANY) th[g4] = *reinterpret_cast<const f32x4*>(a + WTB + mt * 32 + g4 * 8);
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                float tmin = INFINITY, marg = INFINITY;
+                // Fast path: per group of four accumulator registers (four columns), the smallest value and the smallest margin
+                // against the column thresholds.  The row's own norm is added to the minima, not to every element (the extra
+                // rounding is one of those fast_c's 2^-19 term pays for).  (Comparing a group's minimum with the LARGEST of its
+                // four column thresholds - one subtraction per group - was measured: the thresholds of neighbouring columns
+                // differ by more than the distance distribution allows this far out in its tail, four in five groups pass
+                // such a gate, 10.6 -> 13.0 ms.)
+                float tmin4[4], marg4[4];
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
-                    tmin = fminf(tmin, u);
-                    marg = fminf(marg, u - th[reg >> 2][reg & 3]);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float tm = INFINITY, mg = INFINITY;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = fmaf(dsc, acc[mt][nt][g4 * 4 + e], yn[g4][e]);
+                        tm = fminf(tm, t);
+                        if constexpr (NEED_ANY) mg = fminf(mg, t - th[g4][e]);
+                    }
+                    tmin4[g4] = tm + xn[nt];
+                    if constexpr (NEED_ANY) marg4[g4] = mg + xn[nt];
                 }
-                if constexpr (WANT_MIN) m[nt] = fminf(m[nt], fmaxf(tmin, 0.f));
+                if constexpr (WANT_MIN) m[nt] = fminf(m[nt], fmaxf(fminf(fminf(tmin4[0], tmin4[1]), fminf(tmin4[2], tmin4[3])), 0.f));
                 const float prow_thr = WANT_MIN ? fmaxf(thi[nt], m[nt] + e2[nt]) : thi[nt];
-                if (__any(rowok[nt] && (tmin <= prow_thr || (!anyf[nt] && marg <= 0.f)))) {
-                    const float* alo = a + 2 * WTB + mt * 32;
+                // Detail path, per register group and direction, behind wave-uniform gates.  The row direction (column counts,
+                // coverage, row minimum) has a candidate in 0.2 % of the 32 x 32 tiles of the bench problem; the "any" direction
+                // of the rows that still lack a witness in 16 % (candidate radii are wider than a reference row's own test) -
+                // those groups run without ballots and counts.  (One loop with switches, not two loops: a second unrolled copy
+                // pushes the epilogue over the compiler's unroll budget and the accumulator array into scratch.)
+                const float* alo = a + 2 * WTB + mt * 32;
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
-                        const int64_t j = jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3);
-                        const bool sure = rowok[nt] && u < tlo[nt];
-                        const unsigned long long mask = __ballot(sure);
-                        if (mask != 0ull && L.lane == 0) {               // lanes 0-31: column j, lanes 32-63: column j + 4
-                            const int lo = __popcll(mask & 0xffffffffull);
-                            const int hi = __popcll(mask >> 32);
-                            if (lo) atomicAdd(col_count + j - L.h * 4, lo);
-                            if (hi) atomicAdd(col_count + j - L.h * 4 + 4, hi);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const bool row_hit = __any(rowok[nt] && tmin4[g4] <= prow_thr);
+                    bool any_hit = false;
+                    if constexpr (NEED_ANY) any_hit = __any(rowok[nt] && !anyf[nt] && marg4[g4] <= 0.f);
+#ifdef AM_DEV_KNOBS
+                    if (g_wide_dbg & 8) any_hit = false;               // timing experiment: the gate's cost without its loop
+#endif
+                    if (!(row_hit || any_hit)) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int reg = g4 * 4 + e;
+                        const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[g4][e]);
+                        const int64_t j = jbase + mt * 32 + g4 * 8 + e;
+                        bool sure = false, want = false;
+                        if (row_hit) {
+                            sure = rowok[nt] && u < tlo[nt];
+                            const unsigned long long mask = __ballot(sure);
+                            if (mask != 0ull && L.lane == 0) {               // lanes 0-31: column j, lanes 32-63: column j + 4
+                                const int lo = __popcll(mask & 0xffffffffull);
+                                const int hi = __popcll(mask >> 32);
+                                if (lo) atomicAdd(col_count + j - L.h * 4, lo);
+                                if (hi) atomicAdd(col_count + j - L.h * 4 + 4, hi);
+                            }
+                            covf[nt] = covf[nt] || sure;
+                            want = rowok[nt] && !sure && u <= thi[nt];
+                            if constexpr (WANT_MIN) want = want || (rowok[nt] && u <= m[nt] + e2[nt]);
                         }
-                        covf[nt] = covf[nt] || sure;
-                        bool want = rowok[nt] && !sure && u <= thi[nt];
-                        if constexpr (WANT_MIN) want = want || (rowok[nt] && u <= m[nt] + e2[nt]);
-                        if (rowok[nt] && !anyf[nt] && u <= th[reg >> 2][reg & 3]) {
-                            if (u < alo[(reg >> 2) * 8 + (reg & 3)]) anyf[nt] = true;       // certain witness
-                            else want = true;                                             // ambiguous "any"
+                        if constexpr (NEED_ANY) {
+                            if (rowok[nt] && !anyf[nt] && u <= th[g4][e]) {
+                                if (u < alo[g4 * 8 + e]) anyf[nt] = true;       // certain witness
+                                else want = true;                               // ambiguous "any"
+                            }
                         }
                         if (want) push(prow[nt], (unsigned)j | (sure ? FAST_COUNTED : 0u));
                     }
@@ -171,7 +204,7 @@ struct CrossWideEpilogue {
     }
 };
 
-template <bool WANT_MIN>
+template <bool WANT_MIN, bool NEED_ANY>
 struct CrossWideShim {
     CrossWideEpilogue& e;
     __device__ __forceinline__ void aux_issue(int t, int64_t q) { e.aux_issue(t, q); }
@@ -180,7 +213,7 @@ struct CrossWideShim {
     __device__ __forceinline__ void aux_dma(int t, int64_t q, int wave) { e.aux_dma(t, q, wave); }
     __device__ __forceinline__ void aux_cook(int t, int64_t q) { e.aux_cook(t, q); }
 #endif
-    __device__ __forceinline__ void finish(int t, int64_t q, f32x16 (&acc)[4][2]) { e.template finish_impl<WANT_MIN>(t, q, acc); }
+    __device__ __forceinline__ void finish(int t, int64_t q, f32x16 (&acc)[4][2]) { e.template finish_impl<WANT_MIN, NEED_ANY>(t, q, acc); }
 };
 
 struct WideTiles {
@@ -272,8 +305,16 @@ cross_wide_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const f
         epi.anyf[nt] = ok ? (row_any[i] != 0u) : true;
         epi.covf[nt] = false;
     }
-    CrossWideShim<WANT_MIN> shim{epi};
-    wide_pipeline(Cb, Nc, ldc, WideTiles{w.qtile0}, Rb, Nr, ldr, prow0, w.ntiles, Dh, lds, L, shim);
+#ifdef AM_DEV_KNOBS
+    if (g_wide_dbg & 4) {                                      // timing experiment: no block needs the "any" test
+        CrossWideShim<WANT_MIN, false> quick{epi};
+        wide_pipeline(Cb, Nc, ldc, WideTiles{w.qtile0}, Rb, Nr, ldr, prow0, w.ntiles, Dh, lds, L, quick);
+    } else
+#endif
+    {
+        CrossWideShim<WANT_MIN, true> shim{epi};
+        wide_pipeline(Cb, Nc, ldc, WideTiles{w.qtile0}, Rb, Nr, ldr, prow0, w.ntiles, Dh, lds, L, shim);
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const float mn = fminf(epi.m[nt], __shfl_xor(epi.m[nt], 32));

@@ -19,9 +19,12 @@ CSRC = os.path.join(ROOT, "audio-metrics_amd", "csrc")
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
 def test_wide_kernels_stay_within_the_register_file():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-c", "pairwise_wide.hip",
-                        "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], cwd=CSRC, capture_output=True, text=True,
-                       timeout=900)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("am_build", os.path.join(ROOT, "audio-metrics_amd", "_build.py"))
+    build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(build)                                         # the flags the shipped library is built with
+    r = subprocess.run([hipcc, *build.HIPCC_FLAGS, "-c", "pairwise_wide.hip", "-o", os.devnull,
+                        "-Rpass-analysis=kernel-resource-usage"], cwd=CSRC, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     usage = {}
     name = None
