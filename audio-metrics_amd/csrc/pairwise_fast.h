@@ -719,8 +719,9 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
                            b.ovq, b.ov_count, p.ovcap, fail, dbg, fast_c(D), grp_rows);
     };
     const unsigned pre_grid = (unsigned)(ceil_div(Nr, TB) * p.pre_chunks);
+    static const int pre_any = env_int("AM_FAST_PRE_ANY", 1);
     if (want_min) launch_filter(&cross_fast_kernel<true, true>, pre_grid, p.pre_chunks, p.qstride, 0);
-    else launch_filter(&cross_fast_kernel<true, false>, pre_grid, p.pre_chunks, p.qstride, 0);
+    else if (pre_any) launch_filter(&cross_fast_kernel<true, false>, pre_grid, p.pre_chunks, p.qstride, 0);
     AM_LAUNCH_CHECK();
     unsigned* rmin_or_null = want_min ? rmin : nullptr;
     if (p.wide) {
