@@ -271,15 +271,20 @@ struct KnnFastEpilogue {
                     int base = 0;
                     if (count > 0) base = atomicAdd(qn, count);
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const unsigned bit = 1u << reg;
-                        if (__any((any_bits & bit) != 0u)) {                              // wave-uniform
-                            const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]);
-                            const unsigned j = jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3);
-                            const bool own = (own_bits & bit) != 0u, mir = (mir_bits & bit) != 0u;
-                            // filed under its own row, or (mirrored only) under row j
-                            if (own || mir)
-                                store_entry(base + __popc(any_bits & (bit - 1u)), own ? prow[nt] : j, own ? j : prow[nt], own && mir, u);
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        if (!hit[g4]) continue;                                           // (no bits outside the groups that were looked at)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int reg = g4 * 4 + e;
+                            const unsigned bit = 1u << reg;
+                            if (__any((any_bits & bit) != 0u)) {                          // wave-uniform
+                                const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[g4][e]);
+                                const unsigned j = jbase + mt * 32 + g4 * 8 + e;
+                                const bool own = (own_bits & bit) != 0u, mir = (mir_bits & bit) != 0u;
+                                // filed under its own row, or (mirrored only) under row j
+                                if (own || mir)
+                                    store_entry(base + __popc(any_bits & (bit - 1u)), own ? prow[nt] : j, own ? j : prow[nt], own && mir, u);
+                            }
                         }
                     }
                 }

@@ -1,3 +1,2 @@
-for pre in 1 0 1 0; do AB_REPS=5 AM_FAST_PRE_ANY=$pre AM_HIP_LIBRARY=dev timeout 300 python tools/ab_cross.py 2>&1 | tail -1 | sed "s/^/pre $pre: /" | cut -c1-220; done
-for pre in 1 0; do AB_DATA=unit AB_K=10 AB_REPS=3 AM_FAST_PRE_ANY=$pre AM_HIP_LIBRARY=dev timeout 300 python tools/ab_cross.py 2>&1 | tail -1 | sed "s/^/unit pre $pre: /" | cut -c1-220; done
-for pre in 1 0; do AB_REPS=3 AB_TAG="pre$pre" AM_FAST_PRE_ANY=$pre AM_HIP_LIBRARY=dev timeout 300 python tools/wide_bench.py 2>&1 | tail -1 | cut -c1-230; done
+for lib in libprev_dev.so dev libprev_dev.so dev; do AB_REPS=4 AB_TAG="$lib" AM_HIP_LIBRARY=$lib timeout 300 python tools/wide_bench.py 2>&1 | tail -1 | cut -c1-120; done
+for lib in libprev_dev.so dev; do AB_K=10 AB_REPS=3 AB_TAG="$lib" AM_HIP_LIBRARY=$lib timeout 300 python tools/wide_bench.py 2>&1 | tail -1 | cut -c1-230; done
