@@ -154,10 +154,18 @@ kd_tile_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict
             const unsigned bytes = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)n_rows * (uint64_t)g.ld * 4u));
             a.rs.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((static_cast<uintptr_t>(hi) << 32) | lo), 0,
                                                           (int)bytes, 0x00020000);
+            // four independent index loads (a conditional load used at once made the compiler wait for each in turn: eight
+            // exposed memory round trips at the top of every workgroup, whose whole life is one 128 x 128 tile)
+            int64_t ix[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int p = g.tile * TB + q * 32 + srow;
-                a.vo[q] = p < g.m ? (unsigned)((g.idx[p] * g.ld + scol) * 4) : 0xffffffffu;   // padded rows read as 0
+                ix[q] = g.idx[p < g.m ? p : g.m - 1];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = g.tile * TB + q * 32 + srow;
+                a.vo[q] = p < g.m ? (unsigned)((ix[q] * g.ld + scol) * 4) : 0xffffffffu;      // padded rows read as 0
             }
             return a;
         };

@@ -901,28 +901,33 @@ __device__ __forceinline__ void knn_file_approx(float* __restrict__ fval, unsign
 __global__ void __launch_bounds__(256) knn_fast_scatter_kernel(const uint2* __restrict__ wgq, const float* __restrict__ wgv,
                                                                int qcap, const int* __restrict__ wgq_count,
                                                                float* __restrict__ fval, unsigned* __restrict__ fidx,
-                                                               int* __restrict__ cnt, int cap) {
+                                                               int* __restrict__ cnt, int cap, const float* __restrict__ thr) {
+    // thr[i] (the bound the sweep left behind: (k+1)-th smallest approximate value seen + 2E) admits every pair that can
+    // be among row i's k+1 smallest; most entries were queued under the much looser bounds of the first windows and are
+    // dropped here instead of being filed and pruned later
     const int n = wgq_count[blockIdx.x];
     const uint2* q = wgq + (int64_t)blockIdx.x * qcap;
     const float* v = wgv + (int64_t)blockIdx.x * qcap;
     for (int e = threadIdx.x; e < n; e += 256) {
         const uint2 p = q[e];
         const unsigned a = p.x & ~FAST_BOTH;
-        knn_file_approx(fval, fidx, cnt, cap, a, v[e], p.y);
-        if (p.x & FAST_BOTH) knn_file_approx(fval, fidx, cnt, cap, p.y, v[e], a);
+        const float val = v[e];
+        if (val <= thr[a]) knn_file_approx(fval, fidx, cnt, cap, a, val, p.y);
+        if ((p.x & FAST_BOTH) && val <= thr[p.y]) knn_file_approx(fval, fidx, cnt, cap, p.y, val, a);
     }
 }
 
 __global__ void __launch_bounds__(256) knn_fast_scatter_spill_kernel(const uint2* __restrict__ ovq, const float* __restrict__ ovv,
                                                                      const unsigned long long* __restrict__ ovn, int ovcap,
                                                                      float* __restrict__ fval, unsigned* __restrict__ fidx,
-                                                                     int* __restrict__ cnt, int cap) {
+                                                                     int* __restrict__ cnt, int cap, const float* __restrict__ thr) {
     const int n = (int)min(*ovn, (unsigned long long)ovcap);
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         const uint2 p = ovq[e];
         const unsigned a = p.x & ~FAST_BOTH;
-        knn_file_approx(fval, fidx, cnt, cap, a, ovv[e], p.y);
-        if (p.x & FAST_BOTH) knn_file_approx(fval, fidx, cnt, cap, p.y, ovv[e], a);
+        const float val = ovv[e];
+        if (val <= thr[a]) knn_file_approx(fval, fidx, cnt, cap, a, val, p.y);
+        if ((p.x & FAST_BOTH) && val <= thr[p.y]) knn_file_approx(fval, fidx, cnt, cap, p.y, val, a);
     }
 }
 
@@ -1192,9 +1197,9 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     // 3) approximate values filed by row, 4) pruned against the row's own (k+1)-th smallest, 5) exact values of the
     //    survivors, 6) selection, 7) exact fix-up of overflowed rows
     hipLaunchKernelGGL(knn_fast_scatter_kernel, dim3(nwg), dim3(256), 0, st, b.wgq, f.wgv, qcap, b.wgq_count, b.cand, f.fidx, b.cnt,
-                       p.cap);
+                       p.cap, thr);
     hipLaunchKernelGGL(knn_fast_scatter_spill_kernel, dim3(256), dim3(256), 0, st, f.ovq, f.ovv, f.ovn, ovcap, b.cand, f.fidx,
-                       b.cnt, p.cap);
+                       b.cnt, p.cap, thr);
     AM_LAUNCH_CHECK();
     const int64_t pair_cap64 = std::min<int64_t>((int64_t)nwg * qcap, (int64_t)1 << 30);
     const int pair_cap = (int)pair_cap64;
