@@ -719,9 +719,25 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
                            b.ovq, b.ov_count, p.ovcap, fail, dbg, fast_c(D), grp_rows);
     };
     const unsigned pre_grid = (unsigned)(ceil_div(Nr, TB) * p.pre_chunks);
-    static const int pre_any = env_int("AM_FAST_PRE_ANY", 1);
+    static const int pre_any = env_int("AM_FAST_PRE_ANY", 1);          // 1: on the engine of the main pass, 2: 128-row engine, 0: none
     if (want_min) launch_filter(&cross_fast_kernel<true, true>, pre_grid, p.pre_chunks, p.qstride, 0);
-    else if (pre_any) launch_filter(&cross_fast_kernel<true, false>, pre_grid, p.pre_chunks, p.qstride, 0);
+    else if (pre_any == 1 && p.wide) {
+        // chunks of the sampled tiles per row block: the count that needs the fewest tile-times on 256 CUs (rounds of
+        // workgroups x tiles per workgroup, one tile-time of fill and drain per round)
+        const int64_t samples = ceil_div(ceil_div(Nc, WIDE_TILE_ROWS), p.qstride), rbs = ceil_div(Nr, WIDE_TILE_ROWS);
+        int chunks = 1;
+        int64_t best_cost = INT64_MAX;
+        for (int c = 1; c <= 12 && c <= samples; ++c) {
+            const int64_t cost = ceil_div(rbs * c, 256) * (ceil_div(samples, c) + 1);
+            if (cost < best_cost) {
+                best_cost = cost;
+                chunks = c;
+            }
+        }
+        if ((rc = launch_cross_wide_sample(Rb, Nr, ldb / 2, rn, Cb, Nc, ldb / 2, cn, ct, Dh, p.qstride, chunks, b.maxn, rany, fast_c(D),
+                                           st)) != AM_OK)
+            return rc;
+    } else if (pre_any) launch_filter(&cross_fast_kernel<true, false>, pre_grid, p.pre_chunks, p.qstride, 0);
     AM_LAUNCH_CHECK();
     unsigned* rmin_or_null = want_min ? rmin : nullptr;
     if (p.wide) {
