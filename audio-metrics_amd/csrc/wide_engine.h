@@ -131,11 +131,7 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
         const unsigned so = (unsigned)(fkt * WROW * 4);
         float* s = lds + buf * WSTAGE_WORDS + wave * 8 * WROW;
 #pragma unroll
-#ifdef AM_WIDE_LOADER_WAVES                            // experiment: waves 0-3 ONLY load (the Q rows 128-255 that waves 4-7 multiply)
-        for (int j = 4; j < 8; ++j) lds_direct_b128(qrs, s + j * 32 * WROW, voq, so + (unsigned)j * (gq >> 1));
-#else
         for (int j = 0; j < 8; ++j) lds_direct_b128(qrs, s + j * 32 * WROW, voq, so + (unsigned)j * (gq >> 1));
-#endif
 #pragma unroll
         for (int j = 0; j < 8; ++j) lds_direct_b128(prs, s + WTILE_WORDS + j * 32 * WROW, vop, so + (unsigned)j * (gp >> 1));
     };
@@ -228,9 +224,6 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
         __builtin_amdgcn_sched_barrier(0);
 #endif
         Frags f0, f1;
-#ifdef AM_WIDE_LOADER_WAVES
-        if (wave >= 4) {
-#endif
         if (kt == 0) {
             f0 = frags(st, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -261,9 +254,6 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
             epi.finish(t, qtile_of(t), acc);
             if (t + 1 < ntiles) epi.aux_commit(t + 1);
         }
-#ifdef AM_WIDE_LOADER_WAVES
-        } else advance_fetch();
-#endif
         WIDE_STAMP(4);
         __builtin_amdgcn_s_waitcnt(0x0F70);         // the slab of stage g+1 has landed in LDS
         WIDE_STAMP(5);

@@ -78,11 +78,7 @@ int main() {
             (void)hipEventSynchronize(e1);
             float ms = 0;
             (void)hipEventElapsedTime(&ms, e0, e1);
-            #ifdef AM_WIDE_LOADER_WAVES
-            const double flop = 2.0 * 128 * 256 * D * ntiles * 256;     // waves 4-7 multiply Q rows 128-255 only
-#else
             const double flop = 2.0 * 256 * 256 * D * ntiles * 256;
-#endif
             printf("%s D %3d rows %6d: %.3f ms  %.0f TFLOP/s (%.3f of 2500)  %.3f us per k-slab\n", VARIANT, D, rows, ms, flop / ms * 1e-9, flop / ms * 1e-9 / 2500.0,
                    ms * 1e3 / (ntiles * (D / 64)));
         }
