@@ -52,11 +52,11 @@ struct WLane {
 };
 
 // descriptor over the valid rows of a 256-row tile starting at row0 (rows past the end read as zero)
-__device__ __forceinline__ TileRsrc make_wide_rsrc(const float* base, int64_t ld, int64_t n_rows, int64_t row0) {
+__device__ __forceinline__ TileRsrc make_wide_rsrc(const float* base, int64_t ld, int64_t n_rows, int64_t row0, int dbg_bit = 1) {
     int64_t valid = n_rows - row0;
     valid = valid < 0 ? 0 : (valid > WTB ? WTB : valid);
 #ifdef AM_DEV_KNOBS
-    if ((g_wide_dbg & 1) && valid > 0) row0 = row0 % (4 * WTB);   // four blocks per operand: 2 MB in all, L2 resident
+    if ((g_wide_dbg & dbg_bit) && valid > 0) row0 = row0 % (4 * WTB);   // four blocks per operand: 2 MB in all, L2 resident
 #endif
     const float* p = base + (valid > 0 ? row0 : 0) * ld;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(p) & 0xffffffffu));
@@ -111,7 +111,7 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
     // travels in the instruction's scalar offset (two address registers instead of eight)
     const unsigned voq = (unsigned)(((int64_t)srow * ldq + chunk * 4) * 4), vop = (unsigned)(((int64_t)srow * ldp + chunk * 4) * 4);
     const unsigned gq = (unsigned)(64 * ldq * 4), gp = (unsigned)(64 * ldp * 4);
-    const TileRsrc prs = make_wide_rsrc(P, ldp, np, prow0);
+    const TileRsrc prs = make_wide_rsrc(P, ldp, np, prow0, 1 | 32);     // (bit 32: only the P operand L2-resident)
     const int64_t q_tiles_total = (nq + WTB - 1) / WTB;
     auto qtile_of = [&](int t) -> int64_t { return t < ntiles ? tmap(t) : q_tiles_total; };   // past the end: empty descriptor
     int ft = 0, fkt = 0;                                           // (tile, k-slab) of the stage being fetched
