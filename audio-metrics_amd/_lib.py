@@ -21,6 +21,8 @@ SIGNATURES = {
     "am_colsum_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_size_t, _P]),
     "am_scatter_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "am_stats_merge_f64": (c_int, [c_int64, _P, _P, c_int64, _P, _P, c_int, _P, _P, _P]),
+    "am_stats_push_max_rows": (c_int, []),
+    "am_stats_push_f32": (c_int, [_P, c_int64, c_int, c_int64, c_int64, _P, _P, _P, _P, c_int64, _P]),
     "am_frechet_workspace_bytes": (c_size_t, [c_int]),
     "am_frechet_f64": (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, _P, _P, c_size_t, _P]),
     "am_frechet_first_block": (c_int, []),
@@ -56,6 +58,9 @@ SIGNATURES = {
     "am_eigh_workspace_bytes": (c_size_t, [c_int]),
     "am_eigh_sym_f64": (c_int, [_P, c_int, _P, _P, c_int, _P, c_size_t, _P]),
     "am_project_f64": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, c_int, _P, _P]),
+    "am_evaluate_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int, c_int, ctypes.c_uint]),
+    "am_evaluate_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, ctypes.c_uint, c_int, _P, _P, c_int, c_int,
+                                c_double, c_double, c_int, _P, _P, _P, _P, c_size_t, _P, _P]),
     "am_kernel_clock_enable": (c_int, [c_int]),
     "am_kernel_clock_read": (c_int, [c_int, _P, _P]),
     "am_knn_path": (c_int, [c_int64, c_int64, c_int, c_int, c_int]),
@@ -71,6 +76,12 @@ class HipLibraryError(RuntimeError):
 class PreparedSetStruct(ctypes.Structure):
     """am_prepared_set: a host struct of three device pointers."""
     _fields_ = [("norms", c_void_p), ("stats", c_void_p), ("half", c_void_p)]
+
+
+class EvaluateSideStruct(ctypes.Structure):
+    """am_evaluate_side: results the caller already holds / wants to keep (device pointers, NULL = not given)."""
+    _fields_ = [("mean", c_void_p), ("cov", c_void_p), ("radii", c_void_p),
+                ("mean_out", c_void_p), ("cov_out", c_void_p), ("radii_out", c_void_p)]
 
 
 _lib = None

@@ -36,6 +36,7 @@ PROJECTIONS = ("stem_projection", "mix_projection")
 PLAIN_STATE = ("metrics", "need_apa", "win_dur", "input_sr", "apa_d_x_xp")
 ROW_METRICS = frozenset(("kd", "precision", "prdc"))          # metrics that need the stored rows (audio_metrics.py:17)
 MAX_NEAREST_K = 10                                             # audio_metrics.py:263
+FUSED_METRICS = ("fad", "kd", "prdc")                          # what one am_evaluate_f32 call covers (result-key order)
 
 EMPTY_REFERENCE = ("The reference dataset is empty. This can have various causes:"
                    "  - You have not called AudioMetrics.add_reference()"
@@ -200,10 +201,47 @@ class AudioMetrics:
                 "mix_projection", ["mix_reference", "mix_anti_reference"], cand, False)
         if self._group is not None:
             return self._evaluate_sharded(sets)
-        result = {}
+        result = self._run_fused(sets) or {}
         for key, run in METRIC_TABLE:
-            if key in self.metrics:
+            if key in self.metrics and not (result and key in FUSED_METRICS):
                 result.update(run(self, sets))
+        return result
+
+    def _run_fused(self, sets):
+        """FAD / KD / PRDC of the stem sets as ONE library call and one read-back (am_evaluate_f32,
+        audio_metrics.py:254-274) when at least two of them are asked for and both sets are in the plain device form; the
+        statistics come from the sets (accumulated add by add), the reference's cached radii are reused and the radii
+        computed here are cached on the sets exactly as get_radii() would (data.py:60-66).  None -> the per-metric runners."""
+        wanted = [m for m in FUSED_METRICS if m in self.metrics]
+        cand, ref = sets.stem_cand, sets.stem_ref
+        if len(wanted) < 2 or cand is None or ref is None:
+            return None
+        rows = [m for m in wanted if m != "fad"]
+        d = ref.mean.numel()
+        for side in (ref, cand):
+            if rows and (side.embeddings is None or side.embeddings.shape[1] != d):
+                return None
+            if tuple(side.cov.shape) != (d, d) or side.mean.device != self.device:
+                return None
+        from . import distributed, hip_ops
+        k = max(1, min(MAX_NEAREST_K, len(ref), len(cand)))
+        if not rows:
+            return None
+        given = []
+        for side in (ref, cand):
+            g = {"mean": side.mean, "cov": side.cov}
+            if "prdc" in wanted:
+                slot = "radii_%d" % k
+                if slot in side.radii:
+                    g["radii"] = side.radii[slot]
+                else:
+                    g["radii_out"] = torch.empty(side.embeddings.shape[0], dtype=torch.float32, device=self.device)
+            given.append(g)
+        result = distributed.evaluate_single(ref.embeddings, cand.embeddings, wanted, k, hip_ops, given_ref=given[0],
+                                             given_cand=given[1])
+        for side, g in zip((ref, cand), given):
+            if "radii_out" in g:
+                side.radii["radii_%d" % k] = g["radii_out"]
         return result
 
     # -- single-process metric runners (result-key order of audio_metrics.py:254-274)

@@ -126,6 +126,7 @@ __device__ __forceinline__ SymWork sym_work(int64_t T, int win_tiles, int nwin, 
 static __constant__ int g_wide_dbg;
 // AM_WIDE_TRACE: s_memtime stamps of wave 0 / wave 4 of the first 64 workgroups, 96 stages x 6 points each (dev tool)
 static __constant__ unsigned long long* g_wide_trace;
+static __constant__ int g_wide_trace_b0;                      // AM_WIDE_TRACE_B0: first traced workgroup
 #endif
 
 constexpr unsigned FAST_COUNTED = 0x80000000u;                               // membership queue entry: the pair was already counted as certain

@@ -9,11 +9,13 @@ namespace am {
 
 #ifdef AM_DEV_KNOBS
 static unsigned long long* g_trace_dev = nullptr;
-// AM_WIDE_DBG -> g_wide_dbg; AM_WIDE_TRACE=1 -> a trace buffer (64 workgroups x 2 waves x 96 stages x 6 stamps) that
+// AM_WIDE_DBG -> g_wide_dbg; AM_WIDE_TRACE=1 -> a trace buffer (64 workgroups from AM_WIDE_TRACE_B0 on x 2 waves x 96 stages x 6 stamps) that
 // am_wide_trace_read copies out.  Development aid of the A/B build only.
 static hipError_t set_wide_dev_symbols(hipStream_t st) {
-    const int wdbg = env_int("AM_WIDE_DBG", 0);
+    const int wdbg = env_int("AM_WIDE_DBG", 0), b0 = env_int("AM_WIDE_TRACE_B0", 0);
     hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wide_dbg), &wdbg, sizeof(int), 0, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wide_trace_b0), &b0, sizeof(int), 0, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return e;
     if (env_int("AM_WIDE_TRACE", 0) && g_trace_dev == nullptr) {
         e = hipMalloc(&g_trace_dev, 64 * 2 * 96 * 6 * sizeof(unsigned long long));
@@ -36,11 +38,7 @@ namespace am {
 // ---- the same filter on the 256 x 256 f16 engine (wide_engine.h): main pass only ---------------------------------
 constexpr int WIDE_AUX_WORDS = 6 * WTB;                                    // LDS [2][3][256]: what finish() reads
 constexpr int WIDE_RAW_WORDS = 4 * WTB;                                    // LDS [2][2][256]: DMA landing zone of the side data
-#ifdef AM_WIDE_STAMPS
-constexpr size_t WIDE_CROSS_LDS_BYTES = 163840;                            // room for the stamp buffer of wide_phased.h
-#else
 constexpr size_t WIDE_CROSS_LDS_BYTES = (WENGINE_LDS_WORDS + WIDE_AUX_WORDS + WIDE_RAW_WORDS) * sizeof(float) + 16;
-#endif
 
 struct CrossWideEpilogue {
     const float* qnorm;
@@ -48,7 +46,6 @@ struct CrossWideEpilogue {
     int64_t nq;
     float fc, rnmax_c;
     float* aux;                 // LDS [2][3][256] : |c_j|^2, T'_j + E'_j, T'_j - E'_j of the tile
-    float* aux_raw;             // LDS [2][2][256] : |c_j|^2, T'_j as the DMA delivers them
     int32_t* col_count;
     uint2* wgq;
     int* qn;
@@ -95,27 +92,6 @@ struct CrossWideEpilogue {
             d[2 * WTB] = in ? aux_hi - e : -INFINITY;
         }
     }
-#ifdef AM_WIDE_PHASED
-    // phased schedule (wide_phased.h): one DMA instruction per wave - waves 0-3 the norms, waves 4-7 the thresholds, 64 each
-    __device__ __forceinline__ void aux_dma(int t, int64_t qtile, int wave) {
-        const int arr = wave >> 2;
-        const TileRsrc r = make_aux_rsrc(arr ? qthr : qnorm, nq, qtile * WTB);
-        lds_direct_b32<false>(r, aux_raw + ((t & 1) * 2 + arr) * WTB + (wave & 3) * 64, L.lane, (wave & 3) * 64);
-    }
-    __device__ __forceinline__ void aux_cook(int t, int64_t qtile) {
-        if (L.tid < WTB) {
-            const bool in = qtile * WTB + L.tid < nq;
-            const float* raw = aux_raw + (t & 1) * 2 * WTB + L.tid;
-            const float a = in ? raw[0] : INFINITY;             // a = +inf: never below anything
-            const float hi = raw[WTB];
-            float* d = aux + (t & 1) * 3 * WTB + L.tid;
-            const float e = fmaf(fc, a, rnmax_c);
-            d[0] = a;
-            d[WTB] = in ? hi + e : -INFINITY;
-            d[2 * WTB] = in ? hi - e : -INFINITY;
-        }
-    }
-#endif
     // NEED_ANY = false: every row of this block already has its "any" witness - the column-threshold test (one subtraction
     // and half a min3 per accumulator element, and the threshold loads) is not compiled in
     template <bool WANT_MIN, bool NEED_ANY>
@@ -209,10 +185,6 @@ struct CrossWideShim {
     CrossWideEpilogue& e;
     __device__ __forceinline__ void aux_issue(int t, int64_t q) { e.aux_issue(t, q); }
     __device__ __forceinline__ void aux_commit(int t) { e.aux_commit(t); }
-#ifdef AM_WIDE_PHASED
-    __device__ __forceinline__ void aux_dma(int t, int64_t q, int wave) { e.aux_dma(t, q, wave); }
-    __device__ __forceinline__ void aux_cook(int t, int64_t q) { e.aux_cook(t, q); }
-#endif
     __device__ __forceinline__ void finish(int t, int64_t q, f32x16 (&acc)[4][2]) { e.template finish_impl<WANT_MIN, NEED_ANY>(t, q, acc); }
 };
 
@@ -278,7 +250,6 @@ cross_wide_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const f
     epi.nq = Nc;
     epi.rnmax_c = fc * gmax;
     epi.aux = lds + WENGINE_LDS_WORDS;
-    epi.aux_raw = lds + WENGINE_LDS_WORDS + WIDE_AUX_WORDS;
     epi.col_count = col_count;
     epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
     epi.qn = qn;
@@ -392,13 +363,6 @@ struct CrossSampleEpilogue {
             d[WTB] = in ? aux_hi - fmaf(fc, aux_n, rnmax_c) : -INFINITY;
         }
     }
-#ifdef AM_WIDE_PHASED
-    __device__ __forceinline__ void aux_dma(int, int64_t, int) {}
-    __device__ __forceinline__ void aux_cook(int t, int64_t qtile) {       // (plain loads: this pass is not the one being tuned)
-        aux_issue(t, qtile);
-        aux_commit(t);
-    }
-#endif
     __device__ __forceinline__ void finish(int t, int64_t, f32x16 (&acc)[4][2]) {
         const float* a = aux + (t & 1) * 2 * WTB + L.wm * 128 + L.h * 4;
 #pragma unroll
@@ -472,36 +436,10 @@ int launch_cross_wide_sample(const float* Rb, int64_t Nr, int64_t ldr, const flo
 }
 
 // The same sweep on the 256 x 256 f16 engine (wide_engine.h): row blocks and column tiles of 256 rows, 512 threads.
-#ifdef AM_WIDE_STAMPS
-constexpr size_t KNN_WIDE_LDS_BYTES = 163840;
-#else
 constexpr size_t KNN_WIDE_LDS_BYTES = (WENGINE_LDS_WORDS + 8 * WTB) * sizeof(float) + 16;   // + aux [2][2][256] + raw [2][2][256]
-#endif
 
-// side data of the phased engine: waves 0-3 fetch the norms, waves 4-7 the bounds (read at device scope: other workgroups
-// lower them while this kernel runs; a stale value is only a looser filter)
 template <int KCAP>
-struct KnnWideEpilogue : KnnFastEpilogue<KCAP, WLane, WTB, 4> {
-    using Base = KnnFastEpilogue<KCAP, WLane, WTB, 4>;
-    float* aux_raw;
-    __device__ __forceinline__ KnnWideEpilogue(const WLane& l) : Base(l) {}
-#ifdef AM_WIDE_PHASED
-    __device__ __forceinline__ void aux_dma(int t, int64_t qtile, int wave) {
-        float* dst = aux_raw + ((t & 1) * 2 + (wave >> 2)) * WTB + (wave & 3) * 64;
-        if (wave < 4) lds_direct_b32<false>(make_aux_rsrc(this->qnorm, this->n, qtile * WTB), dst, this->L.lane, (wave & 3) * 64);
-        else lds_direct_b32<true>(make_aux_rsrc(this->thr, this->n, qtile * WTB), dst, this->L.lane, (wave & 3) * 64);
-    }
-    __device__ __forceinline__ void aux_cook(int t, int64_t qtile) {
-        if (this->L.tid < WTB) {
-            const bool in = qtile * WTB + this->L.tid < this->n;
-            const float* raw = aux_raw + (t & 1) * 2 * WTB + this->L.tid;
-            float* d = this->aux + (t & 1) * 2 * WTB + this->L.tid;
-            d[0] = in ? raw[0] : INFINITY;
-            d[WTB] = in ? raw[WTB] : -INFINITY;
-        }
-    }
-#endif
-};
+using KnnWideEpilogue = KnnFastEpilogue<KCAP, WLane, WTB, 4>;
 
 template <int KCAP>
 __global__ void __launch_bounds__(WTHREADS, 1)
@@ -525,7 +463,6 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     epi.n = N;
     epi.pblock = sw.pb;
     epi.aux = lds + WENGINE_LDS_WORDS;
-    epi.aux_raw = lds + WENGINE_LDS_WORDS + 4 * WTB;
     epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
     epi.wgv = wgv + (int64_t)blockIdx.x * qcap;
     epi.qn = reinterpret_cast<int*>(lds + WENGINE_LDS_WORDS + 8 * WTB);
@@ -597,7 +534,6 @@ struct KnnSampleEpilogue {
     const float* qnorm;
     int64_t n;
     float* aux;                 // LDS [2][WTB] : |x_j|^2 of the tile
-    float* aux_raw;             // LDS [2][WTB] : the same as the DMA delivers it
     float dsc;
     float xn[2];
     float best[2][KCAP];        // ascending, +inf padded
@@ -613,14 +549,6 @@ struct KnnSampleEpilogue {
     __device__ __forceinline__ void aux_commit(int t) {
         if (L.tid < WTB) aux[(t & 1) * WTB + L.tid] = aux_n;
     }
-#ifdef AM_WIDE_PHASED
-    __device__ __forceinline__ void aux_dma(int t, int64_t qtile, int wave) {
-        if (wave < 4) lds_direct_b32<false>(make_aux_rsrc(qnorm, n, qtile * WTB), aux_raw + (t & 1) * WTB + wave * 64, L.lane, wave * 64);
-    }
-    __device__ __forceinline__ void aux_cook(int t, int64_t qtile) {
-        if (L.tid < WTB) aux[(t & 1) * WTB + L.tid] = qtile * WTB + L.tid < n ? aux_raw[(t & 1) * WTB + L.tid] : INFINITY;
-    }
-#endif
     __device__ __forceinline__ void finish(int t, int64_t, f32x16 (&acc)[4][2]) {
         const float* a = aux + (t & 1) * WTB + L.wm * 128 + L.h * 4;
 #pragma unroll
@@ -641,11 +569,7 @@ struct KnnSampleEpilogue {
 };
 
 
-#ifdef AM_WIDE_STAMPS
-constexpr size_t KNN_SAMPLE_LDS_BYTES = 163840;
-#else
 constexpr size_t KNN_SAMPLE_LDS_BYTES = (WENGINE_LDS_WORDS + 4 * WTB) * sizeof(float);
-#endif
 
 // partial[(chunk * N + i) * KCAP + s]: this chunk's smallest sampled values of row i (knn_merge_kernel combines the chunks)
 template <int KCAP>
@@ -663,7 +587,6 @@ knn_wide_sample_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, con
     epi.qnorm = xnorm;
     epi.n = N;
     epi.aux = lds + WENGINE_LDS_WORDS;
-    epi.aux_raw = lds + WENGINE_LDS_WORDS + 2 * WTB;
     epi.dsc = half_unscale(maxn[2], maxn[2]);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {

@@ -294,6 +294,82 @@ __global__ void merge_mean_kernel(int64_t n1, const double* mean1, int64_t n2, c
     out_mean[i] = ((double)n1 * mean1[i] + (double)n2 * mean2[i]) / (double)(n1 + n2);
 }
 
+
+// ------------------------------------------------------------------ streaming add (one launch per batch)
+// The embedding pipeline feeds AudioMetricsData.add() with batches of <= 32 rows (reference embed.py:231-236), each of
+// which is: batch mean / covariance (data.py:37-47), Chan merge into the running (n, mean, cov) (data.py:77-94), row
+// append (data.py:68-72).  As separate entry points that is >= 6 launches and three temporaries per batch; here it is ONE
+// launch: workgroup (I, J) owns the 32 x 32 tile of the running covariance, stages the batch's columns I and J in LDS,
+// computes their means in f64, centres in f32 (as am_stats_f32 does: exact f32 products of f32-centred values), sums the
+// products in f64, applies the reference's merge formula with its association order to its tile in place, and copies its
+// share of the rows into the stored matrix.  The means are read from mean_in and written to mean_out (two buffers the
+// caller alternates): other workgroups still need the old mean of columns I for their own delta terms.
+constexpr int PUSH_TILE = 32;
+constexpr int PUSH_MAX_ROWS = 128;
+
+__global__ void __launch_bounds__(256) stats_push_kernel(const float* __restrict__ E, int b, int D, int64_t ld, int64_t n_old,
+                                                         const double* __restrict__ mean_in, double* __restrict__ mean_out,
+                                                         double* __restrict__ cov, float* __restrict__ rows_out, int64_t ld_out) {
+    __shared__ float ea[PUSH_MAX_ROWS][PUSH_TILE + 1], eb[PUSH_MAX_ROWS][PUSH_TILE + 1];
+    __shared__ double mu[2][PUSH_TILE];
+    const int tid = threadIdx.x;
+    const int tj = blockIdx.x, ti = blockIdx.y;
+    const int i0 = ti * PUSH_TILE, j0 = tj * PUSH_TILE;
+    // stage the two column strips of the batch (columns past D as zeros)
+    for (int e = tid; e < b * PUSH_TILE; e += 256) {
+        const int r = e / PUSH_TILE, c = e % PUSH_TILE;
+        ea[r][c] = i0 + c < D ? E[(int64_t)r * ld + i0 + c] : 0.f;
+        eb[r][c] = j0 + c < D ? E[(int64_t)r * ld + j0 + c] : 0.f;
+    }
+    __syncthreads();
+    if (tid < 2 * PUSH_TILE) {                                  // batch means of the 64 columns, f64 sums in row order
+        const int which = tid / PUSH_TILE, c = tid % PUSH_TILE;
+        double s = 0;
+        for (int r = 0; r < b; ++r) s += (double)(which ? eb[r][c] : ea[r][c]);
+        mu[which][c] = s / (double)b;
+    }
+    __syncthreads();
+    for (int e = tid; e < b * PUSH_TILE; e += 256) {            // centre in f32 against the f32-rounded mean (am_stats_f32's arithmetic)
+        const int r = e / PUSH_TILE, c = e % PUSH_TILE;
+        ea[r][c] -= (float)mu[0][c];
+        eb[r][c] -= (float)mu[1][c];
+    }
+    __syncthreads();
+    const double n1 = (double)n_old, n2 = (double)b, n = n1 + n2;
+    const int c = tid % PUSH_TILE;
+#pragma unroll
+    for (int q = 0; q < PUSH_TILE / 8; ++q) {
+        const int r = tid / PUSH_TILE + 8 * q;                  // tile row (column of strip A)
+        const int gi = i0 + r, gj = j0 + c;
+        if (gi >= D || gj >= D) continue;
+        double sum = 0;
+        for (int k = 0; k < b; ++k) sum = fma((double)ea[k][r], (double)eb[k][c], sum);
+        const double cov2 = b > 1 ? sum / (double)(b - 1) : 0.0;       // data.py:40-42: one row -> zero covariance
+        const int64_t o = (int64_t)gi * D + gj;
+        if (n_old == 0) {
+            cov[o] = cov2;
+        } else {                                                 // data.py:83-92, same association order
+            const double w1 = (n1 - 1) / (n - 1), w2 = (n2 - 1) / (n - 1), wd = (n1 * n2 / n) / (n - 1);
+            const double di = mean_in[gi] - mu[0][r], dj = mean_in[gj] - mu[1][c];
+            cov[o] = (w1 * cov[o] + w2 * cov2) + wd * (di * dj);
+        }
+    }
+    if (ti == tj && tid < PUSH_TILE && i0 + tid < D) {          // the diagonal workgroups write the new means
+        const int g = i0 + tid;
+        mean_out[g] = n_old == 0 ? mu[0][tid] : (n1 * mean_in[g] + n2 * mu[0][tid]) / n;
+    }
+    if (rows_out != nullptr) {                                   // append: this workgroup's share of the b x D elements
+        const int64_t total = (int64_t)b * D;
+        const int64_t nwg = (int64_t)gridDim.x * gridDim.y, wg = (int64_t)ti * gridDim.x + tj;
+        const int64_t per = (total + nwg - 1) / nwg;
+        const int64_t lo = wg * per, hi = lo + per < total ? lo + per : total;
+        for (int64_t e = lo + tid; e < hi; e += 256) {
+            const int64_t r = e / D, col = e % D;
+            rows_out[r * ld_out + col] = E[r * ld + col];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host side
 struct StatsPlan {
     int cs_blocks;
@@ -427,6 +503,24 @@ extern "C" int am_stats_merge_f64(int64_t n1, const double* mean1, const double*
     AM_LAUNCH_CHECK();
     hipLaunchKernelGGL(merge_mean_kernel, dim3((unsigned)ceil_div(D, 128)), dim3(128), 0, st, n1, mean1, n2, mean2, D,
                        out_mean);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+extern "C" int am_stats_push_max_rows(void) { return PUSH_MAX_ROWS; }
+
+extern "C" int am_stats_push_f32(const float* E, int64_t b, int D, int64_t ld, int64_t n_old, const double* mean_in,
+                                 double* mean_out, double* cov, float* rows_out, int64_t ld_out, am_stream_t stream) {
+    AM_REQUIRE(E != nullptr && mean_out != nullptr && cov != nullptr, AM_ERR_BAD_ARG, "null pointer");
+    AM_REQUIRE(b >= 1 && b <= PUSH_MAX_ROWS && D >= 1, AM_ERR_BAD_SHAPE, "batch of %lld rows x %d (1 .. %d rows per push)",
+               (long long)b, D, PUSH_MAX_ROWS);
+    AM_REQUIRE(ld >= D && n_old >= 0, AM_ERR_BAD_ARG, "ld=%lld < D=%d or n_old=%lld < 0", (long long)ld, D, (long long)n_old);
+    AM_REQUIRE(n_old == 0 || (mean_in != nullptr && mean_in != mean_out), AM_ERR_BAD_ARG,
+               "the running mean is read from mean_in and written to a different mean_out");
+    AM_REQUIRE(rows_out == nullptr || ld_out >= D, AM_ERR_BAD_ARG, "ld_out=%lld < D=%d", (long long)ld_out, D);
+    const unsigned t = (unsigned)ceil_div(D, PUSH_TILE);
+    hipLaunchKernelGGL(stats_push_kernel, dim3(t, t), dim3(256), 0, static_cast<hipStream_t>(stream), E, (int)b, D, ld, n_old,
+                       mean_in, mean_out, cov, rows_out, ld_out);
     AM_LAUNCH_CHECK();
     return AM_OK;
 }

@@ -30,7 +30,6 @@
 
 namespace am {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int WTB = 256;                              // tile rows of either operand
 constexpr int WTHREADS = 512;
 constexpr int WROW = 32;                              // LDS row: 32 words = 128 B = 64 f16
@@ -77,11 +76,6 @@ __device__ __forceinline__ void wide_zero(f32x16 (&acc)[4][2]) {
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 }
 
-#ifdef AM_WIDE_PHASED                              // the alternative schedule (measured: not faster; wide_phased.h)
-}  // namespace am
-#include "wide_phased.h"
-namespace am {
-#else
 // Q, P: f16 matrices viewed as f32 words (ld and Dh in words, Dh % 32 == 0).  tmap(t) = index of the 256-row Q tile
 // that local tile t multiplies; P block = rows prow0 .. prow0 + 255.  Epi as in tile_engine.h:
 //   aux_issue(t, qtile) / aux_commit(t) : per-tile side data through LDS;  finish(t, qtile, acc[4][2])
@@ -123,19 +117,6 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
         if ((j & 1) == 0) lds_direct_b128(qrs, s + (j >> 1) * 64 * WROW, voq, so + (unsigned)(j >> 1) * gq);
         else lds_direct_b128(prs, s + WTILE_WORDS + (j >> 1) * 64 * WROW, vop, so + (unsigned)(j >> 1) * gp);
     };
-#ifdef AM_WIDE_SPLIT_ROLES
-    // waves 0-3 fetch the whole next stage (16 instructions each: rows 32 j + 8 wave of the Q slab, then of the P slab) in
-    // one burst at the top of the stage - the instructions block the issuing wave until the texture path has taken them,
-    // ~0.5-0.9 us per 64 KB stage - while waves 4-7, their SIMD partners, multiply; then waves 0-3 multiply
-    auto fetch_stage = [&](int buf) {
-        const unsigned so = (unsigned)(fkt * WROW * 4);
-        float* s = lds + buf * WSTAGE_WORDS + wave * 8 * WROW;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) lds_direct_b128(qrs, s + j * 32 * WROW, voq, so + (unsigned)j * (gq >> 1));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) lds_direct_b128(prs, s + WTILE_WORDS + j * 32 * WROW, vop, so + (unsigned)j * (gp >> 1));
-    };
-#endif
     auto advance_fetch = [&]() {
         if (++fkt == nk) {
             fkt = 0;
@@ -174,14 +155,8 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
             const f16x8 a = __builtin_bit_cast(f16x8, f.q[m]);
 #pragma unroll
             for (int n = 0; n < 2; ++n)
-#ifdef AM_WIDE_BF16
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.q[m]), __builtin_bit_cast(bf16x8, f.p[n]), first ? zero : acc[m][n], 0, 0, 0);
-#else
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, f.p[n]), first ? zero : acc[m][n], 0, 0, 0);
-#endif
-#ifndef AM_WIDE_SPLIT_ROLES
             if (dma) piece(buf, j0 + m);
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -196,8 +171,8 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
 
 #ifdef AM_DEV_KNOBS
     unsigned long long* trace = nullptr;
-    if (g_wide_trace != nullptr && blockIdx.x < 64 && (wave == 0 || wave == 4) && L.lane == 0)
-        trace = g_wide_trace + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 96 * 6;
+    if (g_wide_trace != nullptr && (int)blockIdx.x >= g_wide_trace_b0 && (int)blockIdx.x < g_wide_trace_b0 + 64 && (wave == 0 || wave == 4) && L.lane == 0)
+        trace = g_wide_trace + ((size_t)((int)blockIdx.x - g_wide_trace_b0) * 2 + (wave >> 2)) * 96 * 6;
 #define WIDE_STAMP(k) do { if (trace != nullptr && g < 96) trace[g * 6 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define WIDE_STAMP(k) do { } while (0)
@@ -219,10 +194,6 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
         const int nbuf = (g + 1) & 1;
         WIDE_STAMP(0);
         if (last_k && t + 1 < ntiles) epi.aux_issue(t + 1, qtile_of(t + 1));   // early: covered by this stage's vmcnt(0)
-#ifdef AM_WIDE_SPLIT_ROLES
-        if (wave < 4) fetch_stage(nbuf);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         Frags f0, f1;
         if (kt == 0) {
             f0 = frags(st, 0);
@@ -267,6 +238,5 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
     }
 }
 
-#endif
 
 }  // namespace am

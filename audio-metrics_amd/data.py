@@ -46,11 +46,25 @@ class AudioMetricsData:
     def __init__(self, store_embeddings=True, device=None):
         self.n = self.mean = self.cov = None
         self.store_embeddings = bool(store_embeddings)
-        self.embeddings = None            # [n, D] f32 view of self._buf
+        self._embeddings = None           # [n, D] f32 view of self._buf (property `embeddings`)
         self.radii = {}                   # "radii_{k}" -> f32[n]
         self.dtype = torch.float64        # dtype of the statistics
         self._device = torch.device(device) if device is not None else None
         self._buf = None                  # [capacity, ld] f32, rows 16-B aligned
+        self._mean_spare = None           # second mean buffer of the one-launch add (am_stats_push_f32 reads one, writes the other)
+        self._content_version = 0         # bumped whenever the stored rows change: validity of the cached PreparedSet
+        self._prepared = None
+        self._prepared_version = -1
+
+    @property
+    def embeddings(self):
+        return self._embeddings
+
+    @embeddings.setter
+    def embeddings(self, rows):
+        # any assignment - the class's own appends or a caller's - makes the cached PreparedSet (norms, f16 copy) stale
+        self._embeddings = rows
+        self._content_version += 1
 
     # ------------------------------------------------------------ plumbing
     @property
@@ -111,14 +125,55 @@ class AudioMetricsData:
         return other
 
     def add(self, embeddings):
-        e = self._to_device_matrix(embeddings)
+        """Batch statistics, Chan merge, row append (data.py:37-47).  Batches of up to am_stats_push_max_rows() rows - what
+        the embedding pipeline feeds (embed.py:231-236) - take ONE kernel launch (am_stats_push_f32) instead of the
+        statistics / merge / copy chain."""
+        e = embeddings
+        if not (torch.is_tensor(e) and e.is_cuda and e.dtype == torch.float32 and e.dim() == 2 and e.stride(1) == 1):
+            e = self._to_device_matrix(embeddings)
+        elif self._device is None:
+            self._device = e.device
         n = e.shape[0]
         if n == 0:
             raise ValueError("cannot add an empty batch of embeddings")
+        if n <= ops.stats_push_max_rows() and self._push(e):
+            return
+        e = ops.as_matrix(e)
         mean, cov = ops.stats(e)          # n == 1 -> zero covariance (data.py:40-42)
         self._update_stats(mean, cov, n)
         if self.store_embeddings:
             self._update_embeddings(e)
+
+    def _push(self, e):
+        """The one-launch form of add().  False (nothing done) when the running state is not in the plain (D,), (D, D) f64
+        form the kernel updates in place (recompute_stats' (1, 1) quirk, foreign dtypes, another device)."""
+        b, d = e.shape
+        n_old = 0 if self.n is None else int(self.n)
+        dev = e.device
+        if n_old:
+            mean, cov = self.mean, self.cov
+            if not (mean.is_cuda and mean.device == dev and mean.dtype == torch.float64 and mean.numel() == d and mean.is_contiguous()
+                    and cov.dtype == torch.float64 and tuple(cov.shape) == (d, d) and cov.is_contiguous() and cov.device == dev):
+                return False
+            if self.store_embeddings and self.embeddings is not None and self.embeddings.shape[1] != d:
+                return False
+        else:
+            self.mean = None
+            self.cov = torch.empty((d, d), dtype=torch.float64, device=dev)
+        spare = self._mean_spare
+        if spare is None or spare.numel() != d or spare.device != dev:
+            spare = torch.empty(d, dtype=torch.float64, device=dev)
+        rows_out, ld_out = None, 0
+        if self.store_embeddings:
+            held = 0 if self.embeddings is None else self.embeddings.shape[0]
+            self._reserve(held + b, d, dev)
+            rows_out, ld_out = self._buf[held], self._buf.stride(0)
+        ops.stats_push(e, n_old, self.mean, spare, self.cov, rows_out, ld_out)
+        self.mean, self._mean_spare = spare, self.mean          # (two mean buffers alternate: the kernel reads one, writes the other)
+        self.n = n_old + b
+        if self.store_embeddings:
+            self.embeddings = self._buf[:held + b, :d]
+        return True
 
     def recompute_stats(self):
         """One-shot statistics of the stored rows (data.py:49-58); a no-op without stored rows."""
@@ -138,10 +193,17 @@ class AudioMetricsData:
         if rows is None:
             return None
         rows = ops.as_matrix(rows)
-        cached = getattr(self, "_prepared", None)
-        if cached is None or not cached.matches(rows):
+        # valid for exactly the content it was computed from: every append / load / move bumps _content_version, and a
+        # matrix assigned to .embeddings from outside no longer is the buffer view the cache was taken from
+        cached = self._prepared
+        if cached is None or self._prepared_version != self._content_version or not cached.matches(rows):
             cached = self._prepared = ops.prepare(rows)
+            self._prepared_version = self._content_version
         return cached
+
+    def invalidate_prepared(self):
+        """Call after editing stored rows IN PLACE (the class never does): the derived norms / f16 copy are recomputed."""
+        self._content_version += 1
 
     def get_radii(self, k_neighbor):
         """k-NN radii of the stored rows, computed once per k and kept (like the reference's cache, data.py:60-66, an
@@ -156,15 +218,21 @@ class AudioMetricsData:
     def _update_embeddings(self, embeddings):
         self._append(self._to_device_matrix(embeddings))
 
+    def _reserve(self, rows, d, device):
+        """Capacity for `rows` stored rows: amortised doubling of the HBM buffer (the reference re-concatenates the whole
+        matrix per batch, data.py:68-72)."""
+        held = 0 if self.embeddings is None else self.embeddings.shape[0]
+        if self._buf is None or self._buf.shape[0] < rows or self._buf.device != device:
+            cap = max(rows, 2 * (0 if self._buf is None else self._buf.shape[0]), 1024)
+            buf = torch.empty((cap, _ld_for(d)), dtype=torch.float32, device=device)
+            if held:
+                buf[:held, :d] = self.embeddings
+            self._buf = buf
+
     def _append(self, e):
         n_new, d = e.shape
         n_old = 0 if self.embeddings is None else self.embeddings.shape[0]
-        if self._buf is None or self._buf.shape[0] < n_old + n_new:
-            cap = max(n_old + n_new, 2 * (0 if self._buf is None else self._buf.shape[0]), 1024)
-            buf = torch.empty((cap, _ld_for(d)), dtype=torch.float32, device=e.device)
-            if n_old:
-                buf[:n_old, :d] = self.embeddings
-            self._buf = buf
+        self._reserve(n_old + n_new, d, e.device)
         self._buf[n_old:n_old + n_new, :d] = e
         self.embeddings = self._buf[:n_old + n_new, :d]
 

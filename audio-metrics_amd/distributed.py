@@ -211,21 +211,77 @@ def sharded_radii(local, full, counts, k, ops, world, rank, group, prepared=None
     return r_local, _all_gather_rows(r_local, counts, world, group)
 
 
+def result_from_record(head, mmds, metrics, n_ref, n_cand, nearest_k):
+    """The evaluate() dict from am_evaluate_f32's record (audio_metrics.py:254-274 key order: fad, kernel distance, PRDC)."""
+    result = {}
+    if "fad" in metrics:
+        result["fad"] = head[0]
+    if "kd" in metrics:
+        result["kernel_distance_mean"] = float(np.mean(mmds))
+        result["kernel_distance_std"] = float(np.std(mmds))
+    if "prdc" in metrics:
+        n_prec, n_rec, sum_cnt, n_cov = (int(v) for v in head[5:9])
+        result.update(precision=n_prec / n_cand, recall=n_rec / n_ref,
+                      density=(1.0 / float(nearest_k)) * (sum_cnt / n_cand), coverage=n_cov / n_ref)
+    return result
+
+
+def evaluate_single(ref, cand, metrics, nearest_k, ops, kid_subsets=KID_SUBSETS, kid_subset_size=KID_SUBSET_SIZE, rng_seed=1234,
+                    given_ref=None, given_cand=None):
+    """One GPU: the whole chain is ONE library call (am_evaluate_f32) and one read-back.  given_*: see hip_ops.evaluate."""
+    from .metrics.kd import device_subset_indices
+    n_ref, n_cand = ref.shape[0], cand.shape[0]
+    if n_ref == 0 or n_cand == 0:
+        raise ValueError(f"empty embedding set: {n_ref} reference and {n_cand} candidate rows over 1 ranks")
+    idx1 = idx2 = None
+    if "kd" in metrics:
+        m = kid_subset_size
+        if m >= min(n_ref, n_cand):
+            m = max(1, min(n_ref, n_cand) // 2)
+        idx1, idx2 = device_subset_indices(n_cand, n_ref, kid_subsets, m, rng_seed, ref.device)      # features_1 = candidate
+    stats = None
+    if "fad" in metrics:
+        # the statistics are written where this function can reach them: a covariance product that needs more than the 32
+        # Newton-Schulz iterations the chain enqueues is finished by the stand-alone solver on them
+        d = ref.shape[1]
+        given_ref, given_cand = dict(given_ref or {}), dict(given_cand or {})
+        stats = []
+        for given in (given_cand, given_ref):                               # (x = candidate, y = reference)
+            if given.get("mean") is None or given.get("cov") is None:
+                given.setdefault("mean_out", torch.empty(d, dtype=torch.float64, device=ref.device))
+                given.setdefault("cov_out", torch.empty((d, d), dtype=torch.float64, device=ref.device))
+                stats += [given["mean_out"], given["cov_out"]]
+            else:
+                stats += [given["mean"], given["cov"]]
+    head, mmds = ops.evaluate(ref, cand, metrics, nearest_k, idx1, idx2, None, KID_COEF0, KID_DEGREE, given_ref, given_cand)
+    if "fad" in metrics:
+        code = int(head[4])
+        if code == 4:
+            from ._lib import HipLibraryError
+            raise HipLibraryError("am_evaluate_f32: non-finite covariance product or trace in Newton-Schulz")
+        if code == 0:
+            head[0] = ops.frechet(*stats)["fd"]
+    return result_from_record(head, mmds, metrics, n_ref, n_cand, nearest_k)
+
+
 def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), nearest_k=5, group=None, ops=None,
-                     kid_subsets=KID_SUBSETS, kid_subset_size=KID_SUBSET_SIZE, rng_seed=1234):
+                     kid_subsets=KID_SUBSETS, kid_subset_size=KID_SUBSET_SIZE, rng_seed=1234, fused=True):
     """FAD / KD / PRDC of (candidate vs reference) from this rank's row shards.
-    Returns the same keys as ``AudioMetrics.evaluate`` on every rank."""
+    Returns the same keys as ``AudioMetrics.evaluate`` on every rank.  With one rank the whole chain is one library
+    call (``evaluate_single``); fused=False keeps the entry points separate there too (per-entry timing in bench.py)."""
     if ops is None:
         from . import hip_ops as ops
     world, rank = _world(group)
     dev = ref_local.device
-    counts = torch.tensor([ref_local.shape[0], cand_local.shape[0]], dtype=torch.int64, device=dev)
+    if world == 1 and fused and hasattr(ops, "evaluate"):
+        return evaluate_single(ref_local, cand_local, metrics, nearest_k, ops, kid_subsets, kid_subset_size, rng_seed)
     if world > 1:
+        counts = torch.tensor([ref_local.shape[0], cand_local.shape[0]], dtype=torch.int64, device=dev)
         allc = torch.empty(world * 2, dtype=torch.int64, device=dev)
         _all_gather_into(allc, counts, world, group)
         allc = allc.view(world, 2).cpu().tolist()
     else:
-        allc = [counts.cpu().tolist()]
+        allc = [[ref_local.shape[0], cand_local.shape[0]]]
     ref_counts, cand_counts = [c[0] for c in allc], [c[1] for c in allc]
     n_ref, n_cand = sum(ref_counts), sum(cand_counts)
     if n_ref == 0 or n_cand == 0:                          # the same error on every rank (all of them hold the totals)

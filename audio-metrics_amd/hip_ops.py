@@ -247,6 +247,32 @@ def stats_merge(n1, mean1, cov1, n2, mean2, cov2, inplace=False):
     return om, oc
 
 
+_PUSH_MAX = None
+
+
+def stats_push_max_rows():
+    global _PUSH_MAX
+    if _PUSH_MAX is None:
+        _PUSH_MAX = int(_lib.load().am_stats_push_max_rows())
+    return _PUSH_MAX
+
+
+def stats_push(e, n_old, mean_in, mean_out, cov, rows_out=None, ld_out=0):
+    """One launch for AudioMetricsData.add(batch) of a small batch (am_stats_push_f32; data.py:37-47, 68-72, 77-94): batch
+    statistics, Chan merge into (n_old, mean_in, cov) -> (mean_out, cov in place), rows copied to `rows_out` (the row
+    n_old of the store, row stride ld_out) when given.  The caller owns every buffer; nothing is allocated here - this is
+    the per-batch hot path of the embedding pipeline, so the glue is kept to one ctypes call."""
+    lib = _lib.load()
+    dev = e.device
+    with torch.cuda.device(dev):
+        status = lib.am_stats_push_f32(e.data_ptr(), e.shape[0], e.shape[1], e.stride(0) if e.shape[0] > 1 else e.shape[1],
+                                       int(n_old), mean_in.data_ptr() if mean_in is not None else None, mean_out.data_ptr(),
+                                       cov.data_ptr(), rows_out.data_ptr() if rows_out is not None else None, int(ld_out),
+                                       torch.cuda.current_stream(dev).cuda_stream)
+    if status != 0:
+        _lib.check(status, "am_stats_push_f32")
+
+
 # ------------------------------------------------------------------ PCA projection support
 def eigh_descending(a, max_sweeps=40):
     """(eigenvalues f64[D] descending, eigenvectors f64[D, D] with row i = vector i) of a symmetric PSD matrix."""
@@ -554,3 +580,91 @@ def prdc_reduce(col, rany, rcov):
     out = torch.empty(4, dtype=torch.int64, device=col.device)
     _call(lib, "am_prdc_reduce", col.device, _ptr(col), col.numel(), _ptr(rany), _ptr(rcov), rany.numel(), _ptr(out))
     return out
+
+
+# ------------------------------------------------------------------ one call = one evaluate()
+EVAL_FAD, EVAL_KD, EVAL_PRDC, EVAL_HEAD = 1, 2, 4, 16
+_EVAL_WS = {}
+
+
+def _eval_workspace(nbytes, device):
+    """The evaluate workspace is kept per device and grown on demand: its size is a function of the shapes, an evaluate
+    runs start to finish on one stream, and re-allocating ~1 GB per call costs the allocator round trips this entry point
+    exists to avoid."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _EVAL_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _EVAL_WS[key] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    return ws
+
+
+def evaluate(ref, cand, what, nearest_k=5, idx_cand=None, idx_ref=None, gamma=None, coef0=1.0, degree=3,
+             given_ref=None, given_cand=None):
+    """am_evaluate_f32: FAD / KD / PRDC of (candidate vs reference) as ONE stream-ordered chain with ONE read-back.
+    `what`: iterable of "fad", "kd", "prdc".  given_*: dict with any of mean, cov, radii (already computed: used as they
+    are) and mean_out, cov_out, radii_out (device tensors the chain writes its own results to, so that the caller keeps
+    them).  Returns the raw host record: (head f64[16], mmds f64[S] or None)."""
+    lib = _lib.load()
+    ref, cand = as_matrix(ref, "reference"), as_matrix(cand, "candidate")
+    dev = _same_device(ref, cand)
+    n_ref, d = ref.shape
+    n_cand = cand.shape[0]
+    if cand.shape[1] != d:
+        raise ValueError("feature dimensions differ")
+    flags = sum(bit for name, bit in (("fad", EVAL_FAD), ("kd", EVAL_KD), ("prdc", EVAL_PRDC)) if name in what)
+    s = m = 0
+    if flags & EVAL_KD:
+        idx_cand, idx_ref = _index_table(idx_cand, "idx_cand"), _index_table(idx_ref, "idx_ref")
+        s, m = idx_cand.shape
+    keep = []
+
+    def side(given):
+        if not given:
+            return None
+        st = _lib.EvaluateSideStruct()
+        for key in ("mean", "cov", "mean_out", "cov_out"):
+            t = given.get(key)
+            if t is not None:
+                t = _f64(t, key)
+                if t.device != dev:
+                    raise ValueError(f"{key} lives on {t.device}, the embeddings on {dev}")
+                keep.append(t)
+                setattr(st, key, t.data_ptr())
+        for key in ("radii", "radii_out"):
+            t = given.get(key)
+            if t is not None:
+                _require_cuda(t, key)
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+                    raise ValueError(f"{key} must be a contiguous f32 tensor on {dev}")
+                keep.append(t)
+                setattr(st, key, t.data_ptr())
+        return st
+
+    s_ref, s_cand = side(given_ref), side(given_cand)
+    with torch.cuda.device(dev):
+        main = torch.cuda.current_stream(dev)
+        side_stream = _SIDE_STREAMS.get(("fad", dev.index))
+        if side_stream is None:
+            side_stream = _SIDE_STREAMS[("fad", dev.index)] = torch.cuda.Stream(dev)
+        nb = lib.am_evaluate_workspace_bytes(n_ref, n_cand, d, int(nearest_k), s, m, flags)
+        ws = _eval_workspace(nb, dev)
+        out = torch.empty(EVAL_HEAD + s, dtype=torch.float64, device=dev)
+        timer = KernelTimer.active
+        if timer is not None:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(main)
+        status = lib.am_evaluate_f32(_ptr(ref), n_ref, _ld(ref), _ptr(cand), n_cand, _ld(cand), d, flags, int(nearest_k),
+                                     _ptr(idx_cand) if s else None, _ptr(idx_ref) if s else None, s, m,
+                                     float(1.0 / d if gamma is None else gamma), float(coef0), int(degree),
+                                     ctypes.byref(s_ref) if s_ref is not None else None,
+                                     ctypes.byref(s_cand) if s_cand is not None else None, _ptr(out), _ptr(ws), nb,
+                                     ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(side_stream.cuda_stream))
+        if timer is not None:
+            b.record(main)
+            timer.records.append(("am_evaluate_f32", a, b))
+        _lib.check(status, "am_evaluate_f32")
+        for t in (ref, cand, *keep):
+            t.record_stream(side_stream)
+        host = out.cpu()                                             # the one read-back
+    head = host[:EVAL_HEAD].tolist()
+    return head, (host[EVAL_HEAD:].numpy() if s else None)

@@ -9,41 +9,60 @@ from functools import partial
 import numpy as np
 
 
-def _peak(x, axis=None):
-    return np.max(np.abs(x), axis=axis)
+def _peak(x):
+    """max |x| of a 1-D array without the |x| temporary (np.abs(x).max() for finite input)."""
+    return max(x.max(), -x.min())
 
 
 def mix_tracks_peak_preserve(audio, sr):
     """Channel average rescaled to the largest peak of the input channels; a single channel, or (near-)silent input,
-    passes its first channel through (behaviour of mix_functions.py:209-227)."""
+    passes its first channel through (behaviour of mix_functions.py:209-227).  Written column-wise: the reference's
+    np.mean / np.abs over the [n, 2] array walk a 2-element inner axis, 5x slower for the same f32 values."""
     if audio.ndim != 2:
         raise AssertionError("expected audio of shape [n_samples, channels]")
     first = audio[:, 0]
     if audio.shape[1] < 2:
         return first
-    loudest = _peak(audio)
+    if audio.shape[1] != 2:
+        loudest = np.abs(audio).max()
+        if not loudest > 1e-5:
+            return first
+        mono = np.mean(audio, axis=1)
+        mono *= loudest / np.abs(mono).max()
+        return mono
+    second = audio[:, 1]
+    loudest = max(_peak(first), _peak(second))
     if not loudest > 1e-5:
         return first
-    mono = np.mean(audio, axis=1)
-    return mono * (loudest / _peak(mono))
+    mono = first + second                      # np.mean over the channel pair: (a + b) / 2 in the input's precision
+    mono /= 2
+    mono *= loudest / _peak(mono)
+    return mono
 
 
 def mix_tracks_peak_normalize(audio, sr, stem_db_red=0.0, out_db=0.0):
     """Every channel is scaled to unit peak - the stem (channel 1) `stem_db_red` dB lower than the context - then the
-    sum is brought to a peak of `out_db` dBFS (behaviour of mix_functions.py:230-250)."""
+    sum is brought to a peak of `out_db` dBFS (behaviour of mix_functions.py:230-250, including where it computes in
+    f64: the two gains are numpy f64 scalars there, so the stem peak and the final scaling round once from f64)."""
     if audio.ndim != 2:
         raise AssertionError("expected audio of shape [n_samples, channels]")
-
-    def from_db(db):
-        return 10.0 ** (db / 20.0)
-
+    out_gain = np.power(10.0, out_db / 20.0)
+    stem_gain = np.power(10.0, stem_db_red / 20.0)
     if audio.shape[1] < 2:
         mono = np.array(audio[:, 0], copy=True)
+    elif audio.shape[1] != 2:
+        peaks = np.abs(audio).max(0, keepdims=True)
+        peaks[0, 1] *= stem_gain
+        mono = (audio / peaks).sum(1)
     else:
-        channel_peaks = _peak(audio, axis=0)[None, :]
-        channel_peaks[0, 1] = channel_peaks[0, 1] * from_db(stem_db_red)    # dividing by a smaller peak = boosting less
-        mono = np.sum(audio / channel_peaks, axis=1)
-    return mono * (from_db(out_db) / _peak(mono))
+        context, stem = audio[:, 0], audio[:, 1]
+        peak_c = _peak(context)
+        peak_s = audio.dtype.type(np.float64(_peak(stem)) * stem_gain)    # `peaks[0, 1] *= stem_gain`: f64 product, stored back
+        mono = context / peak_c
+        mono += stem / peak_s
+    gain = out_gain / _peak(mono)              # numpy f64 scalar, as in the reference
+    np.multiply(mono, gain, out=mono, casting="same_kind")                # `mix *= gain`: f64 product, rounded once
+    return mono
 
 
 MIX_FUNCTIONS = dict(

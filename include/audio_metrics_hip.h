@@ -78,6 +78,24 @@ int am_stats_merge_f64(int64_t n1, const double* mean1, const double* cov1,
                        int D, double* out_mean, double* out_cov, am_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * A1 + A3 + A4 fused for the streaming pipeline   reference: data.py:37-47, 68-72, 77-94
+ *   One launch per AudioMetricsData.add(batch) for batches of up to
+ *   am_stats_push_max_rows() rows (the embedding pipeline adds <= 32 rows at a
+ *   time, embed.py:231-236): batch mean / covariance, Chan merge into the running
+ *   (n_old, mean, cov) and the row append.
+ *     mean_in  [D]   running mean (ignored when n_old == 0)
+ *     mean_out [D]   new mean; must not alias mean_in (other workgroups still read it)
+ *     cov      [D,D] running covariance, updated in place (written when n_old == 0)
+ *     rows_out       where row n_old of the stored matrix lives (row stride ld_out), or NULL
+ *   E needs no alignment (any ld >= D).  Numerics as am_stats_f32: f64 means, f32-centred
+ *   values, products summed in f64; merge in f64 with the reference's association.
+ * ------------------------------------------------------------------------- */
+int am_stats_push_max_rows(void);
+int am_stats_push_f32(const float* E, int64_t b, int D, int64_t ld, int64_t n_old,
+                      const double* mean_in, double* mean_out, double* cov,
+                      float* rows_out, int64_t ld_out, am_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * A5  Frechet distance                         reference: fad.py:16-31
  *   fd = |mu_x-mu_y|^2 + tr(cov_x) + tr(cov_y) - 2 tr sqrt(cov_x cov_y)
  *   tr sqrt by a coupled Newton-Schulz iteration in f64 on the f64 matrix
@@ -260,6 +278,41 @@ int am_eigh_sym_f64(const double* A, int D, double* evals, double* evecs, int ma
                     void* ws, size_t ws_bytes, am_stream_t stream);
 int am_project_f64(const float* X, int64_t N, int64_t ld, int D, const double* mean, const double* components, int p,
                    double* out, am_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * A13  one call = one evaluate()                reference: audio_metrics.py:254-274
+ *   The FAD + KD + PRDC dispatch of AudioMetrics.evaluate for two embedding sets on ONE device as a single stream-ordered
+ *   chain of the entry points above (statistics, Frechet solve on `side_stream` under the PRDC kernels, prepared sets,
+ *   radii of both sets, membership counts and totals, kernel distance on the caller's index tables), with every workspace
+ *   carved from one caller buffer and every result in ONE device buffer `out`:
+ *     out[0..4]   fd, tr sqrt, iterations, residual, Frechet stop code (0: the product needs more than the 32 iterations
+ *                 enqueued here - finish with am_frechet_f64 on the statistics; 4: non-finite; -1: FAD not requested)
+ *     out[5..8]   #candidate columns with count > 0, #reference rows with a witness, sum of counts, #reference rows covered
+ *                 (precision = out[5] / n_cand, recall = out[6] / n_ref, density = out[7] / (k n_cand), coverage = out[8] / n_ref)
+ *     out[16 + s] unbiased MMD^2 of subset s (kernel_distance_mean / _std are numpy's mean / std of these, kd.py:189-192)
+ *   `what` selects the metrics.  am_evaluate_side (optional, per set) hands in results the caller already holds - the
+ *   reference keeps the reference set's statistics and radii between evaluates (data.py:60-66) - and/or names where the
+ *   statistics / radii computed here are to be written so that the caller can keep them; NULL members are ignored.
+ *   idx_cand / idx_ref: int64 [kd_subsets, kd_m] DEVICE tables (am_kd_draw_indices draws them on the host).
+ * ------------------------------------------------------------------------- */
+#define AM_EVAL_FAD 1u
+#define AM_EVAL_KD 2u
+#define AM_EVAL_PRDC 4u
+#define AM_EVAL_HEAD 16
+typedef struct am_evaluate_side {
+    const double* mean;      /* in:  statistics already computed (both or neither) */
+    const double* cov;
+    const float* radii;      /* in:  radii for nearest_k already computed */
+    double* mean_out;        /* out: where statistics computed by this call go (else workspace) */
+    double* cov_out;
+    float* radii_out;        /* out: where radii computed by this call go (else workspace) */
+} am_evaluate_side;
+size_t am_evaluate_workspace_bytes(int64_t n_ref, int64_t n_cand, int D, int nearest_k, int kd_subsets, int kd_m, unsigned what);
+int am_evaluate_f32(const float* ref, int64_t n_ref, int64_t ld_ref, const float* cand, int64_t n_cand, int64_t ld_cand, int D,
+                    unsigned what, int nearest_k, const int64_t* idx_cand, const int64_t* idx_ref, int kd_subsets, int kd_m,
+                    double kd_gamma, double kd_coef0, int kd_degree, const am_evaluate_side* given_ref,
+                    const am_evaluate_side* given_cand, double* out, void* ws, size_t ws_bytes, am_stream_t stream,
+                    am_stream_t side_stream);
 
 /* ---- optional kernel clock (benchmark support; bench.py's roofline) --------------------------------
  * When enabled, the library brackets every launch of the two tile kernels with a hipEvent pair recorded on

@@ -58,6 +58,8 @@ FAD_CASES = {
     "rankdef_300": ("randn", 25, 300, 300, 512),
     "rankdef_40_vs_full": ("randn", 26, 40, 2000, 128),
     "tiny_d8": ("shifted", 27, 50, 60, 8),
+    "clap_unit_100_vs_100": ("unit", 29, 100, 100, 512),  # fewer clips than dimensions, CLAP-shaped: the common small-eval regime
+    "clap_unit_100_vs_4k": ("unit", 30, 4096, 100, 512),
     "clap_100k": ("randn", 28, 100000, 100000, 512),      # BASELINE config 2/3 shape
 }
 

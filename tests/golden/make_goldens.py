@@ -72,6 +72,23 @@ def gen_stats():
     np.savez_compressed(os.path.join(HERE, "stats.npz"), **out)
 
 
+def fad_exact_f64(ref, cand):
+    """The quantity fad.py:28-31 defines, evaluated without the reference's f32 statistics: f64 mean / covariance of the
+    f32 inputs, tr sqrt(Sx Sy) through the symmetric PSD form sqrt(Sx) Sy sqrt(Sx) (eigvalsh, negative rounding noise
+    clamped).  |reference - this| is the reference's own numerical noise on the case."""
+    def stats(x):
+        x = np.asarray(x, dtype=np.float64)
+        mu = x.mean(0)
+        xc = x - mu
+        return mu, xc.T @ xc / max(len(x) - 1, 1)
+    (mx, sx), (my, sy) = stats(cand), stats(ref)
+    w, v = np.linalg.eigh(sx)
+    root = (v * np.sqrt(np.clip(w, 0.0, None))) @ v.T
+    lam = np.linalg.eigvalsh(root @ sy @ root)
+    tr_sqrt = np.sqrt(np.clip(lam, 0.0, None)).sum()
+    return float(((mx - my) ** 2).sum() + np.trace(sx) + np.trace(sy) - 2.0 * tr_sqrt)
+
+
 def gen_fad():
     out = {"versions": VERSIONS}
     for name, (kind, seed, nr, nc, d) in gi.FAD_CASES.items():
@@ -83,7 +100,11 @@ def gen_fad():
         out[f"{name}/tr_sqrt"] = c
         out[f"{name}/tr_sum"] = (a.cov.trace() + b.cov.trace()).item()
         out[f"{name}/mean_sq"] = (a.mean - b.mean).square().sum().item()
-        print("fad", name, out[f"{name}/fad"])
+        # the reference's own noise on this case: |its value - the f64 PSD evaluation of the same definition|
+        out[f"{name}/fad_exact_f64"] = fad_exact_f64(ref, cand)
+        out[f"{name}/ref_noise"] = max(abs(out[f"{name}/fad"] - out[f"{name}/fad_exact_f64"]),
+                                       abs(out[f"{name}/fad_swapped"] - out[f"{name}/fad_exact_f64"]))
+        print("fad", name, out[f"{name}/fad"], "exact", out[f"{name}/fad_exact_f64"], "noise", out[f"{name}/ref_noise"], flush=True)
     np.savez_compressed(os.path.join(HERE, "fad.npz"), **out)
 
 
@@ -167,20 +188,73 @@ def gen_prdc_large():
 
 
 def gen_bench():
-    """oracle.prdc_blocked (row blocks of the reference's torch calls) on bench.py's own 2 x 100k x 512 inputs: the
-    reference's N x N formulation needs 164 GB there.  Stores the integer totals behind the four values."""
+    """bench.py's own 2 x 100k x 512 inputs.  FAD and KD come from the reference's functions themselves; PRDC from
+    oracle.prdc_blocked (row blocks of the reference's torch calls: its N x N formulation needs 164 GB there) for every
+    (data, k) pair the bench line reports.  Incremental: cases already in bench_prdc.npz are kept (6-7 minutes of CPU each)."""
     import time
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
     import oracle
+    path = os.path.join(HERE, "bench_prdc.npz")
     out = {"versions": VERSIONS}
-    for kind, k in (("randn", 5), ("clap", 10)):
-        t0 = time.time()
+    if os.path.exists(path):
+        with np.load(path, allow_pickle=False) as g:
+            out.update({key: g[key] for key in g.files})
+    for kind in ("randn", "clap"):
         ref, cand = gi.bench_pair(kind, 100000, 512)
-        res = oracle.prdc_blocked(ref, cand, k, block=4096)
-        for key, v in res.items():
-            out[f"{kind}_k{k}/{key}"] = v
-        print("bench", kind, k, res, f"{time.time() - t0:.0f}s", flush=True)
-    np.savez_compressed(os.path.join(HERE, "bench_prdc.npz"), **out)
+        if f"{kind}/fad" not in out:
+            t0 = time.time()
+            a, b = amd(cand, store=True), amd(ref, store=True)
+            out[f"{kind}/fad"] = r_fad.frechet_distance(a, b)                 # (candidate, reference), audio_metrics.py:257
+            kd = r_kd.kernel_distance(a, b)                                    # audio_metrics.py:260
+            out[f"{kind}/kernel_distance_mean"] = kd["kernel_distance_mean"]
+            out[f"{kind}/kernel_distance_std"] = kd["kernel_distance_std"]
+            print("bench", kind, "fad", out[f"{kind}/fad"], kd, f"{time.time() - t0:.0f}s", flush=True)
+            del a, b
+            np.savez_compressed(path, **out)
+        for k in (5, 10):
+            if f"{kind}_k{k}/precision" in out:
+                continue
+            t0 = time.time()
+            res = oracle.prdc_blocked(ref, cand, k, block=4096)
+            for key, v in res.items():
+                out[f"{kind}_k{k}/{key}"] = v
+            print("bench", kind, k, res, f"{time.time() - t0:.0f}s", flush=True)
+            np.savez_compressed(path, **out)
+
+
+def mix_inputs():
+    """(name, audio) cases of the peak mixers: f32 / f64, two channels and one, a nearly silent stem, a silent pair."""
+    rng = np.random.default_rng(404)
+    cases = []
+    for i, (n, dt, scale) in enumerate([(4000, np.float32, 1.0), (4001, np.float64, 0.3), (16000, np.float32, 2.5), (333, np.float32, 0.01)]):
+        cases.append((f"pair_{i}", (rng.standard_normal((n, 2)) * scale).astype(dt)))
+    quiet = (rng.standard_normal((2000, 2))).astype(np.float32)
+    quiet[:, 1] *= 1e-7
+    cases.append(("quiet_stem", quiet))
+    cases.append(("silent", np.zeros((500, 2), dtype=np.float32) + np.float32(1e-6)))
+    cases.append(("mono", rng.standard_normal((1500, 1)).astype(np.float32)))
+    return cases
+
+
+def gen_mix():
+    """The reference's peak-based mix functions (mix_functions.py:209-250, registry :335-344) on seeded inputs.  Its module
+    imports pyloudnorm / numpy_audio_limiter / numba at the top (absent here): environment stubs only, the loudness
+    mixers are never called."""
+    import importlib.util
+    for name in ("pyloudnorm", "numpy_audio_limiter", "opt_einsum", "numba"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["numba"].jit = lambda *a, **k: (lambda f: f)
+    spec = importlib.util.spec_from_file_location("ref_mix_functions", os.path.join(REF, "mix_functions.py"))
+    r_mix = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(r_mix)
+    out = {"versions": VERSIONS}
+    for case, audio in mix_inputs():
+        for name in ("PP", "P0", "P1", "P2"):
+            if case == "silent" and name != "PP":
+                continue
+            out[f"{case}/{name}"] = r_mix.MIX_FUNCTIONS[name](audio.copy(), sr=16000)
+    np.savez_compressed(os.path.join(HERE, "mix.npz"), **out)
+    print("mix", len(out) - 1, "outputs")
 
 
 def gen_apa():
@@ -305,7 +379,7 @@ def gen_pca():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["stats", "fad", "kd", "prdc", "apa", "pca", "e2e"]
+    which = sys.argv[1:] or ["stats", "fad", "kd", "prdc", "apa", "pca", "mix", "e2e"]
     for w in which:
         globals()[f"gen_{w}"]()
     print("done", VERSIONS)

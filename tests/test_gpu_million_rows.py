@@ -6,7 +6,13 @@ size-independent properties of the domain (reference src/audio_metrics/metrics/p
     evaluations run the membership filter with the operands exchanged (different tiles, queues and thresholds);
   * the k-NN radii of 512 random rows against a brute-force torch evaluation of those rows (f32 noise of the matmul form);
   * precision's definition on 256 random candidate rows, recounted with torch from the radii;
-  * no row and no call fell back to the exact kernels (the production path at this size is the f16 filter path 3)."""
+  * no row and no call fell back to the exact kernels (the production path at this size is the f16 filter path 3);
+  * FAD (fad.py:28-31): the scale identity FD(sX, sY) = s^2 FD(X, Y), mean and covariance trace / sampled columns recounted in
+    f64 with torch on the device, and the distance itself against the f64 PSD evaluation built from those f64 statistics;
+  * KD (kd.py:127-194): the 100 x 1000-row subsets of 2 x 1M rows against oracle.kid_from_features on the host copies (the
+    oracle's cost depends on the subsets, not on N) - mean, std and the draw order at n = 1M;
+  * the partitioned symmetric k-NN (the multi-GPU form) emulated for 8 parts at 1M rows: bounds per part,
+    each part's share of the sweep, lists stacked as the all-gather would - bit-identical to the single-GPU radii."""
 import numpy as np
 import pytest
 import torch
@@ -72,3 +78,79 @@ def test_million_row_sets_on_one_gpu(am):
     decided = margin > 1e-4                      # rows whose nearest boundary is closer than f32 noise can fall either way
     assert bool((got == inside)[decided].all()), int((got != inside)[decided].sum())
     assert abs(float((col > 0).double().mean()) - fwd["precision"]) < 1e-12
+
+
+@pytest.fixture(scope="module")
+def million(am):
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cuda").manual_seed(32)
+    ref = torch.randn(N, D, generator=gen, device=dev)
+    cand = torch.randn(N, D, generator=gen, device=dev) * 1.03 + 0.02
+    return ref, cand
+
+
+def _stats_f64(x, block=125_000):
+    """mean and covariance of the f32 rows in f64, blockwise on the device (torch; 2 MB result)."""
+    n = x.shape[0]
+    s = torch.zeros(x.shape[1], dtype=torch.float64, device=x.device)
+    for lo in range(0, n, block):
+        s += x[lo:lo + block].double().sum(0)
+    mu = s / n
+    sc = torch.zeros((x.shape[1], x.shape[1]), dtype=torch.float64, device=x.device)
+    for lo in range(0, n, block):
+        xc = x[lo:lo + block].double() - mu
+        sc += xc.T @ xc
+    return mu, sc / (n - 1)
+
+
+def test_million_row_fad(am, million):
+    ref, cand = million
+    a, b = am.AudioMetricsData(False), am.AudioMetricsData(False)
+    a.add(cand)
+    b.add(ref)
+    fad = am.frechet_distance(a, b)
+    (mx, sx), (my, sy) = _stats_f64(cand), _stats_f64(ref)
+    # statistics: mean to f64 accuracy; covariance trace and every 37th column against the f64 recount
+    for got, (mu, cov) in ((a, (mx, sx)), (b, (my, sy))):
+        assert float((got.mean - mu).abs().max()) <= 1e-12
+        assert abs(float(got.cov.trace() - cov.trace())) <= 1e-7 * float(cov.trace())
+        cols = slice(None, None, 37)
+        assert float((got.cov[:, cols] - cov[:, cols]).norm() / cov[:, cols].norm()) <= 2e-7
+    # the distance against the f64 PSD evaluation of the definition
+    w, v = torch.linalg.eigh(sx)
+    root = (v * w.clamp_min(0).sqrt()) @ v.T
+    tr_sqrt = torch.linalg.eigvalsh(root @ sy @ root).clamp_min(0).sqrt().sum()
+    exact = float(((mx - my) ** 2).sum() + sx.trace() + sy.trace() - 2.0 * tr_sqrt)
+    scale = float(sx.trace() + sy.trace())
+    assert abs(fad - exact) <= 1e-6 * abs(exact) + 1e-7 * scale, (fad, exact)
+    # FD(sX, sY) = s^2 FD(X, Y)
+    a3, b3 = am.AudioMetricsData(False), am.AudioMetricsData(False)
+    a3.add(cand * 3)
+    b3.add(ref * 3)
+    assert abs(am.frechet_distance(a3, b3) - 9 * fad) <= 1e-5 * 9 * fad
+
+
+def test_million_row_kd(am, million):
+    import oracle
+    ref, cand = million
+    a, b = am.AudioMetricsData(True), am.AudioMetricsData(True)
+    a.add(cand)
+    b.add(ref)
+    got = am.kernel_distance(a, b)                                        # (candidate, reference), audio_metrics.py:260
+    want = oracle.kid_from_features(cand.cpu().numpy(), ref.cpu().numpy())
+    for key, wk in (("kernel_distance_mean", "kernel_distance_mean"), ("kernel_distance_std", "kernel_distance_std")):
+        assert abs(got[key] - want[wk]) <= max(1e-4 * abs(want[wk]), 5e-7), (key, got[key], want[wk])
+
+
+def test_million_row_partitioned_knn_bit_identical(am, million):
+    ops = am.hip_ops
+    x = million[0]
+    nparts = 8
+    assert ops.knn_sym_eligible(N, D, K) and ops.knn_path(N, N, D, K) == 3
+    prep = ops.prepare(x)
+    want = ops.knn_radii(x, K, prepared=prep)
+    bounds = torch.cat([ops.knn_bounds(x, K, lo, hi - lo, prepared=prep) for lo, hi in
+                        [(N * p // nparts, N * (p + 1) // nparts) for p in range(nparts)]])
+    lists = torch.stack([ops.knn_sym_part(x, K, p, nparts, bounds, prepared=prep) for p in range(nparts)])
+    got = ops.knn_lists_finish(lists, x, K)
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))

@@ -156,6 +156,61 @@ def test_incremental_equals_oneshot(am):
     assert c.embeddings.shape == (1101, 8)
 
 
+@pytest.mark.parametrize("d,splits", [(512, [32] * 40), (21, [1, 7, 1, 32, 128, 3]), (128, [128, 5, 64]), (40, [1, 1, 1, 16])])
+def test_one_launch_add_matches_the_chain(am, d, splits):
+    """am_stats_push_f32 (one launch per small add: batch statistics + Chan merge + row append, data.py:37-47, 68-94)
+    against the separate entry points (am_stats_f32 -> am_stats_merge_f64 -> copy) on the same batches, and both against an
+    f64 one-shot evaluation; odd widths, single-row batches, a first batch of one row, unaligned row views."""
+    ops = am.hip_ops
+    x = gi.randn(17, sum(splits), d, 1.3, 0.2)
+    t = dev(x)
+    pushed, chained = am.AudioMetricsData(True), am.AudioMetricsData(True)
+    s = 0
+    for b in splits:
+        e = t[s:s + b]
+        assert b <= ops.stats_push_max_rows()
+        pushed.add(e)                                             # one launch
+        mean, cov = ops.stats(ops.as_matrix(e))                   # the chain, spelled out
+        chained._update_stats(mean, cov, b)
+        chained._update_embeddings(e)
+        s += b
+    assert pushed.n == chained.n == sum(splits)
+    assert torch.equal(pushed.embeddings, t) and torch.equal(chained.embeddings, t)
+    x64 = x.astype(np.float64)
+    want_mean, want_cov = x64.mean(0), np.cov(x64.T)
+    for got in (pushed, chained):
+        np.testing.assert_allclose(got.mean.cpu().numpy(), want_mean, rtol=0, atol=1e-12)
+        assert np.linalg.norm(got.cov.cpu().numpy() - want_cov) <= 3e-7 * np.linalg.norm(want_cov)
+    # the two paths differ only in how the <= 128 products of a batch entry are summed (f64 here, an f32 MFMA chain there)
+    assert float((pushed.cov - chained.cov).norm() / chained.cov.norm()) <= 2e-7
+    # stats-only sets take the same path without touching a store
+    lean = am.AudioMetricsData(False)
+    s = 0
+    for b in splits:
+        lean.add(t[s:s + b])
+        s += b
+    assert lean.embeddings is None and torch.equal(lean.cov, pushed.cov) and torch.equal(lean.mean, pushed.mean)
+
+
+def test_prepared_set_follows_the_stored_rows(am):
+    """The cached PreparedSet (norms, f16 copy) is tied to a content version, not to a pointer: appends, assignments to
+    .embeddings and invalidate_prepared() all force a fresh one."""
+    a = am.AudioMetricsData(True)
+    a.add(dev(gi.randn(3, 300, 24)))
+    p0 = a.prepared()
+    assert a.prepared() is p0
+    a.add(dev(gi.randn(4, 20, 24)))
+    p1 = a.prepared()
+    assert p1 is not p0 and p1.norms.numel() == 320
+    a.embeddings = a.embeddings.clone()
+    assert a.prepared() is not p1
+    p2 = a.prepared()
+    a.embeddings.mul_(2.0)
+    a.invalidate_prepared()
+    p3 = a.prepared()
+    assert p3 is not p2 and torch.allclose(p3.norms, 4.0 * p2.norms, rtol=1e-6)
+
+
 def test_stats_full_size_vs_f64(am):
     rng = np.random.default_rng(5)
     x = (rng.standard_normal((100000, 512)) * 1.05 + 0.05).astype(np.float32)
@@ -179,28 +234,62 @@ def test_strided_and_odd_width_inputs(am):
 
 
 # ----------------------------------------------------------------- FAD / APA
-def fad_tolerance(fad, cov_x, cov_y, n_min):
-    """1e-4 relative, plus - for rank-deficient covariances only - the reference's own
-    noise floor: its f32 torch.cov leaves spurious eigenvalues of either sign up to
-    ~eps32*lambda_max in each null direction and fad.py:30 adds sqrt of the positive ones."""
-    d = cov_x.shape[0]
-    nullity = max(0, d - (n_min - 1))
-    lam = float(np.linalg.norm(cov_x @ cov_y, 2))
-    return REL * abs(fad) + 2.0 * nullity * np.sqrt(EPS32 * lam)
+def fad_exact_f64(ref, cand):
+    """The quantity fad.py:28-31 defines, evaluated in f64 end to end with torch on the host: mean / covariance of the f32
+    inputs in f64, tr sqrt(Sx Sy) through the symmetric PSD form sqrt(Sx) Sy sqrt(Sx) (eigvalsh; negative rounding
+    noise clamped).  No f32 statistics, no general eigensolver: this is what the reference would return without its own
+    rounding noise."""
+    def stats(x):
+        x = torch.as_tensor(x, dtype=torch.float64)
+        mu = x.mean(0)
+        xc = x - mu
+        return mu, xc.T @ xc / max(len(x) - 1, 1)
+    (mx, sx), (my, sy) = stats(cand), stats(ref)
+    w, v = torch.linalg.eigh(sx)
+    root = (v * w.clamp_min(0).sqrt()) @ v.T
+    lam = torch.linalg.eigvalsh(root @ sy @ root)
+    tr_sqrt = lam.clamp_min(0).sqrt().sum()
+    return float(((mx - my) ** 2).sum() + sx.trace() + sy.trace() - 2.0 * tr_sqrt)
+
+
+FAD_EXACT_REL = 1e-6      # device value against the f64 evaluation of the definition ...
+FAD_TERMS_REL = 1e-7      # ... plus the f32 rounding of the centred inputs in the device covariance (DESIGN "Stats numerics":
+                          # 1e-7 relative Frobenius), relative to tr Sx + tr Sy - the terms the distance is a difference of
+
+
+def fad_exact_tol(exact, scale):
+    return FAD_EXACT_REL * abs(exact) + FAD_TERMS_REL * scale
 
 
 @pytest.mark.parametrize("name", list(gi.FAD_CASES))
 def test_fad_vs_golden(am, golden, name):
+    """Two separate statements (N < D included, no widened formula):
+    (1) the device value equals the f64 PSD evaluation of the definition - recomputed here with torch on the same
+        inputs, and the copy make_goldens.py stored - to 1e-6 relative (+ 1e-7 of tr Sx + tr Sy);
+    (2) it agrees with the reference's own output to 1e-4 relative or the reference's MEASURED noise on that case
+        (|reference - f64 evaluation|, stored by make_goldens.py as `ref_noise`: 2.6e-4 relative for the 40-row set,
+        3.6e-4 for 100 CLAP-shaped rows against 4096 - spurious eigenvalues of its f32 torch.cov in the null directions,
+        fad.py:30) plus (1)'s 1e-6, whichever is larger."""
     g = golden("fad")
     kind, seed, nr, nc, d = gi.FAD_CASES[name]
     ref, cand = gi.pair(kind, seed, nr, nc, d)
     a, b = amd_of(am, cand, False), amd_of(am, ref, False)
-    fad = am.frechet_distance(a, b)
-    want = float(g[f"{name}/fad"])
-    tol = fad_tolerance(want, a.cov.cpu().numpy(), b.cov.cpu().numpy(), min(nr, nc))
-    assert abs(fad - want) <= tol, (fad, want, tol)
-    assert abs(am.frechet_distance(b, a) - float(g[f"{name}/fad_swapped"])) <= tol
+    fad, swapped = am.frechet_distance(a, b), am.frechet_distance(b, a)
     assert isinstance(fad, float)
+    exact = fad_exact_f64(ref, cand)
+    scale = float(a.cov.trace() + b.cov.trace())                       # the terms the distance is a difference of
+    # (the stored copy came from numpy's eigh, this one from torch's: on rank-deficient inputs the square roots of their
+    # rounding-noise eigenvalues differ by a few 1e-9 of the terms)
+    assert abs(exact - float(g[f"{name}/fad_exact_f64"])) <= 2e-8 * scale
+    for got in (fad, swapped):
+        assert abs(got - exact) <= fad_exact_tol(exact, scale), (got, exact, scale)
+    noise = float(g[f"{name}/ref_noise"])
+    for got, key in ((fad, "fad"), (swapped, "fad_swapped")):
+        want = float(g[f"{name}/{key}"])
+        tol = max(REL * abs(want), noise + fad_exact_tol(exact, scale))
+        assert abs(got - want) <= tol, (key, got, want, noise)
+    if min(nr, nc) > d:                                                # full rank: the reference itself is exact to ~1e-7
+        assert noise <= 1e-6 * abs(exact), noise
 
 
 def test_fad_properties(am):
@@ -653,3 +742,49 @@ def test_prepared_sets_change_no_bit(am, rows, dim, k):
                             for p in range(nparts)])
         lists = torch.stack([ops.knn_sym_part(x, k, p, nparts, bounds, prepared=px) for p in range(nparts)])
         assert torch.equal(ops.knn_lists_finish(lists, x, k), rx)
+
+
+# ----------------------------------------------------------------- one call = one evaluate()
+@pytest.mark.parametrize("n_ref,n_cand,d,k", [(2600, 2300, 96, 4), (9000, 8800, 128, 5), (300, 500, 24, 3)])
+def test_fused_evaluate_equals_separate_entry_points(am, n_ref, n_cand, d, k):
+    """am_evaluate_f32 (the whole FAD + KD + PRDC chain as one stream-ordered call with one read-back,
+    audio_metrics.py:254-274) against the same entry points called one by one: identical values (same kernels, same
+    order), cold and with the reference side handed in (cached statistics / radii, data.py:60-66)."""
+    from audio_metrics_amd.distributed import evaluate_sharded, evaluate_single
+    ops = am.hip_ops
+    ref, cand = (dev(x) for x in gi.pair("randn", 91, n_ref, n_cand, d))
+    kw = dict(nearest_k=k, kid_subsets=12, kid_subset_size=200)
+    fused = evaluate_sharded(ref, cand, **kw)
+    apart = evaluate_sharded(ref, cand, fused=False, **kw)
+    assert list(fused) == ["fad", "kernel_distance_mean", "kernel_distance_std", "precision", "recall", "density", "coverage"]
+    for key in fused:
+        if key == "fad":        # (one-shot covariance here, column sums + centred scatter there: the same kernels, one more division)
+            assert abs(fused[key] - apart[key]) <= 1e-9 * abs(apart[key]), key
+        else:
+            assert fused[key] == apart[key], key
+    for metrics in (("fad", "kd"), ("prdc",), ("kd",), ("fad",)):
+        part = evaluate_sharded(ref, cand, metrics=metrics, **kw)
+        assert part == {key: fused[key] for key in part}, metrics
+    # warm: the reference side's statistics and radii come from the object, the candidate's are written into tensors
+    a, b = am.AudioMetricsData(True), am.AudioMetricsData(True)
+    a.add(cand)
+    b.add(ref)
+    r_out = torch.empty(n_cand, dtype=torch.float32, device=cand.device)
+    warm = evaluate_single(ref, cand, ("fad", "kd", "prdc"), k, ops, 12, 200,
+                           given_ref={"mean": b.mean, "cov": b.cov, "radii": b.get_radii(k)},
+                           given_cand={"mean": a.mean, "cov": a.cov, "radii_out": r_out})
+    assert torch.equal(r_out, a.get_radii(k))
+    want = {"fad": am.frechet_distance(a, b)}
+    want.update(am.kid_features_to_metric(cand, ref, kid_subsets=12, kid_subset_size=200))
+    want.update(am.prdc(b, a, k))
+    assert warm == want
+
+
+def test_fused_evaluate_finishes_an_ill_conditioned_frechet_solve(am):
+    """A covariance product that needs more Newton-Schulz iterations than am_evaluate_f32 enqueues (stop code 0) is finished
+    by the stand-alone solver on the statistics the chain wrote: same value as frechet_distance()."""
+    from audio_metrics_amd.distributed import evaluate_sharded
+    ref, cand = (dev(x) for x in gi.pair("decay", 24, 2000, 2000, 128))
+    got = evaluate_sharded(ref, cand, metrics=("fad", "kd"), kid_subsets=4, kid_subset_size=100)
+    a, b = amd_of(am, cand.cpu().numpy(), False), amd_of(am, ref.cpu().numpy(), False)
+    assert abs(got["fad"] - am.frechet_distance(a, b)) <= 1e-9 * abs(got["fad"])

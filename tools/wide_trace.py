@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where does a stage of the wide f16 filter kernels spend its cycles?  (A/B build only: AM_HIP_LIBRARY=dev.)
 Runs one membership-filter call (AB_WHICH=cross) or one k-NN sweep (AB_WHICH=knn) with AM_WIDE_TRACE=1 and averages the
-s_memtime stamps of waves 0 / 4 of the first 64 workgroups:
+s_memtime stamps of waves 0 / 4 of 64 workgroups (AM_WIDE_TRACE_B0 = the first of them; the k-NN sweep runs its windows in
+descending order, so a later block offset shows the epilogues under tighter bounds):
   0 stage start  1 after 8 MFMA + 4 DMA pieces  2 after 16 MFMA + 8 pieces  3 after 32 MFMA  4 after the epilogue
   5 after s_waitcnt vmcnt(0)   (next 0: after the barrier)"""
 import ctypes
@@ -44,3 +45,7 @@ for wv in (0, 1):
             continue
         parts = [float(s[sel].mean()) for s in seg]
         print(f"wave {wv * 4} {label:26s} total {sum(parts):7.0f} cycles: " + "  ".join(f"{nm} {p:6.0f}" for nm, p in zip(names, parts)))
+        if "last" in label:                                    # the tile epilogue: this wave's own time, and until the barrier lets go
+            own, held = seg[3][sel], (seg[3] + seg[4] + seg[5])[sel]
+            q = lambda a: " / ".join(f"{int(np.percentile(a, p))}" for p in (10, 50, 90, 100))
+            print(f"       epilogue p10/p50/p90/max {q(own)}   epilogue + wait + barrier {q(held)}   ({int(sel.sum())} tiles, b0={os.environ.get('AM_WIDE_TRACE_B0', '0')})")
