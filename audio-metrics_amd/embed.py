@@ -15,8 +15,12 @@ organised as three stages:
                       the host and re-concatenates the stored matrix, embed.py:226-236).  The per-GPU partial
                       statistics are merged at the end (Chan merge across devices = SURVEY 8(e)'s reduction).
 """
+import os
 import queue
 import threading
+import time
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
 from enum import IntEnum
 from itertools import tee
 
@@ -25,6 +29,48 @@ import torch
 
 from .data import AudioMetricsData, ensure_ndarray
 from .util import multi_audio_slicer, shuffle_stream
+
+# Optional stage clock (bench.py --config e2e): a dict that the stages below add their seconds to -
+#   mix_wait  the consumer waiting for mixed windows      mix_cpu  summed worker time inside the mix functions
+#   batch     filling the [batch, n_samples] host arrays  forward  embedder forward (incl. its host-to-device copy)
+#   file      routing rows into the per-category sets (enqueue time; the kernels run asynchronously)
+PROFILE = None
+
+
+def _tick(key, t0):
+    if PROFILE is not None:
+        PROFILE[key] = PROFILE.get(key, 0.0) + (time.perf_counter() - t0)
+
+
+def default_mix_workers():
+    """Host threads of the mix stage.  The reference uses 64 (embed.py:190-201); numpy releases the GIL inside the array
+    loops the mixers consist of, so the stage scales until the cores run out."""
+    return max(1, min(32, os.cpu_count() or 1))
+
+
+def ordered_map(fn, items, workers, lookahead):
+    """fn(item) for every item on a thread pool, results IN INPUT ORDER, at most `lookahead` items in flight.  (The
+    reference's cpu_parallel yields in completion order, util/cpu_parallel.py:26-62; keeping the order makes the stored
+    rows - and with them KD / PRDC - reproducible.)  An exception raised by fn surfaces at its item's position."""
+    if workers <= 1:
+        for item in items:
+            yield fn(item)
+        return
+    with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="am-mix") as pool:
+        pending = deque()
+        for item in items:
+            pending.append(pool.submit(fn, item))
+            if len(pending) >= lookahead:
+                t0 = time.perf_counter()
+                result = pending.popleft().result()
+                _tick("mix_wait", t0)
+                yield result
+        while pending:
+            t0 = time.perf_counter()
+            result = pending.popleft().result()
+            _tick("mix_wait", t0)
+            yield result
+
 
 APA_SHAPE_MESSAGE = ("When computing APA items should be tensors/arrays of shape [n_samples, 2] "
                      "(pairing context and stem)")
@@ -54,8 +100,9 @@ class WindowSource:
     """Iterable of ``(ItemCategory, mono window)`` for one ``add_reference`` / ``evaluate`` call."""
 
     def __init__(self, waveforms, sr, win_dur, mix_function, apa_mode=None, stems_mode=False, input_sr=None,
-                 song_buffer_size=100, win_buffer_size=1000, win_min_age=100, seed=None):
+                 song_buffer_size=100, win_buffer_size=1000, win_min_age=100, seed=None, mix_workers=None):
         self.waveforms, self.sr, self.win_dur = waveforms, sr, win_dur
+        self.mix_workers = default_mix_workers() if mix_workers is None else int(mix_workers)
         self.mix_function = mix_function
         self.apa_mode, self.stems_mode = apa_mode, stems_mode
         self.input_sr = input_sr
@@ -70,9 +117,11 @@ class WindowSource:
             songs = (resample(song, self.input_sr, self.sr) for song in songs)
         return multi_audio_slicer(songs, self.win_dur, sr=self.sr)
 
-    def __iter__(self):
+    def _jobs(self):
+        """(category, window, partner) in emission order.  Everything that draws from `random` - the song shuffle and the
+        partner shuffle - happens HERE, on the consuming thread, one window after the other, exactly as in a serial run;
+        only the arithmetic on the windows goes to the pool."""
         windows = self._windows()
-        want_pairs = self.apa_mode is not None
         if self.apa_mode == "reference":
             # a second view of the same window stream, delayed and shuffled, supplies the stems of the misaligned pairs
             windows, delayed = tee(windows)
@@ -81,32 +130,80 @@ class WindowSource:
             stream = zip(windows, partners)
         else:
             stream = ((w, None) for w in windows)
+        want_pairs = self.apa_mode is not None
         for window, partner in stream:
             window = ensure_ndarray(window)
             if want_pairs:
                 if window.ndim != 2:
                     raise ValueError(APA_SHAPE_MESSAGE)
-                yield ItemCategory.aligned, self.mix_function(window, sr=self.sr)
+                yield ItemCategory.aligned, window, None
                 if partner is not None:
                     partner = ensure_ndarray(partner)
                     assert partner.ndim == 2, APA_SHAPE_MESSAGE
-                    crossed = np.column_stack((window[:, 0], partner[:, 1]))      # this context, another window's stem
-                    yield ItemCategory.misaligned, self.mix_function(crossed, sr=self.sr)
+                    yield ItemCategory.misaligned, window, partner
             if self.stems_mode:
-                yield ItemCategory.stem, (window[:, -1] if window.ndim == 2 else window)
+                yield ItemCategory.stem, window, None
+
+    def _render(self, job):
+        category, window, partner = job
+        if category == ItemCategory.stem:
+            return category, (window[:, -1] if window.ndim == 2 else window)
+        t0 = time.perf_counter()
+        if partner is not None:
+            window = np.column_stack((window[:, 0], partner[:, 1]))               # this context, another window's stem
+        mixed = self.mix_function(window, sr=self.sr)
+        _tick("mix_cpu", t0)
+        return category, mixed
+
+    def __iter__(self):
+        if self.apa_mode is None:                                                  # stems only: nothing to compute
+            return (self._render(job) for job in self._jobs())
+        return ordered_map(self._render, self._jobs(), self.mix_workers, lookahead=2 * self.mix_workers + 2)
 
 
-def batches_of(tagged_windows, batch_size=32):
-    """Embedder-protocol batches {"audio": [b, n], "category": [b]} of consecutive windows."""
-    tags, audio = [], []
+def batches_of(tagged_windows, batch_size=32, ring=0, guards=None):
+    """Embedder-protocol batches {"audio": [b, n], "category": [b]} of consecutive windows.
+    ring = 0: every batch owns a fresh array.  ring = R > 0: the audio arrays are R buffers used in turn - a 32 x 240000
+    f32 batch is 30 MB, and a fresh allocation of that size is returned to the OS on free and page-faulted in again on the
+    next one (measured: 117 ms per np.stack against 4 ms for the copies) - valid as long as no more than R - 1 batches
+    are held downstream at a time (EmbedderPool sizes it from its queue depth).  A ring batch carries its buffer index
+    as batch["_slot"]; a consumer whose device copy of the audio may still be in flight when its forward returns puts an
+    event into guards[slot], and the buffer is not refilled before that event has completed."""
+    buffers, turn = [], 0
+    tags, rows = [], []
+
+    def emit():
+        nonlocal turn
+        t0 = time.perf_counter()
+        first = rows[0]
+        uniform = all(r.shape == first.shape and r.dtype == first.dtype for r in rows)
+        if ring > 0 and uniform and first.ndim == 1:
+            if len(buffers) < ring:
+                buffers.append(np.empty((batch_size, first.shape[0]), dtype=first.dtype))
+            slot = turn % len(buffers)
+            turn += 1
+            guard = guards.pop(slot, None) if guards is not None else None
+            if guard is not None:
+                guard.synchronize()
+            buf = buffers[slot]
+            if buf.shape[1] != first.shape[0] or buf.dtype != first.dtype:
+                buf = buffers[slot] = np.empty((batch_size, first.shape[0]), dtype=first.dtype)
+            for i, r in enumerate(rows):
+                buf[i] = r
+            batch = {"audio": buf[:len(rows)], "category": np.array(tags), "_slot": slot}
+        else:
+            batch = {"audio": np.stack(rows), "category": np.array(tags)}
+        _tick("batch", t0)
+        return batch
+
     for tag, samples in tagged_windows:
         tags.append(int(tag))
-        audio.append(samples)
+        rows.append(samples)
         if len(tags) == batch_size:
-            yield {"audio": np.stack(audio), "category": np.array(tags)}
-            tags, audio = [], []
+            yield emit()
+            tags, rows = [], []
     if tags:
-        yield {"audio": np.stack(audio), "category": np.array(tags)}
+        yield emit()
 
 
 class CategoryAggregator:
@@ -165,6 +262,24 @@ class EmbedderPool:
             raise RuntimeError("No GPUs found, cannot compute audio metrics")
         self.devices = [torch.device(d) for d in devices]
         self.replicas = [_replica(embedder, d) for d in self.devices]
+        self.guards = {}                                             # batch-ring slot -> event behind its last device copy
+
+    QUEUE_DEPTH = 4                                                   # batches queued per GPU ahead of its worker
+
+    def batches_in_flight(self):
+        """How many batches can be alive downstream of the batch generator at once (ring size for batches_of)."""
+        if len(self.devices) == 1:
+            return 2
+        return len(self.devices) * (self.QUEUE_DEPTH + 1) + 2
+
+    def _consumed(self, batch, device):
+        """The embedder's host-to-device copy of batch["audio"] is stream-ordered on `device`: an event behind it tells
+        the batch ring when the host buffer may be refilled."""
+        slot = batch.get("_slot")
+        if slot is not None and self.guards is not None:
+            event = torch.cuda.Event()
+            event.record(torch.cuda.current_stream(device))
+            self.guards[slot] = event
 
     def run(self, batches, wanted):
         """-> {ItemCategory: AudioMetricsData} on devices[0]."""
@@ -172,14 +287,19 @@ class EmbedderPool:
         if len(self.devices) == 1:
             with torch.cuda.device(self.devices[0]):
                 for batch in batches:
-                    aggregators[0].file(self.replicas[0].forward(batch)["embedding"], batch["category"])
+                    t0 = time.perf_counter()
+                    embedding = self.replicas[0].forward(batch)["embedding"]
+                    self._consumed(batch, self.devices[0])
+                    _tick("forward", t0)
+                    t0 = time.perf_counter()
+                    aggregators[0].file(embedding, batch["category"])
+                    _tick("file", t0)
             return aggregators[0].data
         self._run_threads(batches, aggregators)
         return merge_across_devices([a.data for a in aggregators], self.devices[0])
 
     def _run_threads(self, batches, aggregators):
-        depth = 4                                                 # batches queued per GPU ahead of its worker
-        inboxes = [queue.Queue(maxsize=depth) for _ in self.devices]
+        inboxes = [queue.Queue(maxsize=self.QUEUE_DEPTH) for _ in self.devices]
         failures = []
 
         def worker(slot):
@@ -191,7 +311,9 @@ class EmbedderPool:
                             return
                         if failures:
                             continue                                # drain so the dealer never blocks
-                        aggregators[slot].file(self.replicas[slot].forward(batch)["embedding"], batch["category"])
+                        embedding = self.replicas[slot].forward(batch)["embedding"]
+                        self._consumed(batch, self.devices[slot])
+                        aggregators[slot].file(embedding, batch["category"])
             except BaseException as e:                              # surfaced by the dealer below
                 failures.append(e)
                 while inboxes[slot].get() is not None:
@@ -229,7 +351,7 @@ def merge_across_devices(per_device, target):
 def embedding_pipeline(waveforms, embedder, mix_function, gpu_handler=None, apa_mode=None, stems_mode=False,
                        store_mix_embeddings=False, store_stem_embeddings=False, batch_size=32, win_dur=5.0,
                        song_buffer_size=100, win_buffer_size=1000, win_min_age=100, seed=None, input_sr=None,
-                       device=None):
+                       device=None, mix_workers=None):
     """{ItemCategory: AudioMetricsData} with device-resident statistics (signature of embed.py:93-109).
 
     `waveforms`: array/tensor (batch, n_samples[, 2]) or any iterable of (n_samples[, 2]) arrays.
@@ -237,7 +359,7 @@ def embedding_pipeline(waveforms, embedder, mix_function, gpu_handler=None, apa_
     one the embedder runs where it lives and the statistics are kept on `device`."""
     source = WindowSource(waveforms, embedder.sr, win_dur, mix_function, apa_mode=apa_mode, stems_mode=stems_mode,
                           input_sr=input_sr, song_buffer_size=song_buffer_size, win_buffer_size=win_buffer_size,
-                          win_min_age=win_min_age, seed=seed)
+                          win_min_age=win_min_age, seed=seed, mix_workers=mix_workers)
     wanted = {}
     if apa_mode is not None:
         wanted[ItemCategory.aligned] = store_mix_embeddings
@@ -252,4 +374,5 @@ def embedding_pipeline(waveforms, embedder, mix_function, gpu_handler=None, apa_
             home = embedder.get_device()
             device = home if home.type == "cuda" else default_device()
         pool = EmbedderPool(embedder, [device])
-    return pool.run(batches_of(source, batch_size), wanted)
+    pool.guards = {}
+    return pool.run(batches_of(source, batch_size, ring=pool.batches_in_flight() + 1, guards=pool.guards), wanted)

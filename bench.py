@@ -466,6 +466,8 @@ def run_e2e(args, am, dev, world, rank, fence):
             clock["forward"] += time.perf_counter() - t0
             return out
 
+    from audio_metrics_amd import embed as am_embed
+    am_embed.PROFILE = stage = {}                      # stage clock of the front end (embed.py)
     embedder = Timed(dim=512, sr=sr, device=dev)
     group = dist.group.WORLD if world > 1 else None
     metric = am.AudioMetrics(metrics=["apa", "fad"], embedder=embedder, mix_function="P0", device_indices=[dev.index],
@@ -490,10 +492,13 @@ def run_e2e(args, am, dev, world, rank, fence):
     result = metric.evaluate(timed_source(hi - lo))
     fence()
     elapsed = time.perf_counter() - t0
+    stages = ("mix_wait", "mix_cpu", "batch", "forward", "file")
     if world > 1:
-        t = torch.tensor([elapsed, clock["forward"], host["t"]], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, clock["forward"], host["t"]] + [stage.get(key, 0.0) for key in stages], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, fwd, synth = (float(v) for v in t.tolist())
+        vals = [float(v) for v in t.tolist()]
+        elapsed, fwd, synth = vals[:3]
+        stage = dict(zip(stages, vals[3:]))
     else:
         fwd, synth = clock["forward"], host["t"]
     if rank == 0:
@@ -507,8 +512,18 @@ def run_e2e(args, am, dev, world, rank, fence):
                                    "randn audio at 48 kHz (BASELINE.json configs[4] shape, reduced pair count), "
                                    "SyntheticEmbedder (NOT CLAP: laion_clap and its checkpoint are not installable here)",
                        "pairs_per_side": pairs, "sharding": f"pairs/{world}", "mix_function": "P0"},
-            "breakdown_s": {"total": elapsed, "embedder_forward": fwd, "host_audio_synthesis": synth,
-                            "mix_batch_aggregate_metrics": elapsed - fwd - synth},
+            "breakdown_s": {
+                "total": elapsed, "host_audio_synthesis": synth,
+                "host_mix_wait": stage.get("mix_wait", 0.0),                      # the consumer waiting for mixed windows
+                "host_mix_cpu_summed_over_threads": stage.get("mix_cpu", 0.0),
+                "host_batch_fill": stage.get("batch", 0.0),
+                "embedder_forward_incl_h2d": fwd,
+                "device_aggregate_enqueue": stage.get("file", 0.0),
+                "metrics_and_rest": elapsed - synth - stage.get("mix_wait", 0.0) - stage.get("batch", 0.0)
+                                    - stage.get("forward", fwd) - stage.get("file", 0.0),
+                "mix_workers": am_embed.default_mix_workers(),
+                "note": ("single consumer thread: host_mix_wait + host_batch_fill + embedder_forward + device_aggregate_enqueue + "
+                         "metrics_and_rest + host_audio_synthesis = total; the mix functions themselves run on the worker threads")},
             "result": result}), flush=True)
 
 
