@@ -281,7 +281,7 @@ class AudioMetrics:
             n_ref, n_cand = self._global_count(sets.stem_ref), self._global_count(sets.stem_cand)
             k = max(1, min(MAX_NEAREST_K, n_ref, n_cand))
             result.update(distributed.evaluate_sharded(
-                distributed.local_rows(sets.stem_ref), distributed.local_rows(sets.stem_cand),
+                distributed.local_rows(sets.stem_ref, group), distributed.local_rows(sets.stem_cand, group),
                 metrics=rows, nearest_k=k, group=group))
         if self.need_apa:
             cand, ref, anti = (distributed.merged_stats(d, group) for d in (sets.mix_cand, sets.mix_ref, sets.mix_anti))

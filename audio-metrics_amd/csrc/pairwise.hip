@@ -973,6 +973,7 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
     const double expect = (double)p.tile_rows * p.tile_rows * p.win_tiles * (double)(k + 1) * stride / (double)N;
     static const int qcap_env = env_int("AM_KNN_SYM_QCAP", 0);
     p.qcap = qcap_env > 0 ? qcap_env : (int)std::min(32768.0, std::max(256.0, 8.0 * expect));   // (the f16 filter path queues both directions)
+    p.qcap = (p.qcap + 7) / 8 * 8;                     // the f16 filter sweeps split a region evenly among their 4 / 8 waves
     return p;
 }
 
@@ -997,7 +998,7 @@ static size_t carve_knn(Carver& c, int64_t N, int64_t M, const KnnPlan& p, KnnBu
         b.ov_count = b.cnt ? b.cnt + N : nullptr;
         const size_t nwg = (size_t)p.nwg;
         b.wgq = c.take<uint2>(nwg * p.qcap);
-        b.wgq_count = c.take<int>(nwg);
+        b.wgq_count = c.take<int>(nwg * 8);        // the f16 filter sweeps count per wave (up to eight sub-regions per workgroup)
     } else {
         b.thr = b.cand = nullptr;
         b.cnt = b.ov_list = b.ov_count = b.wgq_count = nullptr;

@@ -136,16 +136,23 @@ constexpr int FAST_ROW_OVERFLOW = 0x40000000;                                 //
 constexpr unsigned FAST_HOLE = 0xffffffffu;                                  // pair-list slot left unwritten (list full)
 
 // Lane / TBX / MT: geometry of the engine underneath - LaneInfo, 128, 2 (tile_engine.h) or WLane, 256, 4 (wide_engine.h)
+//
+// Queue protocol (round 3).  Every WAVE owns a sub-region of its workgroup's queue region (`wcap` entries at
+// wgq + (blockIdx * NWAVES + wave) * wcap) and counts its entries in a scalar register: the tests that select an entry are
+// wave-wide anyway (ballots), so a slot is `count + (number of selected lanes below this one)` - no LDS atomic, no
+// round trip in the epilogue's critical path.  (Round 2 reserved slots with one returning LDS atomic per lane and
+// accumulator tile, and looked at every register of a hit group twice: once for the bit masks, once to store.)
 template <int KCAP, class Lane = LaneInfo, int TBX = TB, int MT = 2>
 struct KnnFastEpilogue {
+    static constexpr int NWAVES = TBX == WIDE_TILE_ROWS ? 8 : 4;   // waves per workgroup
     const float* qnorm;
     const float* thr;
     int64_t n, pblock;
     float* aux;                 // LDS [2][2][TBX] : |x_j|^2 and thr[j] of the tile
-    uint2* wgq;
+    uint2* wgq;                 // this WAVE's sub-region
     float* wgv;                 // approximate value of each queued pair (pruning, knn_fast_prune_kernel)
-    int* qn;
-    int qcap;
+    int wq;                     // entries this wave has queued (wave-uniform, lives in a scalar register)
+    int wcap;                   // capacity of the sub-region
     uint2* ovq;                 // global spill queue for entries that do not fit their region
     float* ovv;
     unsigned long long* ovn;
@@ -161,11 +168,8 @@ struct KnnFastEpilogue {
     const Lane& L;
 
     __device__ __forceinline__ KnnFastEpilogue(const Lane& l) : L(l) {}
-    // entry into slot `slot` of this workgroup's region (slots are reserved per lane and accumulator tile by ONE LDS
-    // atomic in finish(): a returning atomic per entry - 16 dependent LDS round trips per tile group while the bounds are
-    // still loose - was the critical path of the epilogue: 34 000 of 68 000 cycles per tile in the first windows)
     __device__ __forceinline__ void store_entry(int slot, unsigned a, unsigned b, bool both, float val) {
-        if (slot < qcap) {
+        if (slot < wcap) {
             wgq[slot] = make_uint2(a | (both ? FAST_BOTH : 0u), b);
             wgv[slot] = val;
         } else {
@@ -236,59 +240,41 @@ struct KnnFastEpilogue {
                     marg4[g4] = mg + xn[nt];
                 }
                 const float tmin = fminf(fminf(tmin4[0], tmin4[1]), fminf(tmin4[2], tmin4[3]));
+                const float mmin = fminf(fminf(marg4[0], marg4[1]), fminf(marg4[2], marg4[3]));
                 // the own-row bound is frozen for the 16 elements of this accumulator tile (a looser filter is always
                 // safe); the list - and with it the bound of the next tile - is updated behind the stores
                 const float pl = fminf(flt[nt], best[nt][KCAP - 1] + fmaf(e2c, xn[nt], e2n));
-                bool hit[4];
+                // Gate 1, one wave-uniform branch per accumulator tile (1024 pairs): nothing to look at.  (Round 2 evaluated
+                // the four group gates of every tile and kept their outcomes as values for two later loops: ~100 VALU
+                // instructions per accumulator tile of which ~50 were flag bookkeeping.)
+                if (!__any(tmin <= pl || (mirror && mmin <= 0.f))) continue;
+                // Gate 2 per register group, then ONE pass over the group's four registers: test, ballot, slot, store.
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) hit[g4] = __any(tmin4[g4] <= pl || (mirror && marg4[g4] <= 0.f));     // wave-uniform
-                if (hit[0] || hit[1] || hit[2] || hit[3]) {
-                    // the element-wise tests only for the register groups that have a candidate at all
-                    unsigned own_bits = 0u, mir_bits = 0u;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    if (!__any(tmin4[g4] <= pl || (mirror && marg4[g4] <= 0.f))) continue;
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        if (!hit[g4]) continue;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int reg = g4 * 4 + e;
-                            const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[g4][e]);
-                            own_bits |= (u <= pl) ? (1u << reg) : 0u;
-                            mir_bits |= (mirror && u <= tq[g4][e]) ? (1u << reg) : 0u;
-                        }
-                    }
-                    const unsigned any_bits = own_bits | mir_bits;
-                    // The lane-local list only steers the filter (its (k+1)-th smallest bounds the row's final value from
-                    // above).  It takes ONE value per accumulator tile - the smallest of the sixteen - instead of every
-                    // queued one: a list over a subset of the row's values still bounds from above, two of a row's k+1
-                    // nearest neighbours practically never share a tile, and sixteen conditional insertions per tile were
-                    // a large part of the epilogue while the bounds are loose.
-                    const float vmin = tmin <= pl ? fmaxf(tmin, 0.f) : INFINITY;
-                    if (__any(vmin < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], vmin);
-                    // Queue slots: ONE LDS atomic per lane and accumulator tile reserves them (a returning atomic per
-                    // entry - sixteen dependent LDS round trips per tile - was the epilogue's critical path).  (Compacting
-                    // the entries of a register across the lanes with ballots so that the stores coalesce was measured
-                    // too: the sixteen extra ballots cost more than the scattered stores, 6.7 -> 7.4 ms per launch.)
-                    const int count = __popc(any_bits);
-                    int base = 0;
-                    if (count > 0) base = atomicAdd(qn, count);
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        if (!hit[g4]) continue;                                           // (no bits outside the groups that were looked at)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int reg = g4 * 4 + e;
-                            const unsigned bit = 1u << reg;
-                            if (__any((any_bits & bit) != 0u)) {                          // wave-uniform
-                                const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[g4][e]);
-                                const unsigned j = jbase + mt * 32 + g4 * 8 + e;
-                                const bool own = (own_bits & bit) != 0u, mir = (mir_bits & bit) != 0u;
-                                // filed under its own row, or (mirrored only) under row j
-                                if (own || mir)
-                                    store_entry(base + __popc(any_bits & (bit - 1u)), own ? prow[nt] : j, own ? j : prow[nt], own && mir, u);
-                            }
+                    for (int e = 0; e < 4; ++e) {
+                        const int reg = g4 * 4 + e;
+                        const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[g4][e]);
+                        const bool own = u <= pl, mir = mirror && u <= tq[g4][e];
+                        const unsigned long long sel = __ballot(own || mir);
+                        if (sel != 0ull) {                                                  // wave-uniform
+                            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(sel >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sel, 0u));
+                            const int slot = wq + below;
+                            wq += __popcll(sel);
+                            const unsigned j = jbase + mt * 32 + g4 * 8 + e;
+                            // filed under its own row, or (mirrored only) under row j
+                            if (own || mir) store_entry(slot, own ? prow[nt] : j, own ? j : prow[nt], own && mir, u);
                         }
                     }
                 }
+                // The lane-local list only steers the filter (its (k+1)-th smallest bounds the row's final value from
+                // above).  It takes ONE value per accumulator tile - the smallest of the sixteen - instead of every
+                // queued one: a list over a subset of the row's values still bounds from above, two of a row's k+1
+                // nearest neighbours practically never share a tile, and sixteen conditional insertions per tile were
+                // a large part of the epilogue while the bounds are loose.
+                const float vmin = tmin <= pl ? fmaxf(tmin, 0.f) : INFINITY;
+                if (__any(vmin < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], vmin);
             }
         }
     }

@@ -818,8 +818,9 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     const LaneInfo L;
     const int64_t T = (N + TB - 1) / TB;
     const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
+    constexpr int NW = KnnFastEpilogue<KCAP>::NWAVES;
     if (sw.ntiles == 0) {
-        if (L.tid == 0) wgq_count[blockIdx.x] = 0;
+        if (L.tid < NW) wgq_count[(int64_t)blockIdx.x * NW + L.tid] = 0;
         return;
     }
     const float nmax = __uint_as_float(maxn[0]);
@@ -829,10 +830,11 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     epi.n = N;
     epi.pblock = sw.pb;
     epi.aux = lds + ENGINE_LDS_FLOATS;
-    epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
-    epi.wgv = wgv + (int64_t)blockIdx.x * qcap;
-    epi.qn = reinterpret_cast<int*>(lds + ENGINE_LDS_FLOATS + 4 * TB);
-    epi.qcap = qcap;
+    const int wave = __builtin_amdgcn_readfirstlane(L.tid >> 6);
+    epi.wcap = qcap / NW;                             // every wave owns a quarter of the workgroup's region
+    epi.wgq = wgq + ((int64_t)blockIdx.x * NW + wave) * epi.wcap;
+    epi.wgv = wgv + ((int64_t)blockIdx.x * NW + wave) * epi.wcap;
+    epi.wq = 0;
     epi.ovq = ovq;
     epi.ovv = ovv;
     epi.ovn = ovn;
@@ -840,7 +842,6 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     epi.cnt = cnt;
     epi.cap = cap;
     epi.dsc = half_unscale(maxn[2], maxn[2]);
-    if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int64_t i = sw.pb * TB + L.wn * 64 + nt * 32 + L.r;
@@ -861,7 +862,7 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
         for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
     }
     __syncthreads();
-    if (L.tid == 0) wgq_count[blockIdx.x] = min(*epi.qn, qcap);
+    if (L.lane == 0) wgq_count[(int64_t)blockIdx.x * NW + wave] = min(epi.wq, epi.wcap);
     if (L.tid < TB) {
         const int64_t i = sw.pb * TB + L.tid;
         if (i < N) {
@@ -1195,7 +1196,10 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     {
         AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_fast_kernel<KCAP>), (int)PAIRWISE_LDS_BYTES + 16));
     }
-    const int qcap = p.qcap;
+    const int qcap = p.qcap;                                               // per workgroup; every wave owns qcap / nsub of it
+    const int nsub = p.tile_rows == WIDE_TILE_ROWS ? 8 : 4;                  // KnnFastEpilogue::NWAVES of the engine that runs
+    const int wcap = qcap / nsub;
+    const unsigned nreg = nwg * (unsigned)nsub;                             // queue sub-regions in all
     static const int ovcap = std::max(0, std::min(env_int("AM_KNN_FAST_OVCAP", KNN_FAST_OVCAP), KNN_FAST_OVCAP));   // (tests shrink it)
     clock_begin(AM_KERNEL_KNN, st);
     if (p.tile_rows == WIDE_TILE_ROWS) {
@@ -1212,7 +1216,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     AM_LAUNCH_CHECK();
     // 3) approximate values filed by row, 4) pruned against the row's own (k+1)-th smallest, 5) exact values of the
     //    survivors, 6) selection, 7) exact fix-up of overflowed rows
-    hipLaunchKernelGGL(knn_fast_scatter_kernel, dim3(nwg), dim3(256), 0, st, b.wgq, f.wgv, qcap, b.wgq_count, b.cand, f.fidx, b.cnt,
+    hipLaunchKernelGGL(knn_fast_scatter_kernel, dim3(nreg), dim3(256), 0, st, b.wgq, f.wgv, wcap, b.wgq_count, b.cand, f.fidx, b.cnt,
                        p.cap, thr);
     hipLaunchKernelGGL(knn_fast_scatter_spill_kernel, dim3(256), dim3(256), 0, st, f.ovq, f.ovv, f.ovn, ovcap, b.cand, f.fidx,
                        b.cnt, p.cap, thr);
@@ -1239,7 +1243,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
         AM_LAUNCH_CHECK();
     }
     if (long long* stats = filter_stats_for_current_device()) {
-        hipLaunchKernelGGL(filter_stats_kernel, dim3(1), dim3(256), 0, st, b.wgq_count, (int64_t)nwg, stats, 0, 1,
+        hipLaunchKernelGGL(filter_stats_kernel, dim3(1), dim3(256), 0, st, b.wgq_count, (int64_t)nreg, stats, 0, 1,
                            (const unsigned long long*)f.ovn, (const int*)nullptr, ovcap, 2, (const int*)f.pair_count, 3,
                            out_lists == nullptr ? (const int*)b.ov_count : (const int*)nullptr, 4);
         AM_LAUNCH_CHECK();
@@ -1248,15 +1252,15 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     static const int debug = env_int("AM_FAST_DEBUG", 0);
     if (debug) {                                       // development aid: synchronises
         AM_HIP_TRY(hipStreamSynchronize(st));
-        std::vector<int> wc(nwg), cn(N + 1), c2(N + 2);
-        AM_HIP_TRY(hipMemcpy(wc.data(), b.wgq_count, nwg * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<int> wc(nreg), cn(N + 1), c2(N + 2);
+        AM_HIP_TRY(hipMemcpy(wc.data(), b.wgq_count, nreg * sizeof(int), hipMemcpyDeviceToHost));
         AM_HIP_TRY(hipMemcpy(cn.data(), b.cnt, (N + 1) * sizeof(int), hipMemcpyDeviceToHost));
         AM_HIP_TRY(hipMemcpy(c2.data(), f.cnt2, (N + 2) * sizeof(int), hipMemcpyDeviceToHost));
         long long tot = 0, full = 0, ctot = 0, bad = 0;
         int wmax = 0, cmax = 0;
         unsigned long long spilled = 0;
         AM_HIP_TRY(hipMemcpy(&spilled, f.ovn, sizeof(spilled), hipMemcpyDeviceToHost));
-        for (int v : wc) { tot += v; full += (v >= qcap); wmax = std::max(wmax, v); }
+        for (int v : wc) { tot += v; full += (v >= wcap); wmax = std::max(wmax, v); }
         for (int64_t i = 0; i < N; ++i) { ctot += std::min(cn[i], p.cap); cmax = std::max(cmax, cn[i]); bad += c2[i] > p.cap; }
         fprintf(stderr, "[knn_fast] wgs=%u nwin=%d qcap=%d queued=%lld (max/wg %d, full regions %lld) filed=%lld max/row=%d "
                         "pairs verified=%d spilled=%llu rows to fix-up=%lld\n", nwg, p.nwin, qcap, tot, wmax, full, ctot, cmax, c2[N], spilled, bad);

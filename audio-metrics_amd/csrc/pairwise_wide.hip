@@ -130,13 +130,20 @@ struct CrossWideEpilogue {
                     tmin4[g4] = tm + xn[nt];
                     if constexpr (NEED_ANY) marg4[g4] = mg + xn[nt];
                 }
-                if constexpr (WANT_MIN) m[nt] = fminf(m[nt], fmaxf(fminf(fminf(tmin4[0], tmin4[1]), fminf(tmin4[2], tmin4[3])), 0.f));
+                const float tmin = fminf(fminf(tmin4[0], tmin4[1]), fminf(tmin4[2], tmin4[3]));
+                if constexpr (WANT_MIN) m[nt] = fminf(m[nt], fmaxf(tmin, 0.f));
                 const float prow_thr = WANT_MIN ? fmaxf(thi[nt], m[nt] + e2[nt]) : thi[nt];
-                // Detail path, per register group and direction, behind wave-uniform gates.  The row direction (column counts,
-                // coverage, row minimum) has a candidate in 0.2 % of the 32 x 32 tiles of the bench problem; the "any" direction
-                // of the rows that still lack a witness in 16 % (candidate radii are wider than a reference row's own test) -
-                // those groups run without ballots and counts.  (One loop with switches, not two loops: a second unrolled copy
-                // pushes the epilogue over the compiler's unroll budget and the accumulator array into scratch.)
+                // Gate 1, one wave-uniform branch per accumulator tile (1024 pairs).  The row direction (column counts,
+                // coverage, row minimum) has a candidate in 0.2 % of the 32 x 32 tiles of the bench problem, the "any"
+                // direction of the rows that still lack a witness in 16 % - the other tiles used to pay four group gates each.
+                {
+                    bool hit = rowok[nt] && tmin <= prow_thr;
+                    if constexpr (NEED_ANY) hit = hit || (rowok[nt] && !anyf[nt] && fminf(fminf(marg4[0], marg4[1]), fminf(marg4[2], marg4[3])) <= 0.f);
+                    if (!__any(hit)) continue;
+                }
+                // Detail path, per register group and direction, behind wave-uniform gates - those groups run without ballots
+                // and counts.  (One loop with switches, not two loops: a second unrolled copy pushes the epilogue over the
+                // compiler's unroll budget and the accumulator array into scratch.)
                 const float* alo = a + 2 * WTB + mt * 32;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -452,8 +459,9 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     const WLane L;
     const int64_t T = (N + WTB - 1) / WTB;
     const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
+    constexpr int NW = KnnWideEpilogue<KCAP>::NWAVES;
     if (sw.ntiles == 0) {
-        if (L.tid == 0) wgq_count[blockIdx.x] = 0;
+        if (L.tid < NW) wgq_count[(int64_t)blockIdx.x * NW + L.tid] = 0;
         return;
     }
     const float nmax = __uint_as_float(maxn[0]);
@@ -463,10 +471,11 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     epi.n = N;
     epi.pblock = sw.pb;
     epi.aux = lds + WENGINE_LDS_WORDS;
-    epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
-    epi.wgv = wgv + (int64_t)blockIdx.x * qcap;
-    epi.qn = reinterpret_cast<int*>(lds + WENGINE_LDS_WORDS + 8 * WTB);
-    epi.qcap = qcap;
+    const int wave = __builtin_amdgcn_readfirstlane(L.wave);
+    epi.wcap = qcap / NW;                             // every wave owns an eighth of the workgroup's region
+    epi.wgq = wgq + ((int64_t)blockIdx.x * NW + wave) * epi.wcap;
+    epi.wgv = wgv + ((int64_t)blockIdx.x * NW + wave) * epi.wcap;
+    epi.wq = 0;
     epi.ovq = ovq;
     epi.ovv = ovv;
     epi.ovn = ovn;
@@ -474,7 +483,6 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     epi.cnt = cnt;
     epi.cap = cap;
     epi.dsc = half_unscale(maxn[2], maxn[2]);
-    if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int64_t i = sw.pb * WTB + L.wn * 64 + nt * 32 + L.r;
@@ -495,7 +503,7 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
         for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
     }
     __syncthreads();
-    if (L.tid == 0) wgq_count[blockIdx.x] = min(*epi.qn, qcap);
+    if (L.lane == 0) wgq_count[(int64_t)blockIdx.x * NW + wave] = min(epi.wq, epi.wcap);
     if (L.tid < WTB) {
         const int64_t i = sw.pb * WTB + L.tid;
         if (i < N) {

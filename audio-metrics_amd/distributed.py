@@ -53,8 +53,9 @@ def _all_reduce(t, world, group):
 
 def _flat_gather_supported(group):
     """RCCL gathers straight into one tensor; gloo takes the list form (decided once from the backend, never by
-    catching a failed collective: an exception on one rank must not turn into a different collective there)."""
-    return dist.get_backend(group) == "nccl"
+    catching a failed collective: an exception on one rank must not turn into a different collective there).
+    Composite backend strings ("cuda:nccl,cpu:gloo") count as RCCL for device tensors."""
+    return "nccl" in str(dist.get_backend(group))
 
 
 def _all_gather_into(out, local, world, group, async_op=False):
@@ -109,11 +110,28 @@ def global_count(n_local, device, group=None):
     return int(t.item())
 
 
-def local_rows(data):
-    """This rank's stored rows of an ``AudioMetricsData`` as an [n, D] matrix (possibly with zero rows)."""
-    if data is None or data.embeddings is None:
+def local_rows(data, group=None):
+    """This rank's stored rows of an ``AudioMetricsData`` as an [n, D] f32 matrix - possibly with ZERO rows: a rank that was
+    fed no audio holds a set that never received a row (``embeddings is None``) and must still take part in every
+    collective of the evaluation.  Collective itself when a group is given (every rank must call): the width D is agreed on
+    with an all-reduce, and the one condition that is an error - a set that keeps no embeddings - is evaluated identically
+    on every rank (it is a property of the configuration), so either all ranks raise or none does."""
+    world, _ = _world(group)
+    rows = None if data is None else data.embeddings
+    stores = data is not None and bool(data.store_embeddings)
+    if world == 1:
+        if rows is None:
+            raise ValueError("the metric needs the stored embeddings of a set that kept none")
+        return rows
+    dev = data.device if data is not None else torch.device("cpu")
+    t = torch.tensor([0 if rows is None else rows.shape[1], 0 if stores else 1], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    width, someone_keeps_none = (int(v) for v in t.cpu().tolist())
+    if someone_keeps_none:
         raise ValueError("the metric needs the stored embeddings of a set that kept none")
-    return data.embeddings
+    if rows is None:
+        rows = torch.empty((0, width), dtype=torch.float32, device=dev)
+    return rows
 
 
 def global_stats_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group):

@@ -79,7 +79,12 @@ DEFAULT_MIX_FUNCTION = "L0"
 
 
 def resolve_mix_function(name=None, needed=True):
-    """Registry lookup used by ``AudioMetrics``.  `needed` = the configuration mixes at all (APA requested)."""
+    """Registry lookup used by ``AudioMetrics``.  `needed` = the configuration mixes at all (APA requested).
+    A loudness mixer asked for BY NAME is an error right here.  The reference's DEFAULT (mix_function=None -> "L0") is
+    different: `AudioMetrics()` must stay constructible - e.g. to load a state file written elsewhere - so the default
+    resolves to a stub that raises the same message at the first window it is asked to mix, i.e. at the very start of an
+    add_reference() / evaluate() call, never in the middle of a stream."""
+    explicit = name is not None
     if name is None:
         name = DEFAULT_MIX_FUNCTION
     if name in MIX_FUNCTIONS:
@@ -88,9 +93,9 @@ def resolve_mix_function(name=None, needed=True):
         raise ValueError(f"Unknown mix_function {name}, must be one of {list(MIX_FUNCTIONS) + list(LOUDNESS_MIXERS)}")
     message = (f"mix_function {name!r} is a BS.1770 loudness mixer (pyloudnorm + numpy_audio_limiter), which this build "
                "does not provide; pass mix_function='P0' (peak based) or your own callable f(audio[n, 2], sr) -> audio[n]")
-    if needed:
+    if needed and explicit:
         raise ValueError(message)
 
-    def unavailable(audio, sr):               # only reachable if a caller mixes although APA was not requested
+    def unavailable(audio, sr):
         raise ValueError(message)
     return unavailable

@@ -71,3 +71,63 @@ def test_shard_bounds_cover_rows():
             b = [shard_bounds(n, w, r) for r in range(w)]
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+def _empty_rank_worker(rank, world, port, n_ref, n_cand, d, k, out_q):
+    """Rank 1 was fed no audio: its sets never received a row (embeddings is None).  The front end's local_rows() must
+    hand evaluate_sharded an empty [0, D] matrix there instead of raising on that rank alone (which left the others
+    waiting in the first all-gather)."""
+    from types import SimpleNamespace
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_ops
+    from audio_metrics_amd.distributed import evaluate_sharded, local_rows
+    ref, cand = gi.pair("shifted", 92, n_ref, n_cand, d)
+    cpu = torch.device("cpu")
+    if rank == 0:
+        sets = [SimpleNamespace(embeddings=torch.as_tensor(x), store_embeddings=True, device=cpu) for x in (ref, cand)]
+    else:
+        sets = [SimpleNamespace(embeddings=None, store_embeddings=True, device=cpu) for _ in range(2)]
+    rows = [local_rows(s, None if world == 1 else dist.group.WORLD) for s in sets]
+    assert rows[0].shape == ((n_ref, d) if rank == 0 else (0, d)) and rows[0].dtype == torch.float32
+    res = evaluate_sharded(rows[0], rows[1], nearest_k=k, ops=cpu_ops, kid_subsets=6, kid_subset_size=200)
+    # a set that keeps no embeddings is an error on EVERY rank (same exception, no hang)
+    keeps_none = SimpleNamespace(embeddings=None, store_embeddings=rank == 0, device=cpu)
+    try:
+        local_rows(keeps_none, dist.group.WORLD)
+        raised = False
+    except ValueError:
+        raised = True
+    out_q.put((rank, res, raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_without_rows_takes_part_in_the_evaluation():
+    n_ref, n_cand, d, k, world = 500, 450, 16, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_rank_worker, args=(r, world, port, n_ref, n_cand, d, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results = {rank: res for rank, res, _ in got}
+    assert all(raised for _, _, raised in got)
+    ref, cand = gi.pair("shifted", 92, n_ref, n_cand, d)
+    a = oracle.OracleData(True).add(torch.as_tensor(cand))
+    b = oracle.OracleData(True).add(torch.as_tensor(ref))
+    want = {"fad": oracle.frechet_distance(a, b)}
+    want.update(oracle.kid_from_features(cand, ref, subsets=6, subset_size=200))
+    want.update(oracle.prdc(b, a, k))
+    assert results[0] == results[1]
+    for key, w in want.items():
+        assert abs(results[0][key] - w) <= max(2e-5 * abs(w), 5e-7), (key, results[0][key], w)

@@ -127,21 +127,23 @@ def test_sharded_evaluate_takes_symmetric_path():
         assert results[0][key] == single[key], key
 
 
-@pytest.mark.parametrize("rows,dim", [(3000, 64), (9000, 128)])
-def test_bench_two_rank_launch(rows, dim):
+@pytest.mark.parametrize("ranks,rows,dim", [(2, 3000, 64), (2, 9000, 128), (8, 66000, 128)])
+def test_bench_multi_rank_launch(ranks, rows, dim):
     """bench.py launched the way the driver launches it for N=2 (torch.distributed.run, one JSON line from
     rank 0).  Both ranks share cuda:0 over gloo (bench.py's AM_BENCH_* test hooks); 9000x128 is eligible for the
-    partitioned symmetric k-NN, 3000x64 takes the general kernel on row shards.  The 2-rank result must equal the
-    1-rank result of the same command."""
+    partitioned symmetric k-NN, 3000x64 takes the general kernel on row shards.  The N-rank result must equal the
+    1-rank result of the same command.  The 8-rank case at 66000 x 128 is the driver's 8-GPU launch in every respect but the
+    transport: am_knn_path == 3 (the f16 filter sweep on the 256-row engine, partitioned eight ways), prepared sets shared
+    by a rank's entry points, 8-way fused collectives, unequal shards (66000 / 8 = 8250 rows: 32.2 row blocks per rank)."""
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--steps", "1", "--warmup", "1", "--rows", str(rows), "--dim", str(dim), "--no-cpu-baseline"]
     env = dict(os.environ, AM_BENCH_DEVICE="0", AM_BENCH_BACKEND="gloo")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-                          os.path.join(root, "bench.py"), "--gpus", "2"] + common,
-                         env=env, capture_output=True, text=True, timeout=600)
+                          os.path.join(root, "bench.py"), "--gpus", str(ranks)] + common,
+                         env=env, capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, two.stdout[-2000:]
@@ -150,7 +152,9 @@ def test_bench_two_rank_launch(rows, dim):
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     out1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
-    assert out2["n_gpus"] == 2 and out1["n_gpus"] == 1
+    assert out2["n_gpus"] == ranks and out1["n_gpus"] == 1
+    if rows >= 32768 and dim >= 128:
+        assert out2["filter"]["knn_path"] == 3 and out2["filter"]["knn_fallback_rows"] == 0, out2["filter"]
     for key in ("metric", "value", "unit", "ms_per_step", "scaling", "roofline", "config"):
         assert key in out2
     assert out2["roofline"]["frac"] > 0
@@ -172,13 +176,13 @@ def test_overlapped_frechet_solve_gives_the_same_result():
     ref, cand = gi.pair("randn", 41, 6000, 5500, 96)
     dev = torch.device("cuda:0")
     r, c = torch.as_tensor(ref).to(dev), torch.as_tensor(cand).to(dev)
-    with_overlap = [evaluate_sharded(r, c, nearest_k=3, kid_subsets=6, kid_subset_size=500) for _ in range(3)]
+    with_overlap = [evaluate_sharded(r, c, nearest_k=3, kid_subsets=6, kid_subset_size=500, fused=False) for _ in range(3)]
 
     class SyncOps:                                  # the same library without the asynchronous entry point
         def __getattr__(self, name):
             if name == "frechet_async":
                 raise AttributeError(name)
             return getattr(ops, name)
-    without = evaluate_sharded(r, c, nearest_k=3, kid_subsets=6, kid_subset_size=500, ops=SyncOps())
+    without = evaluate_sharded(r, c, nearest_k=3, kid_subsets=6, kid_subset_size=500, ops=SyncOps(), fused=False)
     for res in with_overlap:
         assert res == without

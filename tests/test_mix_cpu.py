@@ -34,3 +34,8 @@ def test_loudness_mixers_are_rejected_at_construction():
     with pytest.raises(ValueError):
         resolve_mix_function("nope")
     assert callable(resolve_mix_function("P0"))
+    # the reference's default (None -> "L0") keeps AudioMetrics() constructible; the first mix raises the same message
+    import numpy as np
+    deferred = resolve_mix_function(None, needed=True)
+    with pytest.raises(ValueError, match="BS.1770"):
+        deferred(np.zeros((10, 2), dtype=np.float32), sr=16000)
