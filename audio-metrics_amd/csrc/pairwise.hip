@@ -439,10 +439,15 @@ knn_sym_kernel(const float* __restrict__ X, int64_t N, int64_t ld, const float* 
             // Publish a new upper bound for the row: the (k+1)-th smallest over this window AND the lists the
             // higher windows have already written (distinct columns, so their union is a set of true entries;
             // a slot that is still +inf or stale only makes the bound looser, never wrong).
+            // (a window's KCAP values are fetched together: written as load-insert-load-insert the agent-scope loads were
+            // kept strictly serial - s_waitcnt vmcnt(0) behind each - and every one of them misses L2)
             for (int w2 = W + 1; w2 < nwin; ++w2) {
                 const float* src2 = partial + ((int64_t)w2 * N + i) * KCAP;
-                for (int s = 0; s < KCAP; ++s)
-                    list_insert<KCAP>(m, __hip_atomic_load(src2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                float v[KCAP];
+#pragma unroll
+                for (int s = 0; s < KCAP; ++s) v[s] = __hip_atomic_load(src2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int s = 0; s < KCAP; ++s) list_insert<KCAP>(m, v[s]);
             }
             float kth = m[0];
 #pragma unroll
@@ -973,7 +978,7 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
     const double expect = (double)p.tile_rows * p.tile_rows * p.win_tiles * (double)(k + 1) * stride / (double)N;
     static const int qcap_env = env_int("AM_KNN_SYM_QCAP", 0);
     p.qcap = qcap_env > 0 ? qcap_env : (int)std::min(32768.0, std::max(256.0, 8.0 * expect));   // (the f16 filter path queues both directions)
-    p.qcap = (p.qcap + 7) / 8 * 8;                     // the f16 filter sweeps split a region evenly among their 4 / 8 waves
+    p.qcap = (p.qcap + 15) / 16 * 16;                  // the f16 filter sweeps split half of a region evenly among their 4 / 8 waves
     return p;
 }
 
@@ -998,7 +1003,7 @@ static size_t carve_knn(Carver& c, int64_t N, int64_t M, const KnnPlan& p, KnnBu
         b.ov_count = b.cnt ? b.cnt + N : nullptr;
         const size_t nwg = (size_t)p.nwg;
         b.wgq = c.take<uint2>(nwg * p.qcap);
-        b.wgq_count = c.take<int>(nwg * 8);        // the f16 filter sweeps count per wave (up to eight sub-regions per workgroup)
+        b.wgq_count = c.take<int>(nwg * 9);        // the f16 filter sweeps count per wave + the shared part (up to nine parts per workgroup)
     } else {
         b.thr = b.cand = nullptr;
         b.cnt = b.ov_list = b.ov_count = b.wgq_count = nullptr;
@@ -1008,7 +1013,8 @@ static size_t carve_knn(Carver& c, int64_t N, int64_t M, const KnnPlan& p, KnnBu
 }
 
 extern "C" size_t am_knn_workspace_bytes(int64_t N, int64_t M, int D, int k) {
-    if (N < 1 || M < 1 || D < 1 || k < 1 || k > AM_MAX_K) return 0;
+    if (N < 1 || M < 1 || D < 1 || k < 1 || (int64_t)k + 1 > M) return 0;
+    if (k > AM_MAX_K) return knn_rows_ws(N, M);
     // sized for the symmetric path whenever the shapes allow it (the caller may pass Y == X)
     const KnnPlan p = plan_knn(N, M, D, k, N == M);
     Carver c(nullptr, 0);
@@ -1102,6 +1108,90 @@ static int run_knn(const float* X, int64_t N, int64_t ldx, const float* Y, int64
     return rc;
 }
 
+
+// ---- nearest_k beyond the per-lane lists (k > AM_MAX_K) -------------------------------------------------------------------
+// The tile kernels keep the k+1 smallest values of a row in registers, which stops at 32 slots.  The reference takes any
+// k (prdc.py:18: torch.kthvalue on the full distance row), so larger k run here: one workgroup per row (grid-stride) walks
+// all M columns with the exact engine's fmaf order - the same values, bit for bit, as the tile kernels' - writes the row
+// of squared distances to its own scratch line, and finds the (k+1)-th smallest by a most-significant-byte-first radix
+// select over the f32 bit patterns (non-negative values order like their bit patterns; four histogram passes).
+// O(N M D) on the vector ALUs instead of the matrix cores: a correctness path for a rarely used argument range
+// (AudioMetrics.evaluate caps k at 10, audio_metrics.py:263), not a fast one.
+__global__ void __launch_bounds__(256) knn_rows_kernel(const float* __restrict__ X, int64_t N, int64_t ldx,
+                                                       const float* __restrict__ xnorm, const float* __restrict__ Y, int64_t M,
+                                                       int64_t ldy, const float* __restrict__ ynorm, int D, int k1,
+                                                       float* __restrict__ scratch, float* __restrict__ radii) {
+    extern __shared__ __attribute__((aligned(16))) float xrow[];      // D padded to a multiple of 32
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel_prefix, sel_rank;
+    const int dp = (D + 31) / 32 * 32;
+    float* line = scratch + (int64_t)blockIdx.x * M;
+    for (int64_t i = blockIdx.x; i < N; i += gridDim.x) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < dp; k += 256) xrow[k] = k < D ? X[i * ldx + k] : 0.f;
+        __syncthreads();
+        const float xi = xnorm[i];
+        for (int64_t j = threadIdx.x; j < M; j += 256) {
+            const float* y = Y + j * ldy;
+            float a = 0.f;
+            for (int c = 0; c < dp; c += 8) {                         // index order 8c+s, 8c+4+s (tile_engine.h)
+                const f32x4 a0 = load_k4(y, c, D), a1 = load_k4(y, c + 4, D);
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow + c), x1 = *reinterpret_cast<const f32x4*>(xrow + c + 4);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    a = fmaf(a0[s2], x0[s2], a);
+                    a = fmaf(a1[s2], x1[s2], a);
+                }
+            }
+            line[j] = fmaxf(fmaf(-2.f, a, xi + ynorm[j]), 0.f);
+        }
+        if (threadIdx.x == 0) { sel_prefix = 0u; sel_rank = (unsigned)(k1 - 1); }      // 0-based rank of the wanted value
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hist[threadIdx.x] = 0u;
+            __syncthreads();                                          // (also makes the row of distances visible)
+            const unsigned prefix = sel_prefix, mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+            for (int64_t j = threadIdx.x; j < M; j += 256) {
+                const unsigned bits = __float_as_uint(line[j]);
+                if ((bits & mask) == prefix) atomicAdd(&hist[(bits >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned rank = sel_rank, bin = 0;
+                while (bin < 255u && rank >= hist[bin]) rank -= hist[bin++];
+                sel_rank = rank;
+                sel_prefix = prefix | (bin << shift);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) radii[i] = sqrt_rn(__uint_as_float(sel_prefix));
+    }
+}
+
+static size_t knn_rows_ws(int64_t N, int64_t M) {
+    Carver c(nullptr, 0);
+    c.take<float>(N);
+    c.take<float>(M);
+    c.take<float>((size_t)std::min<int64_t>(N, 1024) * M);
+    return c.off;
+}
+
+static int run_knn_rows(const float* X, int64_t N, int64_t ldx, const float* Y, int64_t M, int64_t ldy, int D, int k1, bool self,
+                        float* out_r, void* ws, size_t ws_bytes, hipStream_t st, const PreparedSet* prep) {
+    int rc;
+    Carver c(ws, ws_bytes);
+    float* xn = c.take<float>(N);
+    float* yn = c.take<float>(M);
+    const int64_t grid = std::min<int64_t>(N, 1024);
+    float* scratch = c.take<float>((size_t)grid * M);
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    if ((rc = norms_of(prep, X, N, ldx, D, xn, st)) != AM_OK) return rc;
+    if (!self && (rc = launch_norms(Y, M, ldy, D, yn, st)) != AM_OK) return rc;
+    hipLaunchKernelGGL(knn_rows_kernel, dim3((unsigned)grid), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ldx,
+                       xn, Y, M, ldy, self ? xn : yn, D, k1, scratch, out_r);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
 static int knn_radii_impl(const float* X, int64_t N, int64_t ldx, const float* Y, int64_t M, int64_t ldy, int D, int k,
                           float* out_r, void* ws, size_t ws_bytes, am_stream_t stream, const PreparedSet* prep) {
     int rc;
@@ -1109,11 +1199,12 @@ static int knn_radii_impl(const float* X, int64_t N, int64_t ldx, const float* Y
     if ((rc = check_matrix(Y, M, ldy, D, "Y")) != AM_OK) return rc;
     AM_REQUIRE(out_r != nullptr, AM_ERR_BAD_ARG, "out_r is null");
     AM_REQUIRE(k >= 1, AM_ERR_BAD_SHAPE, "nearest_k must be >= 1 (got %d)", k);
-    AM_REQUIRE(k <= AM_MAX_K, AM_ERR_UNSUPPORTED_K, "nearest_k %d > AM_MAX_K %d", k, AM_MAX_K);
     AM_REQUIRE((int64_t)k + 1 <= M, AM_ERR_BAD_SHAPE, "k + 1 = %d exceeds the %lld available rows (kthvalue out of range)",
                k + 1, (long long)M);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool self = (Y == X && M == N && ldy == ldx);
+    if (k > AM_MAX_K)                              // beyond the per-lane lists of the tile kernels: one row at a time
+        return run_knn_rows(X, N, ldx, Y, M, ldy, D, k + 1, self, out_r, ws, ws_bytes, st, prep);
     KnnPlan p = plan_knn(N, M, D, k, self);
     Carver c(ws, ws_bytes);
     KnnBuffers b;
@@ -1191,7 +1282,8 @@ extern "C" int am_filter_stats_enable(int64_t* device_slots) {
 // which form am_knn_radii_f32 / am_prdc_counts_f32 take for a shape: 0 exact general, 1 exact symmetric,
 // 2 f16 filter + verify on the 128 x 128 engine, 3 the same on the 256 x 256 engine
 extern "C" int am_knn_path(int64_t N, int64_t M, int D, int k, int self) {
-    if (N < 1 || M < 1 || D < 1 || k < 1 || k > AM_MAX_K) return -1;
+    if (N < 1 || M < 1 || D < 1 || k < 1) return -1;
+    if (k > AM_MAX_K) return 4;                     // row-at-a-time kernel (knn_rows_kernel)
     const KnnPlan p = plan_knn(N, M, D, k, self != 0 && N == M);
     return !p.sym ? 0 : (knn_fast_enabled(N, D) ? (p.tile_rows == 256 ? 3 : 2) : 1);
 }

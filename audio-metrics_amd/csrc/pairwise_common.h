@@ -137,11 +137,14 @@ constexpr unsigned FAST_HOLE = 0xffffffffu;                                  // 
 
 // Lane / TBX / MT: geometry of the engine underneath - LaneInfo, 128, 2 (tile_engine.h) or WLane, 256, 4 (wide_engine.h)
 //
-// Queue protocol (round 3).  Every WAVE owns a sub-region of its workgroup's queue region (`wcap` entries at
-// wgq + (blockIdx * NWAVES + wave) * wcap) and counts its entries in a scalar register: the tests that select an entry are
-// wave-wide anyway (ballots), so a slot is `count + (number of selected lanes below this one)` - no LDS atomic, no
-// round trip in the epilogue's critical path.  (Round 2 reserved slots with one returning LDS atomic per lane and
-// accumulator tile, and looked at every register of a hit group twice: once for the bit masks, once to store.)
+// Queue protocol (round 3).  A workgroup's region of `qcap` entries is NWAVES private sub-regions of wcap = qcap / (2 NWAVES)
+// entries followed by one shared part of the remaining half.  Every WAVE counts the entries of its private sub-region in a
+// scalar register: the tests that select an entry are wave-wide anyway (ballots), so a slot is `count + (number of
+// selected lanes below this one)` - no LDS atomic, no round trip in the epilogue's critical path.  (Round 2 reserved slots
+// with one returning LDS atomic per lane and accumulator tile, and looked at every register of a hit group twice: once
+// for the bit masks, once to store.)  Only a wave whose private part is full - a lane holding an outlier row with a loose
+// bound sends all of that row's entries through ONE wave - takes slots of the shared part from an LDS counter; with
+// private parts alone 1M-row sets overflowed regions that the whole workgroup would have absorbed.
 template <int KCAP, class Lane = LaneInfo, int TBX = TB, int MT = 2>
 struct KnnFastEpilogue {
     static constexpr int NWAVES = TBX == WIDE_TILE_ROWS ? 8 : 4;   // waves per workgroup
@@ -149,10 +152,14 @@ struct KnnFastEpilogue {
     const float* thr;
     int64_t n, pblock;
     float* aux;                 // LDS [2][2][TBX] : |x_j|^2 and thr[j] of the tile
-    uint2* wgq;                 // this WAVE's sub-region
+    uint2* wgq;                 // this WAVE's private sub-region
     float* wgv;                 // approximate value of each queued pair (pruning, knn_fast_prune_kernel)
     int wq;                     // entries this wave has queued (wave-uniform, lives in a scalar register)
-    int wcap;                   // capacity of the sub-region
+    int wcap;                   // capacity of the private sub-region
+    uint2* shq;                 // the workgroup's shared part (slots from the LDS counter `qn`)
+    float* shv;
+    int* qn;
+    int shcap;
     uint2* ovq;                 // global spill queue for entries that do not fit their region
     float* ovv;
     unsigned long long* ovn;
@@ -172,6 +179,12 @@ struct KnnFastEpilogue {
         if (slot < wcap) {
             wgq[slot] = make_uint2(a | (both ? FAST_BOTH : 0u), b);
             wgv[slot] = val;
+            return;
+        }
+        const int s1 = atomicAdd(qn, 1);                 // private part full: the workgroup's shared part
+        if (s1 < shcap) {
+            shq[s1] = make_uint2(a | (both ? FAST_BOTH : 0u), b);
+            shv[s1] = val;
         } else {
             // Region full (rare: the regions hold 8x the expected survivors).  The 128-row short-list instantiation keeps a
             // global spill queue; everywhere else the row(s) go straight to the exact fix-up kernel - this store is

@@ -820,7 +820,7 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
     constexpr int NW = KnnFastEpilogue<KCAP>::NWAVES;
     if (sw.ntiles == 0) {
-        if (L.tid < NW) wgq_count[(int64_t)blockIdx.x * NW + L.tid] = 0;
+        if (L.tid <= NW) wgq_count[(int64_t)blockIdx.x * (NW + 1) + L.tid] = 0;
         return;
     }
     const float nmax = __uint_as_float(maxn[0]);
@@ -831,10 +831,15 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     epi.pblock = sw.pb;
     epi.aux = lds + ENGINE_LDS_FLOATS;
     const int wave = __builtin_amdgcn_readfirstlane(L.tid >> 6);
-    epi.wcap = qcap / NW;                             // every wave owns a quarter of the workgroup's region
-    epi.wgq = wgq + ((int64_t)blockIdx.x * NW + wave) * epi.wcap;
-    epi.wgv = wgv + ((int64_t)blockIdx.x * NW + wave) * epi.wcap;
+    epi.wcap = qcap / (2 * NW);                       // private sub-regions: half of the workgroup's region in all
+    epi.wgq = wgq + (int64_t)blockIdx.x * qcap + wave * epi.wcap;
+    epi.wgv = wgv + (int64_t)blockIdx.x * qcap + wave * epi.wcap;
     epi.wq = 0;
+    epi.shcap = qcap - NW * epi.wcap;                 // the shared part behind them
+    epi.shq = wgq + (int64_t)blockIdx.x * qcap + NW * epi.wcap;
+    epi.shv = wgv + (int64_t)blockIdx.x * qcap + NW * epi.wcap;
+    epi.qn = reinterpret_cast<int*>(lds + ENGINE_LDS_FLOATS + 4 * TB);
+    if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
     epi.ovq = ovq;
     epi.ovv = ovv;
     epi.ovn = ovn;
@@ -862,7 +867,8 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
         for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
     }
     __syncthreads();
-    if (L.lane == 0) wgq_count[(int64_t)blockIdx.x * NW + wave] = min(epi.wq, epi.wcap);
+    if (L.lane == 0) wgq_count[(int64_t)blockIdx.x * (NW + 1) + wave] = min(epi.wq, epi.wcap);
+    if (L.tid == 0) wgq_count[(int64_t)blockIdx.x * (NW + 1) + NW] = min(*epi.qn, epi.shcap);
     if (L.tid < TB) {
         const int64_t i = sw.pb * TB + L.tid;
         if (i < N) {
@@ -872,17 +878,29 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
             for (int s = 0; s < KCAP; ++s) m[s] = src[s];
             for (int s = KCAP; s < 4 * KCAP; ++s)
                 if (src[s] > -INFINITY) list_insert<KCAP>(m, src[s]);
-            float* out = partial + ((int64_t)sw.W * N + i) * KCAP;
+            // CUMULATIVE list: this window's values merged with the cumulative list of the row block's previous window in
+            // processing order (the nearest higher window in which the block owned tiles; windows are dispatched in
+            // descending order) - distinct columns, so the (k+1)-th smallest still bounds the row's final value from above.
+            // One list is read (KCAP independent loads) instead of the own lists of ALL higher windows one value at a time:
+            // the compiler kept those agent-scope loads strictly serial (s_waitcnt vmcnt(0) behind each), up to 21 x KCAP
+            // L2-missing round trips at the end of every workgroup - ~10 % of the kernel at 100k rows.
+            // (A block still running, or not started, leaves +inf pads or a partly written list there: any subset is valid.)
+            int prev = -1;
+            for (int w2 = sw.W + 1; w2 < nwin && prev < 0; ++w2)
+                if (sym_item(T, win_tiles, w2, sw.pb, part, nparts).ntiles > 0) prev = w2;
+            if (prev >= 0) {
+                const float* src2 = partial + ((int64_t)prev * N + i) * KCAP;
+                float v[KCAP];
+#pragma unroll
+                for (int s = 0; s < KCAP; ++s) v[s] = __hip_atomic_load(src2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int s = 0; s < KCAP; ++s)
+                    if (v[s] > -INFINITY) list_insert<KCAP>(m, v[s]);
+            }
             // write-through stores / agent-scope loads: other XCDs read these lists while the kernel runs
+            float* out = partial + ((int64_t)sw.W * N + i) * KCAP;
 #pragma unroll
             for (int s = 0; s < KCAP; ++s) __hip_atomic_store(out + s, m[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int w2 = sw.W + 1; w2 < nwin; ++w2) {      // cumulative over the windows already swept (distinct columns)
-                const float* src2 = partial + ((int64_t)w2 * N + i) * KCAP;
-                for (int s = 0; s < KCAP; ++s) {
-                    const float v = __hip_atomic_load(src2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v > -INFINITY) list_insert<KCAP>(m, v);
-                }
-            }
             const float kthv = m[KCAP - 1];
             const float bound = kthv + 2.f * fc * (xnorm[i] + nmax);     // >= 0, so its bit pattern orders like the value
             atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
@@ -915,16 +933,19 @@ __device__ __forceinline__ void knn_file_approx(float* __restrict__ fval, unsign
     }
 }
 
+// one workgroup per queue part: blockIdx = workgroup of the sweep * (nsub + 1) + part; parts 0 .. nsub-1 are the waves'
+// private sub-regions (wcap entries each), part nsub is the shared part behind them
 __global__ void __launch_bounds__(256) knn_fast_scatter_kernel(const uint2* __restrict__ wgq, const float* __restrict__ wgv,
-                                                               int qcap, const int* __restrict__ wgq_count,
+                                                               int qcap, int wcap, int nsub, const int* __restrict__ wgq_count,
                                                                float* __restrict__ fval, unsigned* __restrict__ fidx,
                                                                int* __restrict__ cnt, int cap, const float* __restrict__ thr) {
     // thr[i] (the bound the sweep left behind: (k+1)-th smallest approximate value seen + 2E) admits every pair that can
     // be among row i's k+1 smallest; most entries were queued under the much looser bounds of the first windows and are
     // dropped here instead of being filed and pruned later
     const int n = wgq_count[blockIdx.x];
-    const uint2* q = wgq + (int64_t)blockIdx.x * qcap;
-    const float* v = wgv + (int64_t)blockIdx.x * qcap;
+    const int64_t base = (int64_t)(blockIdx.x / (nsub + 1)) * qcap + (int64_t)(blockIdx.x % (nsub + 1)) * wcap;
+    const uint2* q = wgq + base;
+    const float* v = wgv + base;
     for (int e = threadIdx.x; e < n; e += 256) {
         const uint2 p = q[e];
         const unsigned a = p.x & ~FAST_BOTH;
@@ -1196,10 +1217,10 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     {
         AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_fast_kernel<KCAP>), (int)PAIRWISE_LDS_BYTES + 16));
     }
-    const int qcap = p.qcap;                                               // per workgroup; every wave owns qcap / nsub of it
+    const int qcap = p.qcap;                                               // per workgroup: nsub private sub-regions + a shared part
     const int nsub = p.tile_rows == WIDE_TILE_ROWS ? 8 : 4;                  // KnnFastEpilogue::NWAVES of the engine that runs
-    const int wcap = qcap / nsub;
-    const unsigned nreg = nwg * (unsigned)nsub;                             // queue sub-regions in all
+    const int wcap = qcap / (2 * nsub);
+    const unsigned nreg = nwg * (unsigned)(nsub + 1);                       // queue parts in all
     static const int ovcap = std::max(0, std::min(env_int("AM_KNN_FAST_OVCAP", KNN_FAST_OVCAP), KNN_FAST_OVCAP));   // (tests shrink it)
     clock_begin(AM_KERNEL_KNN, st);
     if (p.tile_rows == WIDE_TILE_ROWS) {
@@ -1216,8 +1237,8 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     AM_LAUNCH_CHECK();
     // 3) approximate values filed by row, 4) pruned against the row's own (k+1)-th smallest, 5) exact values of the
     //    survivors, 6) selection, 7) exact fix-up of overflowed rows
-    hipLaunchKernelGGL(knn_fast_scatter_kernel, dim3(nreg), dim3(256), 0, st, b.wgq, f.wgv, wcap, b.wgq_count, b.cand, f.fidx, b.cnt,
-                       p.cap, thr);
+    hipLaunchKernelGGL(knn_fast_scatter_kernel, dim3(nreg), dim3(256), 0, st, b.wgq, f.wgv, qcap, wcap, nsub, b.wgq_count, b.cand,
+                       f.fidx, b.cnt, p.cap, thr);
     hipLaunchKernelGGL(knn_fast_scatter_spill_kernel, dim3(256), dim3(256), 0, st, f.ovq, f.ovv, f.ovn, ovcap, b.cand, f.fidx,
                        b.cnt, p.cap, thr);
     AM_LAUNCH_CHECK();
@@ -1260,7 +1281,10 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
         int wmax = 0, cmax = 0;
         unsigned long long spilled = 0;
         AM_HIP_TRY(hipMemcpy(&spilled, f.ovn, sizeof(spilled), hipMemcpyDeviceToHost));
-        for (int v : wc) { tot += v; full += (v >= wcap); wmax = std::max(wmax, v); }
+        for (size_t r = 0; r < wc.size(); ++r) {
+            const int v = wc[r], capr = (int)(r % (nsub + 1)) == nsub ? qcap - nsub * wcap : wcap;
+            tot += v; full += (v >= capr); wmax = std::max(wmax, v);
+        }
         for (int64_t i = 0; i < N; ++i) { ctot += std::min(cn[i], p.cap); cmax = std::max(cmax, cn[i]); bad += c2[i] > p.cap; }
         fprintf(stderr, "[knn_fast] wgs=%u nwin=%d qcap=%d queued=%lld (max/wg %d, full regions %lld) filed=%lld max/row=%d "
                         "pairs verified=%d spilled=%llu rows to fix-up=%lld\n", nwg, p.nwin, qcap, tot, wmax, full, ctot, cmax, c2[N], spilled, bad);

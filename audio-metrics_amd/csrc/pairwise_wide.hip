@@ -461,7 +461,7 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
     constexpr int NW = KnnWideEpilogue<KCAP>::NWAVES;
     if (sw.ntiles == 0) {
-        if (L.tid < NW) wgq_count[(int64_t)blockIdx.x * NW + L.tid] = 0;
+        if (L.tid <= NW) wgq_count[(int64_t)blockIdx.x * (NW + 1) + L.tid] = 0;
         return;
     }
     const float nmax = __uint_as_float(maxn[0]);
@@ -472,10 +472,15 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     epi.pblock = sw.pb;
     epi.aux = lds + WENGINE_LDS_WORDS;
     const int wave = __builtin_amdgcn_readfirstlane(L.wave);
-    epi.wcap = qcap / NW;                             // every wave owns an eighth of the workgroup's region
-    epi.wgq = wgq + ((int64_t)blockIdx.x * NW + wave) * epi.wcap;
-    epi.wgv = wgv + ((int64_t)blockIdx.x * NW + wave) * epi.wcap;
+    epi.wcap = qcap / (2 * NW);                       // private sub-regions: half of the workgroup's region in all
+    epi.wgq = wgq + (int64_t)blockIdx.x * qcap + wave * epi.wcap;
+    epi.wgv = wgv + (int64_t)blockIdx.x * qcap + wave * epi.wcap;
     epi.wq = 0;
+    epi.shcap = qcap - NW * epi.wcap;                 // the shared part behind them
+    epi.shq = wgq + (int64_t)blockIdx.x * qcap + NW * epi.wcap;
+    epi.shv = wgv + (int64_t)blockIdx.x * qcap + NW * epi.wcap;
+    epi.qn = reinterpret_cast<int*>(lds + WENGINE_LDS_WORDS + 8 * WTB);
+    if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
     epi.ovq = ovq;
     epi.ovv = ovv;
     epi.ovn = ovn;
@@ -503,7 +508,8 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
         for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
     }
     __syncthreads();
-    if (L.lane == 0) wgq_count[(int64_t)blockIdx.x * NW + wave] = min(epi.wq, epi.wcap);
+    if (L.lane == 0) wgq_count[(int64_t)blockIdx.x * (NW + 1) + wave] = min(epi.wq, epi.wcap);
+    if (L.tid == 0) wgq_count[(int64_t)blockIdx.x * (NW + 1) + NW] = min(*epi.qn, epi.shcap);
     if (L.tid < WTB) {
         const int64_t i = sw.pb * WTB + L.tid;
         if (i < N) {
@@ -513,16 +519,29 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
             for (int s = 0; s < KCAP; ++s) m[s] = src[s];
             for (int s = KCAP; s < 4 * KCAP; ++s)
                 if (src[s] > -INFINITY) list_insert<KCAP>(m, src[s]);
+            // CUMULATIVE list: this window's values merged with the cumulative list of the row block's previous window in
+            // processing order (the nearest higher window in which the block owned tiles; windows are dispatched in
+            // descending order) - distinct columns, so the (k+1)-th smallest still bounds the row's final value from above.
+            // One list is read (KCAP independent loads) instead of the own lists of ALL higher windows one value at a time:
+            // the compiler kept those agent-scope loads strictly serial (s_waitcnt vmcnt(0) behind each), up to 21 x KCAP
+            // L2-missing round trips at the end of every workgroup - ~10 % of the kernel at 100k rows.
+            // (A block still running, or not started, leaves +inf pads or a partly written list there: any subset is valid.)
+            int prev = -1;
+            for (int w2 = sw.W + 1; w2 < nwin && prev < 0; ++w2)
+                if (sym_item(T, win_tiles, w2, sw.pb, part, nparts).ntiles > 0) prev = w2;
+            if (prev >= 0) {
+                const float* src2 = partial + ((int64_t)prev * N + i) * KCAP;
+                float v[KCAP];
+#pragma unroll
+                for (int s = 0; s < KCAP; ++s) v[s] = __hip_atomic_load(src2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int s = 0; s < KCAP; ++s)
+                    if (v[s] > -INFINITY) list_insert<KCAP>(m, v[s]);
+            }
+            // write-through stores / agent-scope loads: other XCDs read these lists while the kernel runs
             float* out = partial + ((int64_t)sw.W * N + i) * KCAP;
 #pragma unroll
             for (int s = 0; s < KCAP; ++s) __hip_atomic_store(out + s, m[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int w2 = sw.W + 1; w2 < nwin; ++w2) {
-                const float* src2 = partial + ((int64_t)w2 * N + i) * KCAP;
-                for (int s = 0; s < KCAP; ++s) {
-                    const float v = __hip_atomic_load(src2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v > -INFINITY) list_insert<KCAP>(m, v);
-                }
-            }
             const float kthv = m[KCAP - 1];
             const float bound = kthv + 2.f * fc * (xnorm[i] + nmax);
             atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));

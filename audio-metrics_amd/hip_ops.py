@@ -160,6 +160,21 @@ def _same_device(*tensors):
     return dev
 
 
+_NARROWING_WARNED = False
+
+
+def _warn_narrowing():
+    """Once per process: the reference computes an add()'s statistics in the dtype of the embeddings it is given
+    (data.py:39-44; its own test embedder yields float64), this path computes on float32 rows - real embedders (CLAP,
+    VGGish) produce float32, so only synthetic float64 inputs see a difference (~1e-7 relative in the statistics)."""
+    global _NARROWING_WARNED
+    if not _NARROWING_WARNED:
+        _NARROWING_WARNED = True
+        import warnings
+        warnings.warn("audio_metrics_amd: float64 embeddings are narrowed to float32 for the device path (the reference "
+                      "computes in the input dtype; differences are at the 1e-7 level)", RuntimeWarning, stacklevel=3)
+
+
 def as_matrix(e, name="embeddings"):
     """(N, D) f32 device matrix with unit column stride, 16-B aligned rows
     (row stride % 4 == 0).  Copies (zero-padding the row stride) only if needed."""
@@ -167,6 +182,8 @@ def as_matrix(e, name="embeddings"):
     if e.dim() != 2:
         raise ValueError(f"{name} must be 2-D, got shape {tuple(e.shape)}")
     if e.dtype != torch.float32:
+        if e.dtype == torch.float64:
+            _warn_narrowing()
         e = e.to(torch.float32)
     n, d = e.shape
     ok = e.stride(1) == 1 and e.stride(0) % 4 == 0 and e.stride(0) >= d and e.data_ptr() % 16 == 0

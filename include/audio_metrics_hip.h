@@ -38,13 +38,14 @@ typedef enum am_status {
     AM_OK = 0,
     AM_ERR_BAD_ARG = -1,          /* null pointer, misaligned base, ld % 4 != 0 ...           */
     AM_ERR_BAD_SHAPE = -2,        /* empty input, D < 1, k + 1 > N (torch.kthvalue would raise) */
-    AM_ERR_UNSUPPORTED_K = -3,    /* nearest_k > AM_MAX_K                                      */
+    AM_ERR_UNSUPPORTED_K = -3,    /* nearest_k > AM_MAX_K in an entry point of the partitioned form */
     AM_ERR_WORKSPACE = -4,        /* workspace missing or too small                            */
     AM_ERR_NO_CONVERGENCE = -5,   /* Newton-Schulz produced a non-finite trace                 */
     AM_ERR_HIP = -6               /* a HIP runtime call failed (see am_last_error)             */
 } am_status;
 
-#define AM_MAX_K 31               /* largest nearest_k of am_knn_radii_f32 (k+1 <= 32 slots)   */
+#define AM_MAX_K 31               /* largest nearest_k of the TILE kernels (k+1 <= 32 list slots); am_knn_radii_f32 takes any
+                                     k < M and runs larger ones row by row (am_knn_path == 4)        */
 
 const char* am_version(void);
 const char* am_status_string(int status);
@@ -166,7 +167,8 @@ int am_kd_rbf_f32(const float* X, int64_t N1, int64_t ldx,
  *   rows of Y (Y == X for the reference's self-distance use; a multi-GPU
  *   caller passes its row shard as X and the gathered set as Y).
  *   Distances follow torch.cdist's matmul form  sqrt(max(|x|^2+|y|^2-2x.y, 0))
- *   in f32; no N x M matrix is materialised.  1 <= k <= AM_MAX_K, k+1 <= M.
+ *   in f32; no N x M matrix is materialised.  1 <= k, k+1 <= M (k > AM_MAX_K: one row at a time on the vector ALUs,
+ *   same values; a correctness path - the reference's evaluate() caps k at 10).
  *   Y == X with >= 32768 rows (32 <= D <= 4096) runs as a scaled-f16 MFMA FILTER sweep over half of the tile pairs
  *   followed by an f32 evaluation - with the arithmetic of the exact kernel - of the pairs its error bound cannot
  *   rule out (csrc/pairwise_fast.h): the radii are bit-identical to the exact kernels', which remain the path for

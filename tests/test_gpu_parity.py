@@ -89,6 +89,28 @@ def test_knn_other_k_bit_exact(am, k):
     assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, k).view(np.uint32))
 
 
+@pytest.mark.parametrize("k", [32, 40, 100, 699])
+def test_knn_beyond_the_list_kernels_bit_exact(am, k):
+    """nearest_k > AM_MAX_K (31): the reference takes any k (prdc.py:18), the tile kernels hold k + 1 <= 32 values per
+    lane - larger k run row by row (am_knn_path == 4) and must give the C model's bits too, for the set against itself and
+    against other columns; prdc() with such a k against the oracle."""
+    from oracle import exact
+    import oracle
+    x, y = gi.randn(61, 700, 40), gi.randn(64, 901, 40)
+    ops = am.hip_ops
+    assert ops.knn_path(700, 700, 40, k) == 4
+    r = am.nearest_neighbour_distances(dev(x), k).cpu().numpy()
+    assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, k).view(np.uint32))
+    r2 = ops.knn_radii(dev(x), k, columns=dev(y)).cpu().numpy()
+    assert np.array_equal(r2.view(np.uint32), exact.knn_radii(x, k, columns=y).view(np.uint32))
+    if k <= 100:
+        a, b = amd_of(am, x), amd_of(am, y[:650])
+        got = am.prdc(a, b, k)
+        want = oracle.prdc_from_features(torch.as_tensor(x), torch.as_tensor(y[:650]), oracle.knn_radii(x, k), oracle.knn_radii(y[:650], k), k)
+        for key in want:
+            assert abs(got[key] - want[key]) <= max(REL * abs(want[key]), 2.0 / 650), (key, got[key], want[key])
+
+
 def test_knn_rows_vs_other_columns(am):
     """row shard against a larger column set (the multi-GPU calling pattern)."""
     from oracle import exact
@@ -102,7 +124,7 @@ def test_knn_k_out_of_range(am):
     with pytest.raises(am._lib.HipLibraryError):
         am.nearest_neighbour_distances(x, 5)          # k + 1 > N: torch.kthvalue raises in the reference
     with pytest.raises(am._lib.HipLibraryError):
-        am.nearest_neighbour_distances(dev(gi.randn(1, 64, 8)), 32)   # > AM_MAX_K
+        am.nearest_neighbour_distances(dev(gi.randn(1, 64, 8)), 64)   # k + 1 > N
     with pytest.raises(am._lib.HipLibraryError):
         am.hip_ops.stats(torch.zeros(4, 4))            # host tensor: no CPU fallback
 
