@@ -29,6 +29,7 @@ SIGNATURES = {
     "am_frechet_enqueue_f64": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P, _P, c_size_t, _P]),
     "am_apa_f64": (c_double, [c_double, c_double, c_double]),
     "am_kd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "am_kd_poly_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "am_kd_poly_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, _P, _P, c_int, c_int,
                                c_double, c_double, c_int, _P, _P, c_size_t, _P]),
     "am_kd_draw_indices": (c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, c_int64, c_int64, c_int,

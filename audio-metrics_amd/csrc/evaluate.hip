@@ -74,7 +74,7 @@ static bool eval_layout(Carver& c, int64_t n_ref, int64_t n_cand, int D, int k, 
         main_bytes = std::max({main_bytes, am_knn_workspace_bytes(n_ref, n_ref, D, k), am_knn_workspace_bytes(n_cand, n_cand, D, k),
                                am_prdc_workspace_bytes(n_ref, n_cand, D)});
     }
-    if (what & AM_EVAL_KD) main_bytes = std::max(main_bytes, am_kd_workspace_bytes(S, m));
+    if (what & AM_EVAL_KD) main_bytes = std::max(main_bytes, am_kd_poly_workspace_bytes(S, m, D));
     L.ws_main_bytes = round_up(std::max<size_t>(main_bytes, 256), 256);
     L.ws_main = c.take<char>(L.ws_main_bytes);
     L.total = c.off;

@@ -9,7 +9,9 @@
 // forms K in f32 and sums with numpy's pairwise f32 sums; f64 keeps the device
 // on the exact side of the reference's own rounding noise).
 #include "am_common.h"
-#include "tile_engine.h"
+#include "pairwise_common.h"
+#include "wide_engine.h"
+#include <algorithm>
 
 namespace am {
 
@@ -230,6 +232,214 @@ __global__ void __launch_bounds__(256) kd_gather_norms_kernel(const float* __res
     if (lane == 0) out[e] = acc;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Split-f16 form of the polynomial kernel distance on the 256 x 256 f16 engine (wide_engine.h).
+//
+// The f32 MFMA runs at 1/16 of the f16 rate, and kd_tile_kernel already sits at 96 % of it (2.1 ms per evaluate at
+// S = 100, m = 1000, D = 512).  Here every gathered row x is scaled by its own exact power of two (largest |element| in
+// [2^13, 2^14)) and split into two f16 planes, hi = rn16(x) and lo = rn16(x - hi) - x = hi + lo up to 2^-22 |x| - and
+// the dot product is accumulated as  <hi, hi'> + <lo, hi'> + <hi, lo'>  by three stages of the unchanged pipeline per
+// 64-element slab (SplitSlabs below: the Q operand walks the planes hi, lo, hi, the P operand hi, hi, lo).  f16 x f16
+// products are exact in the f32 accumulator, so what is left out is the lo x lo' term and the two plane roundings:
+// |error of a dot product| <= ~3 * 2^-22 |x| |y| - the size of one f32 rounding of the f32 chain it replaces - and the
+// kernel values and every sum are formed in f64 exactly as before.  Measured against the reference's own outputs: see
+// tests/test_gpu_parity.py::test_kd_vs_golden (same tolerances as the f32 form).
+// Layout: planes[(s * 2 + set) * MP + p] = [hi: DP f16 | lo: DP f16], MP = m rounded up to 256, DP = D rounded up to 64,
+// rows p >= m zero; unscale[...] = 2^-e of the row (the factor that undoes its scaling).
+constexpr int KW = 256;
+
+__global__ void __launch_bounds__(256) kd_split_gather_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ Y,
+                                                              int64_t ldy, int D, int DP, const int64_t* __restrict__ idx1,
+                                                              const int64_t* __restrict__ idx2, int S, int m, int MP,
+                                                              uint16_t* __restrict__ planes, float* __restrict__ unscale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per gathered row
+    if (e >= (int64_t)S * 2 * MP) return;
+    const int p = (int)(e % MP), set = (int)((e / MP) & 1);
+    const int64_t s = e / (2 * (int64_t)MP);
+    uint16_t* dst = planes + e * 2 * DP;
+    if (p >= m) {                                                          // padded row: zeros, contributes kval(0)
+        for (int k = lane * 8; k < 2 * DP; k += 512) *reinterpret_cast<uint4*>(dst + k) = make_uint4(0u, 0u, 0u, 0u);
+        if (lane == 0) unscale[e] = 0.f;
+        return;
+    }
+    const float* x = set ? Y + idx2[s * m + p] * ldy : X + idx1[s * m + p] * ldx;
+    float mx = 0.f;
+    for (int k = lane * 4; k < D; k += 256) {
+        const f32x4 v = load_k4(x, k, D);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    const int ex = half_scale_exp(__float_as_uint(mx));                    // 13 - floor(log2(max)), clamped (pairwise_common.h)
+    const float up = __uint_as_float((unsigned)(127 + ex) << 23);
+    if (lane == 0) unscale[e] = __uint_as_float((unsigned)(127 - ex) << 23);
+    for (int k = lane * 4; k < DP; k += 256) {
+        const f32x4 v = load_k4(x, k, D);                                  // zero past D
+        _Float16 hi[4], lo[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float t = v[c] * up;
+            hi[c] = (_Float16)t;
+            lo[c] = (_Float16)(t - (float)hi[c]);
+        }
+        *reinterpret_cast<uint2*>(dst + k) = *reinterpret_cast<const uint2*>(hi);
+        *reinterpret_cast<uint2*>(dst + DP + k) = *reinterpret_cast<const uint2*>(lo);
+    }
+}
+
+struct SplitSlabs {                   // three stages per 64-element slab: Q planes hi, lo, hi against P planes hi, hi, lo
+    unsigned plane_bytes;
+    __device__ __forceinline__ int count(int Dh) const { return 3 * (Dh / WROW); }
+    __device__ __forceinline__ unsigned q(int kt) const { return (unsigned)((kt / 3) * WROW * 4) + ((kt % 3) == 1 ? plane_bytes : 0u); }
+    __device__ __forceinline__ unsigned p(int kt) const { return (unsigned)((kt / 3) * WROW * 4) + ((kt % 3) == 2 ? plane_bytes : 0u); }
+};
+
+struct KdWideEpilogue {
+    double gamma, coef0;
+    int degree, m;
+    const float* qun;           // unscale factors of the Q rows of this (subset, set)
+    float* aux;                 // LDS [256]
+    float pun[2];               // unscale factors of this lane's two P rows
+    int q0, p0;
+    bool drop_diag;
+    double sum;
+    float aux_v;
+    const WLane& L;
+    __device__ __forceinline__ KdWideEpilogue(const WLane& l) : L(l) {}
+    __device__ __forceinline__ void aux_issue(int, int64_t) {
+        if (L.tid < KW) aux_v = qun[q0 + L.tid];
+    }
+    __device__ __forceinline__ void aux_commit(int) {
+        if (L.tid < KW) aux[L.tid] = aux_v;
+    }
+    // degree 3 (kd.py:22, the only degree this form is built for: a run-time power loop per accumulator element makes the
+    // epilogue 128 small loops, and the register allocator then spills accumulators inside the MAIN loop)
+    __device__ __forceinline__ double kval(double dot) const {
+        const double base = dot * gamma + coef0;
+        return base * base * base;
+    }
+    // sums ALL 256 x 256 entries of the tile (padded rows give exactly kval(0) each: subtracted by the caller) and takes
+    // the valid diagonal entries of a diagonal Kxx / Kyy tile out again
+    __device__ __forceinline__ void finish(int, int64_t, f32x16 (&acc)[4][2]) {
+        const float* a = aux + L.wm * 128 + L.h * 4;
+        double s = 0.0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x4 qs[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) qs[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                double part = 0.0;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float dot = acc[mt][nt][reg] * (qs[reg >> 2][reg & 3] * pun[nt]);      // exact powers of two
+                    part += kval((double)dot);
+                }
+                s += part;
+                // (one accumulator tile at a time: left to itself the scheduler converts all 128 accumulators to f64 first
+                // and spills 170 registers)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (drop_diag && L.wm == (L.wn >> 1)) {          // wave-uniform: only waves whose 128 x 64 block meets the diagonal
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    if ((L.wn & 1) * 2 + nt != mt) continue;     // Q rows wm*128 + mt*32 + .. against P rows wn*64 + nt*32 + ..
+                    const float qsel[4] = {a[mt * 32 + 0], a[mt * 32 + 8], a[mt * 32 + 16], a[mt * 32 + 24]};
+                    (void)qsel;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int q = q0 + L.wm * 128 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * L.h;
+                        const int p = p0 + L.wn * 64 + nt * 32 + L.r;
+                        if (q == p && p < m) {
+                            const float dot = acc[mt][nt][reg] * (a[mt * 32 + (reg >> 2) * 8 + (reg & 3)] * pun[nt]);
+                            s -= kval((double)dot);
+                        }
+                    }
+                }
+        }
+        sum = s;
+    }
+};
+
+constexpr size_t KD_WIDE_LDS_BYTES = (WENGINE_LDS_WORDS + KW) * sizeof(float);
+
+__global__ void __launch_bounds__(WTHREADS, 1)
+kd_wide_kernel(const float* __restrict__ planes, const float* __restrict__ unscale, int DP, int m, int MP, int T, int ntri,
+               double gamma, double coef0, int degree, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const WLane L;
+    const int per_subset = 2 * ntri + T * T;
+    const int s = blockIdx.x / per_subset;
+    int b = blockIdx.x % per_subset;
+    int which, tq, tp;                       // which: 0 = XX, 1 = YY, 2 = XY
+    if (b < 2 * ntri) {
+        which = b / ntri;
+        int t = b % ntri;
+        tq = 0;
+        while (t >= T - tq) { t -= T - tq; ++tq; }
+        tp = tq + t;
+    } else {
+        which = 2;
+        b -= 2 * ntri;
+        tq = b / T;
+        tp = b % T;
+    }
+    // Kxy[a][b] = k(x_a, y_b): Q rows (register axis) from set 1 (X), P rows (lane axis) from set 2 (Y)
+    const int qset = which == 1 ? 1 : 0, pset = which == 0 ? 0 : 1;
+    const int64_t ldw = DP;                                              // words per row: two planes of DP f16
+    const float* Q = planes + ((int64_t)s * 2 + qset) * MP * ldw;
+    const float* P = planes + ((int64_t)s * 2 + pset) * MP * ldw;
+    KdWideEpilogue epi(L);
+    epi.gamma = gamma;
+    epi.coef0 = coef0;
+    epi.degree = degree;
+    epi.m = m;
+    epi.qun = unscale + ((int64_t)s * 2 + qset) * MP;
+    epi.aux = lds + WENGINE_LDS_WORDS;
+    epi.q0 = tq * KW;
+    epi.p0 = tp * KW;
+    epi.drop_diag = (which != 2) && (tq == tp);
+    epi.sum = 0.0;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) epi.pun[nt] = unscale[((int64_t)s * 2 + pset) * MP + tp * KW + L.wn * 64 + nt * 32 + L.r];
+    const SplitSlabs slabs{(unsigned)(DP * 2)};
+    wide_pipeline(Q, MP, ldw, WideSingleTile{tq}, P, MP, ldw, (int64_t)tp * KW, 1, DP / 2, lds, L, epi, slabs);
+    double v = epi.sum;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(lds);          // the engine's buffers are idle after the pipeline's last barrier
+    if (L.lane == 0) red[L.wave] = v;
+    __syncthreads();
+    if (L.tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 8; ++w) t += red[w];
+        const double w2 = (which != 2 && tq != tp) ? 2.0 : 1.0;   // symmetric blocks: count the mirrored tile too
+        const int vq = max(0, min(KW, m - tq * KW)), vp = max(0, min(KW, m - tp * KW));
+        const double pad = (double)(KW * KW - vq * vp) * epi.kval(0.0);
+        partial[blockIdx.x] = w2 * (t - pad);
+    }
+}
+
+static bool kd_wide_eligible(int S, int m, int D, int rbf, int degree = 3) {
+    (void)S;
+    return !rbf && degree == 3 && m >= 512 && D >= 128 && D <= 8192;   // (smaller: a subset is one or two tiles, the f32 form is as fast)
+}
+static size_t kd_wide_ws(int S, int m, int D) {
+    const int MP = (int)ceil_div(m, KW) * KW, DP = (int)ceil_div(D, 64) * 64, T = MP / KW;
+    Carver c(nullptr, 0);
+    c.take<double>((size_t)S * (T * (T + 1) + T * T));
+    c.take<uint16_t>((size_t)S * 2 * MP * 2 * DP);
+    c.take<float>((size_t)S * 2 * MP);
+    return c.off;
+}
+
 constexpr size_t KD_LDS_BYTES = ENGINE_LDS_FLOATS * sizeof(float);
 
 static int run_kd(const float* X, int64_t N1, int64_t ldx, const float* Y, int64_t N2, int64_t ldy, int D, const int64_t* idx1,
@@ -241,6 +451,27 @@ static int run_kd(const float* X, int64_t N1, int64_t ldx, const float* Y, int64
     AM_REQUIRE(m <= N1 && m <= N2, AM_ERR_BAD_SHAPE, "subset size %d exceeds a set size", m);
     AM_REQUIRE(aligned16(X) && aligned16(Y) && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= D && ldy >= D, AM_ERR_BAD_ARG,
                "X/Y must be 16-byte aligned with ld %% 4 == 0 and ld >= D");
+    if (kd_wide_eligible(S, m, D, rbf, degree)) {        // split-f16 form on the 256 x 256 engine
+        const int MP = (int)ceil_div(m, KW) * KW, DP = (int)ceil_div(D, 64) * 64, T = MP / KW;
+        const int ntri = T * (T + 1) / 2, per_subset = 2 * ntri + T * T;
+        Carver c(ws, ws_bytes);
+        double* partial = c.take<double>((size_t)S * per_subset);
+        uint16_t* planes = c.take<uint16_t>((size_t)S * 2 * MP * 2 * DP);
+        float* unscale = c.take<float>((size_t)S * 2 * MP);
+        if (c.ok()) {                                     // (a workspace sized by the D-less am_kd_workspace_bytes: f32 form below)
+        const int64_t rows = (int64_t)S * 2 * MP;
+        hipLaunchKernelGGL(kd_split_gather_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, X, ldx, Y, ldy, D, DP, idx1,
+                           idx2, S, m, MP, planes, unscale);
+        AM_LAUNCH_CHECK();
+        AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&kd_wide_kernel), (int)KD_WIDE_LDS_BYTES));
+        hipLaunchKernelGGL(kd_wide_kernel, dim3((unsigned)((int64_t)S * per_subset)), dim3(WTHREADS), KD_WIDE_LDS_BYTES, st,
+                           reinterpret_cast<const float*>(planes), unscale, DP, m, MP, T, ntri, gamma, coef0, degree, partial);
+        AM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(kd_finish_kernel, dim3((unsigned)ceil_div(S, 64)), dim3(64), 0, st, partial, S, m, T, ntri, out_mmd);
+        AM_LAUNCH_CHECK();
+        return AM_OK;
+        }
+    }
     const int T = (int)ceil_div(m, TB);
     const int ntri = T * (T + 1) / 2;
     const int per_subset = 2 * ntri + T * T;
@@ -288,11 +519,21 @@ static int run_kd(const float* X, int64_t N1, int64_t ldx, const float* Y, int64
 using namespace am;
 
 extern "C" size_t am_kd_workspace_bytes(int S, int m) {
+    // the f32 form's workspace (this query does not know the feature width; with it am_kd_poly_f32 runs the f32 kernel -
+    // am_kd_poly_workspace_bytes sizes the split-f16 form)
     if (S < 1 || m < 1) return 0;
     const int T = (int)ceil_div(m, TB);
     Carver c(nullptr, 0);
     c.take<double>((size_t)S * (T * (T + 1) + T * T));
     return c.off;
+}
+
+extern "C" size_t am_kd_poly_workspace_bytes(int S, int m, int D) {
+    if (S < 1 || m < 1 || D < 1) return 0;
+    const int T = (int)ceil_div(m, TB);
+    Carver c(nullptr, 0);
+    c.take<double>((size_t)S * (T * (T + 1) + T * T));
+    return std::max(c.off, kd_wide_eligible(S, m, D, 0) ? kd_wide_ws(S, m, D) : (size_t)0);
 }
 
 extern "C" int am_kd_poly_f32(const float* X, int64_t N1, int64_t ldx, const float* Y, int64_t N2, int64_t ldy, int D,

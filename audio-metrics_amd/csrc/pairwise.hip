@@ -1012,6 +1012,8 @@ static size_t carve_knn(Carver& c, int64_t N, int64_t M, const KnnPlan& p, KnnBu
     return c.off;
 }
 
+static size_t knn_rows_ws(int64_t N, int64_t M);      // workspace of the row-at-a-time kernel (k > AM_MAX_K), below
+
 extern "C" size_t am_knn_workspace_bytes(int64_t N, int64_t M, int D, int k) {
     if (N < 1 || M < 1 || D < 1 || k < 1 || (int64_t)k + 1 > M) return 0;
     if (k > AM_MAX_K) return knn_rows_ws(N, M);

@@ -92,11 +92,26 @@ __device__ __forceinline__ void wide_zero(f32x16 (&acc)[4][2]) {
 // as soon as ITS three fragments are back and the reads of the second chunk go out behind it.)
 // LDS safety: stage g+1 is written into the buffer that stage g-1 was read from; every wave has finished those reads
 // (s_waitcnt lgkmcnt(0) of __syncthreads) before the barrier that ends stage g-1, and the pieces are issued after it.
-template <class TileMap, class Epi>
+struct WideSingleTile {            // tile map of a workgroup that multiplies exactly one Q tile
+    int64_t q;
+    __device__ __forceinline__ int64_t operator()(int) const { return q; }
+};
+
+// KMap: which 128-byte slab of a row stage kt fetches, per operand (byte offset inside the row).  PlainSlabs walks a row
+// front to back; the kernel-distance kernel (kd.hip) lays two f16 planes side by side in a row and makes three stages
+// of every 64-element slab - (hi, hi), (lo, hi), (hi, lo) - so that the same pipeline accumulates a split-f16 product.
+struct PlainSlabs {
+    __device__ __forceinline__ int count(int Dh) const { return Dh / WROW; }
+    __device__ __forceinline__ unsigned q(int kt) const { return (unsigned)(kt * WROW * 4); }
+    __device__ __forceinline__ unsigned p(int kt) const { return (unsigned)(kt * WROW * 4); }
+};
+
+template <class TileMap, class Epi, class KMap = PlainSlabs>
 __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64_t nq, int64_t ldq, const TileMap& tmap,
                                               const float* __restrict__ P, int64_t np, int64_t ldp, int64_t prow0,
-                                              int ntiles, int Dh, float* __restrict__ lds, const WLane& L, Epi& epi) {
-    const int nk = Dh / WROW;
+                                              int ntiles, int Dh, float* __restrict__ lds, const WLane& L, Epi& epi,
+                                              const KMap& kmap = KMap()) {
+    const int nk = kmap.count(Dh);
     const int G = ntiles * nk;
     const int wave = __builtin_amdgcn_readfirstlane(L.wave);
     const int srow = L.tid >> 3;                                   // 0..63 (+64 j)
@@ -112,10 +127,9 @@ __device__ __forceinline__ void wide_pipeline(const float* __restrict__ Q, int64
     TileRsrc qrs = make_wide_rsrc(Q, ldq, nq, qtile_of(0) * WTB);
     // piece j of the stage being fetched into buffer `buf`: even j -> 64 Q rows, odd j -> 64 P rows
     auto piece = [&](int buf, int j) {
-        const unsigned so = (unsigned)(fkt * WROW * 4);
         float* s = lds + buf * WSTAGE_WORDS + wave * 8 * WROW;
-        if ((j & 1) == 0) lds_direct_b128(qrs, s + (j >> 1) * 64 * WROW, voq, so + (unsigned)(j >> 1) * gq);
-        else lds_direct_b128(prs, s + WTILE_WORDS + (j >> 1) * 64 * WROW, vop, so + (unsigned)(j >> 1) * gp);
+        if ((j & 1) == 0) lds_direct_b128(qrs, s + (j >> 1) * 64 * WROW, voq, kmap.q(fkt) + (unsigned)(j >> 1) * gq);
+        else lds_direct_b128(prs, s + WTILE_WORDS + (j >> 1) * 64 * WROW, vop, kmap.p(fkt) + (unsigned)(j >> 1) * gp);
     };
     auto advance_fetch = [&]() {
         if (++fkt == nk) {

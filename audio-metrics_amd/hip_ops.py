@@ -409,7 +409,7 @@ def kd_poly(x, y, idx1, idx2, gamma, coef0, degree):
     idx1, idx2 = _index_table(idx1, "idx1"), _index_table(idx2, "idx2")
     s, m = idx1.shape
     out = torch.empty(s, dtype=torch.float64, device=x.device)
-    nb = lib.am_kd_workspace_bytes(s, m)
+    nb = lib.am_kd_poly_workspace_bytes(s, m, x.shape[1])
     ws = _workspace(nb, x.device)
     _call(lib, "am_kd_poly_f32", x.device, _ptr(x), x.shape[0], _ld(x), _ptr(y), y.shape[0], _ld(y), x.shape[1],
                                   _ptr(idx1), _ptr(idx2), s, m, float(gamma), float(coef0), int(degree),

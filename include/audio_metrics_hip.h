@@ -138,7 +138,11 @@ double am_apa_f64(double d_y_x, double d_y_xp, double d_x_xp);
  *   Dot products in f32 on the matrix cores, kernel values and sums in f64.
  *   The index table is drawn by the caller (numpy PCG64, kd.py:176,185-186).
  * ------------------------------------------------------------------------- */
-size_t am_kd_workspace_bytes(int S, int m);
+size_t am_kd_workspace_bytes(int S, int m);               /* f32-MFMA form only                                         */
+size_t am_kd_poly_workspace_bytes(int S, int m, int D);   /* + the split-f16 form (m >= 512, D >= 128): three f16 MFMA
+                                                             stages per slab on two f16 planes of every gathered row,
+                                                             error of a dot product <= ~3 * 2^-22 |x||y|; am_kd_poly_f32
+                                                             takes it when the workspace has this size                  */
 int am_kd_poly_f32(const float* X, int64_t N1, int64_t ldx,
                    const float* Y, int64_t N2, int64_t ldy, int D,
                    const int64_t* idx1, const int64_t* idx2, int S, int m,
