@@ -2,15 +2,21 @@
 //   am_eigh_sym_f64   eigen-decomposition of the symmetric D x D Gram matrix of the stacked, centred batch
 //   am_project_f64    (x - mean) . components^T for an N x D f32 matrix
 //
-// Eigensolver: one-sided Jacobi (Hestenes) in f64.  W starts as A (rows = columns, A is symmetric), V as the identity;
-// a rotation of rows (p, q) makes W_p . W_q = 0 and is applied to V as well, so W = V A throughout.  At convergence the
-// rows of W are mutually orthogonal: rows of V are the eigenvectors and lambda_i = W_i . V_i (a Rayleigh quotient -
-// signed, unlike |W_i|).  Rounds follow the round-robin tournament: m/2 disjoint pairs per round, one workgroup per
-// pair, m - 1 rounds per sweep, launched back to back; the host reads one "rotations applied" counter per sweep.
-// D = 512: ~10 sweeps x 511 launches of 256 small workgroups, ~20 ms - the projection is fitted once per reference set,
-// not per evaluate.  All reductions run in a fixed order (deterministic).
+// Eigensolver: one-sided BLOCK Jacobi (Hestenes) in f64.  W starts as A (rows = columns, A is symmetric), V as the
+// identity; W = V A throughout.  At convergence the rows of W are mutually orthogonal: rows of V are the eigenvectors, and
+// the eigenvalue of row i is the Rayleigh quotient W_i . V_i (signed, unlike |W_i|).
+// Rows are grouped in blocks of 16.  A round pairs the blocks by the round-robin tournament (one workgroup per block
+// pair, mb - 1 rounds per sweep); a workgroup makes the 32 rows of its pair mutually orthogonal in one go:
+//   G = R R^T (32 x 32 Gram matrix of its W rows, on the f64 matrix cores), a two-sided cyclic Jacobi of G in LDS that
+//   accumulates the rotations into J (G is tiny: 31 x 16 rotations per inner sweep, no row-length work), then R <- J^T R
+//   for its rows of W and of V (f64 matrix cores again).
+// Round 2 rotated ONE row pair per workgroup and needed D - 1 = 511 launches of a latency-bound kernel per sweep (42 ms
+// at D = 512); here a sweep is 31 launches.  The rounds of several sweeps are enqueued ahead: a round kernel of sweep s
+// returns at once when sweep s - 1 applied no rotation (counter on the device), so the host synchronises once per block
+// of sweeps - normally once per solve - instead of once per sweep.  All reductions run in a fixed order (deterministic).
 #include "am_common.h"
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 
 namespace am {
@@ -37,51 +43,227 @@ __device__ __forceinline__ double block_sum3(double& a, double& b, double& c, do
     return a;
 }
 
-// W = A, V = I
-__global__ void __launch_bounds__(256) jacobi_init_kernel(const double* __restrict__ A, int n, double* __restrict__ W,
-                                                          double* __restrict__ V) {
+// rank[i] = position of row i when the rows of A are ordered by decreasing diagonal entry (ties by index).  One-sided
+// Jacobi converges in fewer sweeps when rows of similar norm sit together and the larger ones come first (de Rijk's
+// ordering); for the Gram matrices of a PCA fit the diagonal is a good proxy of the final row norms.
+__global__ void __launch_bounds__(256) jacobi_rank_kernel(const double* __restrict__ A, int n, int* __restrict__ rank) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double di = fabs(A[(int64_t)i * n + i]);
+    int before = 0;
+    for (int j = 0; j < n; ++j) {
+        const double dj = fabs(A[(int64_t)j * n + j]);
+        before += (dj > di || (dj == di && j < i)) ? 1 : 0;
+    }
+    rank[i] = before;
+}
+
+// W = P A, V = P (row rank[i] of W is row i of A)
+__global__ void __launch_bounds__(256) jacobi_init_kernel(const double* __restrict__ A, int n, const int* __restrict__ rank,
+                                                          double* __restrict__ W, double* __restrict__ V, double* __restrict__ scale) {
     const int64_t total = (int64_t)n * n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        W[i] = A[i];
-        V[i] = (i / n == i % n) ? 1.0 : 0.0;
+        const int row = (int)(i / n), col = (int)(i % n);
+        const int64_t o = (int64_t)rank[row] * n + col;
+        W[o] = A[i];
+        V[o] = row == col ? 1.0 : 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {        // trace A >= largest eigenvalue (A is positive semi-definite), fixed order
+        double t = 0.0;
+        for (int i = 0; i < n; ++i) t += fabs(A[(int64_t)i * n + i]);
+        *scale = t;
     }
 }
 
-// round `round` of the tournament over m = n rounded up to even players: pair i = (perm(i), perm(m - 1 - i)) with
-// perm(0) = m - 1 fixed and the others rotating; a player index >= n is a bye
-__global__ void __launch_bounds__(256) jacobi_round_kernel(double* __restrict__ W, double* __restrict__ V, int n, int m, int round,
-                                                           double tol, unsigned* __restrict__ rotations) {
-    __shared__ double red[4][3];
-    const int i = blockIdx.x;
-    auto player = [&](int slot) { return slot == 0 ? m - 1 : (slot - 1 + round) % (m - 1); };
-    int p = player(i), q = player(m - 1 - i);
-    if (p > q) { const int t = p; p = q; q = t; }
-    if (q >= n) return;
-    double* wp = W + (int64_t)p * n;
-    double* wq = W + (int64_t)q * n;
-    double alpha = 0, beta = 0, gamma = 0;
-    for (int k = threadIdx.x; k < n; k += 256) {
-        const double a = wp[k], b = wq[k];
-        alpha = fma(a, a, alpha);
-        beta = fma(b, b, beta);
-        gamma = fma(a, b, gamma);
+// 1 / sqrt(y) and 1 / y for positive normal y: hardware estimate + two Newton steps (quadratic: 2^-26 -> 2^-52)
+__device__ __forceinline__ double rsqrt_f64(double y) {
+    double r = __builtin_amdgcn_rsq(y);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = fma(-y * r, r, 1.0);          // 1 - y r^2
+        r = fma(r * 0.5, e, r);
     }
-    block_sum3(alpha, beta, gamma, red);
-    if (!(fabs(gamma) > tol * sqrt(alpha * beta))) return;          // already orthogonal (or a zero row)
-    const double zeta = (beta - alpha) / (2.0 * gamma);
-    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-    double* vp = V + (int64_t)p * n;
-    double* vq = V + (int64_t)q * n;
-    for (int k = threadIdx.x; k < n; k += 256) {
-        const double a = wp[k], b = wq[k];
-        wp[k] = c * a - s * b;
-        wq[k] = s * a + c * b;
-        const double x = vp[k], y = vq[k];
-        vp[k] = c * x - s * y;
-        vq[k] = s * x + c * y;
+    return r;
+}
+__device__ __forceinline__ double rcp_f64(double y) {
+    double r = __builtin_amdgcn_rcp(y);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) r = fma(fma(-y, r, 1.0), r, r);
+    return r;
+}
+
+constexpr int JB = 16;            // rows per block
+constexpr int JP = 2 * JB;        // rows a workgroup orthogonalises
+constexpr int JLD = JP + 1;       // LDS row stride of the 32 x 32 matrices (doubles)
+
+// round `round` of sweep `sweep`: block pair i = (player(i), player(mb - 1 - i)) of the tournament over mb = number of
+// blocks rounded up to even (player(0) = mb - 1 fixed, the others rotate); a block index >= nb is a bye
+__global__ void __launch_bounds__(256) jacobi_block_round_kernel(double* __restrict__ W, double* __restrict__ V, int n, int nb, int mb,
+                                                                 int round, int sweep, double tol, const double* __restrict__ scale,
+                                                                 unsigned* __restrict__ rotations) {
+    if (sweep > 0 && rotations[sweep - 1] == 0u) return;           // the previous sweep found every pair orthogonal: done
+    // rows whose squared norm is below (1e-14 trace A)^2 are numerically zero (null directions of a rank-deficient A: their
+    // content is rounding noise, whose mutual angles never settle - 3x the sweeps on a Gram matrix of D/3 rows)
+    const double floor2 = (1e-14 * *scale) * (1e-14 * *scale), tol2 = tol * tol;
+    __shared__ double G[JP][JLD], J[JP][JLD];
+    __shared__ int applied;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    auto player = [](int slot, int m, int r) { return slot == 0 ? m - 1 : (slot - 1 + r) % (m - 1); };
+    int bp = player(blockIdx.x, mb, round), bq = player(mb - 1 - blockIdx.x, mb, round);
+    if (bp > bq) { const int t = bp; bp = bq; bq = t; }
+    if (bp >= nb) return;
+    // local row r of the pair -> global row (or -1)
+    auto grow = [&](int r) {
+        const int b = r < JB ? bp : bq;
+        const int g = b * JB + (r & (JB - 1));
+        return (b < nb && g < n) ? g : -1;
+    };
+    // ---- 1. G = R R^T on v_mfma_f64_16x16x4_f64: wave w owns the 16 x 16 tile (w >> 1, w & 1)
+    {
+        const int ti = wave >> 1, tj = wave & 1;
+        const int ra = grow(ti * JB + l15), rb = grow(tj * JB + l15);
+        const double* wa = W + (int64_t)(ra < 0 ? 0 : ra) * n;
+        const double* wb = W + (int64_t)(rb < 0 ? 0 : rb) * n;
+        f64x4e acc = {0, 0, 0, 0};
+        // The sum over k may run in any order as long as both operands use the same one: lane (l15, l4) takes the four
+        // consecutive elements k0 + 4 l4 .. + 3 of its row per 16-element chunk (one 32-byte load per operand, 128 B per row
+        // and instruction), eight chunks in flight - a load-then-MFMA loop was one exposed L2 round trip per MFMA, 128 of
+        // them in a row: 60 of the 75 us of a round.
+        const bool vec = (n % 4) == 0;
+        for (int k0 = 0; k0 < n; k0 += 128) {
+            double av[8][4], bw[8][4];
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const int k = k0 + ch * 16 + l4 * 4;
+                if (vec && k + 3 < n) {
+                    const f64x4e a4 = ra >= 0 ? *reinterpret_cast<const f64x4e*>(wa + k) : f64x4e{0, 0, 0, 0};
+                    const f64x4e b4 = rb >= 0 ? *reinterpret_cast<const f64x4e*>(wb + k) : f64x4e{0, 0, 0, 0};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { av[ch][j] = a4[j]; bw[ch][j] = b4[j]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        av[ch][j] = (ra >= 0 && k + j < n) ? wa[k + j] : 0.0;
+                        bw[ch][j] = (rb >= 0 && k + j < n) ? wb[k + j] : 0.0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ch][j], bw[ch][j], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) G[ti * JB + l4 + 4 * r][tj * JB + l15] = acc[r];       // C layout: row = (lane >> 4) + 4 reg, column = lane & 15
     }
-    if (threadIdx.x == 0) atomicAdd(rotations, 1u);
+    for (int e = tid; e < JP * JP; e += 256) J[e / JP][e % JP] = (e / JP == e % JP) ? 1.0 : 0.0;
+    __syncthreads();
+    // ---- 2. two-sided cyclic Jacobi of G in LDS, rotations accumulated in J.  Thread group g = tid >> 4 (16 threads of
+    //         one wave) owns the index pair g of the inner round; thread l of it the columns / rows l and l + 16.
+    // ONE inner sweep per visit: the pair's rows meet again in the next outer sweep, and a full diagonalisation of G here
+    // (5-8 inner sweeps while the off-diagonal mass is large) costs more than the outer sweeps it saves - measured 54 ms
+    // against 7 at D = 512.  An inner round is latency-bound (three dependent LDS round trips, an f64 sqrt / divide chain,
+    // two barriers): ~0.45 us.
+    const int grp = tid >> 4, l = tid & 15;
+    bool any_first = false;
+    for (int isweep = 0; isweep < 1; ++isweep) {
+        if (tid == 0) applied = 0;
+        __syncthreads();
+        for (int ir = 0; ir < JP - 1; ++ir) {
+            int p = player(grp, JP, ir), q = player(JP - 1 - grp, JP, ir);
+            if (p > q) { const int t = p; p = q; q = t; }
+            const double gpp = G[p][p], gqq = G[q][q], gpq = G[p][q];
+            double c = 1.0, sn = 0.0;
+            if (gpq * gpq > tol2 * (gpp * gqq) && fmin(gpp, gqq) > floor2) {      // not yet orthogonal, neither row (numerically) zero
+                // t = tan(theta) = sign(d) 2 g_pq / (|d| + sqrt(d^2 + 4 g_pq^2)), d = g_qq - g_pp; c = 1 / sqrt(1 + t^2); s = c t.
+                // The library sqrt and divide are ~200-cycle sequences each and this chain sits between two barriers 31 times
+                // per visit: hardware reciprocal (square root) estimates with two Newton steps instead (full f64 accuracy:
+                // c^2 + s^2 = 1 to 1e-16, which is what keeps V orthonormal).
+                const double d = gqq - gpp, g2 = 2.0 * gpq;
+                const double y = fma(d, d, g2 * g2);
+                const double h = y * rsqrt_f64(y);
+                const double t = (d >= 0 ? g2 : -g2) * rcp_f64(fabs(d) + h);
+                c = rsqrt_f64(fma(t, t, 1.0));
+                sn = c * t;
+                if (l == 0) applied = 1;
+            }
+            // rows p, q (the 16 threads of a group sit in one wave: all of them have read the three entries above before any
+            // of them writes; other groups never write these three)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = l + 16 * h;
+                const double a = G[p][k], b = G[q][k];
+                G[p][k] = c * a - sn * b;
+                G[q][k] = sn * a + c * b;
+            }
+            __syncthreads();
+            // columns p, q of G and of J
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = l + 16 * h;
+                const double a = G[k][p], b = G[k][q];
+                G[k][p] = c * a - sn * b;
+                G[k][q] = sn * a + c * b;
+                const double x = J[k][p], y = J[k][q];
+                J[k][p] = c * x - sn * y;
+                J[k][q] = sn * x + c * y;
+            }
+            __syncthreads();
+        }
+        const bool again = applied != 0;
+        if (isweep == 0) any_first = again;
+        __syncthreads();
+        if (!again) break;
+    }
+    if (!any_first) return;                                          // the 32 rows were orthogonal already: nothing to apply
+    if (tid == 0) atomicAdd(rotations + sweep, 1u);
+    // ---- 3. rows <- J^T rows for W and V: out[r'][c] = sum_r J[r][r'] in[r][c].  A wave takes 16-column strips; it loads the
+    //         strip's 32 x 16 block (eight k-steps of four rows), forms both 16-row output tiles, stores them back.
+    // (four strips per pass: 32 loads in flight and eight independent MFMA chains instead of one strip's 8 and 2)
+    const int strips = (n + 15) / 16;
+    for (int st0 = wave * 4; st0 < 2 * strips; st0 += 16) {
+        double bv[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int st = st0 + u;
+            const double* M = st < strips ? W : V;
+            const int c = (st % strips) * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int g = grow(ks * 4 + l4);
+                bv[u][ks] = (st < 2 * strips && g >= 0 && c < n) ? M[(int64_t)g * n + c] : 0.0;
+            }
+        }
+        f64x4e acc[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int to = 0; to < 2; ++to) acc[u][to] = f64x4e{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const double j0 = J[ks * 4 + l4][l15], j1 = J[ks * 4 + l4][JB + l15];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(j0, bv[u][ks], acc[u][0], 0, 0, 0);
+                acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(j1, bv[u][ks], acc[u][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int st = st0 + u;
+            if (st >= 2 * strips) continue;
+            double* M = st < strips ? W : V;
+            const int c = (st % strips) * 16 + l15;
+#pragma unroll
+            for (int to = 0; to < 2; ++to)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int g = grow(to * JB + l4 + 4 * r);
+                    if (g >= 0 && c < n) M[(int64_t)g * n + c] = acc[u][to][r];
+                }
+        }
+    }
 }
 
 // lambda_i = W_i . V_i
@@ -157,6 +339,8 @@ extern "C" size_t am_eigh_workspace_bytes(int D) {
     c.take<double>((size_t)D * D);     // V
     c.take<double>((size_t)D);         // lambda (unsorted)
     c.take<unsigned>(64);              // rotation counters, one per sweep
+    c.take<double>(1);                 // trace of A
+    c.take<int>(D);                    // initial row order
     return c.off;
 }
 
@@ -171,22 +355,37 @@ extern "C" int am_eigh_sym_f64(const double* A, int D, double* evals, double* ev
     double* V = c.take<double>((size_t)D * D);
     double* lambda = c.take<double>((size_t)D);
     unsigned* rotations = c.take<unsigned>(64);
+    double* scale = c.take<double>(1);
+    int* rank = c.take<int>(D);
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    hipLaunchKernelGGL(jacobi_rank_kernel, dim3((unsigned)ceil_div(D, 256)), dim3(256), 0, st, A, D, rank);
     hipLaunchKernelGGL(jacobi_init_kernel, dim3((unsigned)std::min<int64_t>(1024, ceil_div((int64_t)D * D, 256))), dim3(256), 0, st, A, D,
-                       W, V);
+                       rank, W, V, scale);
     AM_LAUNCH_CHECK();
     AM_HIP_TRY(hipMemsetAsync(rotations, 0, 64 * sizeof(unsigned), st));
-    const int m = (D + 1) / 2 * 2;
+    const int nb = (D + JB - 1) / JB, mb = (nb + 1) / 2 * 2;
     const double tol = 1e-14 * sqrt((double)D);       // |W_p . W_q| <= tol |W_p| |W_q|: the rounding level of a D-term f64 dot product
-    bool converged = D == 1;
-    for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
-        for (int round = 0; round < m - 1; ++round)
-            hipLaunchKernelGGL(jacobi_round_kernel, dim3(m / 2), dim3(256), 0, st, W, V, D, m, round, tol, rotations + sweep);
+    // Sweeps are enqueued in blocks; a round kernel returns at once when the sweep before it applied no rotation, so
+    // running ahead costs only empty launches.  One read-back per block: normally one per solve.
+    bool converged = false;
+    unsigned counts[64];
+    for (int done = 0; done < max_sweeps && !converged;) {
+        const int block = std::min(done == 0 ? 12 : 6, max_sweeps - done);
+        for (int sweep = done; sweep < done + block; ++sweep)
+            for (int round = 0; round < mb - 1; ++round)
+                hipLaunchKernelGGL(jacobi_block_round_kernel, dim3(mb / 2), dim3(256), 0, st, W, V, D, nb, mb, round, sweep, tol, scale, rotations);
         AM_LAUNCH_CHECK();
-        unsigned applied = 0;
-        AM_HIP_TRY(hipMemcpyAsync(&applied, rotations + sweep, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        done += block;
+        AM_HIP_TRY(hipMemcpyAsync(counts, rotations, (size_t)done * sizeof(unsigned), hipMemcpyDeviceToHost, st));
         AM_HIP_TRY(hipStreamSynchronize(st));
-        converged = applied == 0;
+        for (int sweep = 0; sweep < done; ++sweep) converged = converged || counts[sweep] == 0u;
+#ifdef AM_DEV_KNOBS
+        if (getenv("AM_EIGH_DEBUG")) {                 // block pairs that rotated, per sweep (development aid)
+            fprintf(stderr, "[am eigh] D=%d sweeps enqueued %d:", D, done);
+            for (int sweep = 0; sweep < done; ++sweep) fprintf(stderr, " %u", counts[sweep]);
+            fprintf(stderr, "\n");
+        }
+#endif
     }
     AM_REQUIRE(converged, AM_ERR_NO_CONVERGENCE, "Jacobi eigensolver: rows still not orthogonal after %d sweeps", max_sweeps);
     hipLaunchKernelGGL(jacobi_values_kernel, dim3(D), dim3(256), 0, st, W, V, D, lambda);
