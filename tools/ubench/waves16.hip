@@ -1,0 +1,119 @@
+// Microbenchmark: does a 256 x 256 x 64 stage run faster with SIXTEEN waves per CU (1024-thread workgroup, four waves per
+// SIMD, 64 accumulator registers per wave) than with the wide engine's eight?  Same bytes through the LDS-DMA path (64 KB
+// per stage), same 256 MFMAs (v_mfma_f32_32x32x16_f16) per stage and CU, same vmcnt(0) + barrier per stage; fragment reads
+// from LDS included (ds_read_b128: 6 per 8 MFMAs with eight waves - 4 x 2 MFMA tiles per wave -, 4 per 4 with sixteen -
+// 2 x 2 tiles).  Double-buffered: the DMA of stage g + 1 is issued before the MFMAs of stage g.
+// Build: hipcc --offload-arch=gfx950 -O3 waves16.hip -o waves16 ; run: ./waves16
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int ROWS = 512, ROWB = 128;                 // stage = 512 rows x 128 B = 64 KB
+constexpr int STAGE_WORDS = ROWS * ROWB / 4;
+
+template <int NW>                                      // waves per workgroup: 8 or 16
+__global__ void __launch_bounds__(NW * 64, 1) stage_kernel(const float* __restrict__ src, int64_t src_rows, int ld_words, int stages,
+                                                           int interleave, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int PIECES = 64 / NW;                    // DMA instructions per wave and stage (1 KB each)
+    constexpr int MT = NW == 8 ? 4 : 2, NT = 2;        // MFMA tiles per wave: 4 x 2 (128 x 64) or 2 x 2 (64 x 64)
+    const int srow = lane >> 3, chunk = lane & 7;      // a piece = 8 rows x 128 B
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i][n][j] = 0.f;
+    const int64_t nblk = src_rows / ROWS;
+    // fragment rows of this wave inside the stage: Q rows 0..255, P rows 256..511
+    const int wm = NW == 8 ? wave >> 2 : wave >> 2, wn = wave & 3;     // 8 waves: 2 x 4 of (128 x 64); 16 waves: 4 x 4 of (64 x 64)
+    const int r = lane & 31, h = lane >> 5;
+    const int qrow = (wm * (MT * 32) + r) * 32, prow = (256 + wn * 64 + r) * 32;
+    auto issue = [&](int g) {
+        const int64_t blk = ((int64_t)blockIdx.x * 7 + (g >> 3) * 13) % nblk;
+        const int kslab = g & 7;
+        const float* base = src + (blk * ROWS) * (int64_t)ld_words + kslab * 32;
+        float* st = lds + (g & 1) * STAGE_WORDS;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(ROWS * ld_words * 4 - kslab * 128), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int row0 = (j * NW + wave) * 8;
+            const unsigned vo = (unsigned)(((row0 + srow) * ld_words + chunk * 4) * 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(st + row0 * 32), 16, (int)vo, 0, 0, 0);
+        }
+    };
+    issue(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int g = 0; g < stages; ++g) {
+        const float* st = lds + (g & 1) * STAGE_WORDS;
+        if (!interleave) issue(g + 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                  // four k16 chunks of the 64-deep slab
+            f32x4 q[MT], p[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) p[n] = *reinterpret_cast<const f32x4*>(st + prow + n * 32 * 32 + ((2 * c + h) ^ ((r >> 1) & 7)) * 4);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) q[m] = *reinterpret_cast<const f32x4*>(st + qrow + m * 32 * 32 + ((2 * c + h) ^ ((r >> 1) & 7)) * 4);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, q[m]), __builtin_bit_cast(f16x8, p[n]), acc[m][n], 0, 0, 0);
+            if (interleave && c == 0) issue(g + 1);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0)
+        __syncthreads();
+    }
+    float sink = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) sink += acc[i][n][3];
+    if (sink == 12345.678f) out[0] = sink;
+}
+
+template <int NW>
+static void run(const float* src, int64_t rows, int ld_words, float* out, int src_mb) {
+    const int stages = 4096;
+    hipFuncSetAttribute((const void*)stage_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_WORDS * 4);
+    for (int interleave : {0, 1}) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL(stage_kernel<NW>, dim3(256), dim3(NW * 64), 2 * STAGE_WORDS * 4, 0, src, rows, ld_words, 64, interleave, out);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(stage_kernel<NW>, dim3(256), dim3(NW * 64), 2 * STAGE_WORDS * 4, 0, src, rows, ld_words, stages, interleave, out);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        const double us_stage = ms * 1e3 / stages;
+        printf("src %3d MB, %2d waves, DMA %s: %.3f us per stage = %.2f PF (256 x 256 x 64 per CU and stage)\n", src_mb, NW,
+               interleave ? "after the first chunk" : "at the top", us_stage, 2.0 * 256 * 256 * 64 * 256 / us_stage * 1e-9);
+    }
+}
+
+int main() {
+    for (int src_mb : {16, 200}) {
+        const int ld_words = 256;                                     // 1 KB rows (D = 512 f16)
+        const int64_t rows = (int64_t)src_mb * 1024 * 1024 / 1024;
+        float *src, *out;
+        hipMalloc(&src, rows * 1024);
+        hipMalloc(&out, 4);
+        // random-ish f16 payload (power matters: constant operands clock higher)
+        uint32_t* hsrc = (uint32_t*)malloc(rows * 1024);
+        uint32_t s = 12345u;
+        for (int64_t i = 0; i < rows * 256; ++i) { s = s * 1664525u + 1013904223u; hsrc[i] = (s & 0x3fff3fffu) | 0x30003000u; }
+        hipMemcpy(src, hsrc, rows * 1024, hipMemcpyHostToDevice);
+        free(hsrc);
+        run<8>(src, rows, ld_words, out, src_mb);
+        run<16>(src, rows, ld_words, out, src_mb);
+        hipFree(src); hipFree(out);
+    }
+    return 0;
+}
