@@ -134,9 +134,8 @@ def local_rows(data, group=None):
     return rows
 
 
-def global_stats_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group):
-    """((mean, cov) of the reference, (mean, cov) of the candidate) of two row-sharded sets: two all-reduces in all
-    (SURVEY section 5: one fused buffer per phase)."""
+def global_means_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group):
+    """Means of two row-sharded sets: local column sums of both in ONE all-reduce (8 KB)."""
     d = ref_local.shape[1]
     dev = ref_local.device
 
@@ -145,14 +144,28 @@ def global_stats_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group):
 
     sums = torch.stack((colsum(ref_local), colsum(cand_local)))                 # [2, D]
     _all_reduce(sums, world, group)
-    mean_r, mean_c = sums[0] / float(n_ref), sums[1] / float(n_cand)
+    return sums[0] / float(n_ref), sums[1] / float(n_cand)
+
+
+def global_covariances_pair(ref_local, cand_local, mean_r, mean_c, n_ref, n_cand, ops, world, group):
+    """Covariances of two row-sharded sets around the global means: local centred scatters of both in ONE all-reduce (4 MB)."""
+    d = ref_local.shape[1]
+    dev = ref_local.device
 
     def scatter(x, mean):
         return ops.scatter(x, mean) if x.shape[0] > 0 else torch.zeros((d, d), dtype=torch.float64, device=dev)
 
     sc = torch.stack((scatter(ref_local, mean_r), scatter(cand_local, mean_c)))  # [2, D, D]
     _all_reduce(sc, world, group)
-    return (mean_r, sc[0] / float(max(n_ref - 1, 1))), (mean_c, sc[1] / float(max(n_cand - 1, 1)))
+    return sc[0] / float(max(n_ref - 1, 1)), sc[1] / float(max(n_cand - 1, 1))
+
+
+def global_stats_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group):
+    """((mean, cov) of the reference, (mean, cov) of the candidate) of two row-sharded sets: two all-reduces in all
+    (SURVEY section 5: one fused buffer per phase)."""
+    mean_r, mean_c = global_means_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group)
+    cov_r, cov_c = global_covariances_pair(ref_local, cand_local, mean_r, mean_c, n_ref, n_cand, ops, world, group)
+    return (mean_r, cov_r), (mean_c, cov_c)
 
 
 class _Stats:
@@ -306,18 +319,25 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
         raise ValueError(f"empty embedding set: {n_ref} reference and {n_cand} candidate rows over {world} ranks")
     d = ref_local.shape[1]
 
-    # 1) the big exchange first: the gathered copies are only needed after the statistics, so the transfer
-    #    (410 MB at 2 x 100k x 512) runs under the statistics kernels
+    # 1) the 8 KB column-sum all-reduce goes FIRST: the collectives of one process group run in issue order on one
+    #    communication stream, so anything issued behind the 410 MB gather waits for all of it - and the centred scatter
+    #    kernels need the global means.  2) the big exchange is started (asynchronously).  3) the scatter kernels run on
+    #    the compute stream while the gather is in flight; their 4 MB all-reduce queues behind it, which is fine: only the
+    #    Frechet solve on the side stream waits for it.
     need_full = ("kd" in metrics) or ("prdc" in metrics)
+    means = None
+    if "fad" in metrics:
+        means = global_means_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group)
     if need_full:
         ref_g = _Gathered(ref_local, ref_counts, world, group)
         cand_g = _Gathered(cand_local, cand_counts, world, group)
 
-    # 2) statistics; the Frechet solve goes to a side stream right away (its stopping rule runs on the device, so
-    #    the host just enqueues it) and overlaps the PRDC chain issued next
+    # statistics; the Frechet solve goes to a side stream right away (its stopping rule runs on the device, so
+    # the host just enqueues it) and overlaps the PRDC chain issued next
     fad_job = None
     if "fad" in metrics:
-        (mu_r, cov_r), (mu_c, cov_c) = global_stats_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group)
+        mu_r, mu_c = means
+        cov_r, cov_c = global_covariances_pair(ref_local, cand_local, mu_r, mu_c, n_ref, n_cand, ops, world, group)
         starter = getattr(ops, "frechet_async", None)
         fad_job = starter(mu_c, cov_c, mu_r, cov_r) if starter is not None else None
 
