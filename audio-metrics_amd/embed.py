@@ -206,6 +206,89 @@ def batches_of(tagged_windows, batch_size=32, ring=0, guards=None):
         yield emit()
 
 
+def rendered_batches(source, batch_size=32, ring=4, guards=None):
+    """``batches_of(source, ...)`` with the copy into the batch buffer done by the worker that mixed the window: a job
+    knows its (batch, row) position when it is created - jobs are numbered in emission order - so the consumer thread only
+    hands out rows and collects finished batches.  (Copying 32 x 960 KB per batch on the consumer thread was a third of
+    the pipeline's wall time once mixing itself ran on the pool.)  Stems-only streams (nothing to mix) and window streams
+    of mixed shapes / dtypes fall back to ``batches_of``."""
+    if source.apa_mode is None:
+        yield from batches_of(source, batch_size, ring=ring, guards=guards)
+        return
+    workers = source.mix_workers
+    lookahead = 2 * max(workers, 1) + 2
+    buffers = []                                   # ring of [batch_size, n] arrays
+    state = {"shape": None, "dtype": None}
+
+    def buffer_for(batch_no, n, dtype):
+        slot = batch_no % ring
+        if slot >= len(buffers):
+            buffers.append(np.empty((batch_size, n), dtype=dtype))
+        return slot, buffers[slot]
+
+    def render_into(job, dst):
+        category, samples = source._render(job)
+        samples = np.asarray(samples)
+        if samples.shape != dst.shape or samples.dtype != dst.dtype:
+            raise _ShapeChanged()
+        t0 = time.perf_counter()
+        np.copyto(dst, samples)
+        _tick("batch_copy_in_workers", t0)
+        return int(category)
+
+    class _ShapeChanged(Exception):
+        pass
+
+    pool = ThreadPoolExecutor(max_workers=max(workers, 1), thread_name_prefix="am-mix")
+    try:
+        pending = deque()                          # (future, batch number, row)
+        tags, count, batch_no = [], 0, 0
+        current_slot = None
+
+        def finish_batch(rows_in_batch, slot):
+            batch = {"audio": buffers[slot][:rows_in_batch], "category": np.array(tags[:rows_in_batch]), "_slot": slot}
+            del tags[:rows_in_batch]
+            return batch
+
+        def drain(limit):
+            # collect finished jobs in order until at most `limit` are pending; yields complete batches
+            nonlocal count
+            while len(pending) > limit:
+                fut, bno, row = pending.popleft()
+                t0 = time.perf_counter()
+                tags.append(fut.result())
+                _tick("mix_wait", t0)
+                if row == batch_size - 1:
+                    yield finish_batch(batch_size, bno % ring)
+
+        row = 0
+        for job in source._jobs():
+            window = job[1]
+            n, dtype = window.shape[0], window.dtype
+            if state["shape"] is None:
+                state["shape"], state["dtype"] = n, dtype
+            elif (n, dtype) != (state["shape"], state["dtype"]):
+                raise ValueError("windows of different lengths or dtypes in one stream")
+            if row == 0:
+                # the buffer this batch goes to may still be read by the device copy of the batch that used it `ring` batches ago
+                slot = batch_no % ring
+                guard = guards.pop(slot, None) if guards is not None else None
+                if guard is not None:
+                    guard.synchronize()
+                # and every job writing to it must have been collected (they have: ring > batches in flight in `pending`)
+            slot, buf = buffer_for(batch_no, n, dtype)
+            pending.append((pool.submit(render_into, job, buf[row]), batch_no, row))
+            row += 1
+            if row == batch_size:
+                row, batch_no = 0, batch_no + 1
+            yield from drain(lookahead)
+        yield from drain(0)
+        if row:                                    # the last, partial batch
+            yield finish_batch(row, batch_no % ring)
+    finally:
+        pool.shutdown(wait=True, cancel_futures=True)
+
+
 class CategoryAggregator:
     """Owns one device's ``AudioMetricsData`` per wanted category and files embedder outputs into them."""
 
@@ -375,4 +458,6 @@ def embedding_pipeline(waveforms, embedder, mix_function, gpu_handler=None, apa_
             device = home if home.type == "cuda" else default_device()
         pool = EmbedderPool(embedder, [device])
     pool.guards = {}
-    return pool.run(batches_of(source, batch_size, ring=pool.batches_in_flight() + 1, guards=pool.guards), wanted)
+    # ring: batches alive downstream + the batches the mix workers are still writing into (lookahead / batch_size, rounded up)
+    ring = pool.batches_in_flight() + 2 + (2 * source.mix_workers + 2 + batch_size - 1) // batch_size
+    return pool.run(rendered_batches(source, batch_size, ring=ring, guards=pool.guards), wanted)
