@@ -296,24 +296,34 @@ def evaluate_single(ref, cand, metrics, nearest_k, ops, kid_subsets=KID_SUBSETS,
 
 
 def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), nearest_k=5, group=None, ops=None,
-                     kid_subsets=KID_SUBSETS, kid_subset_size=KID_SUBSET_SIZE, rng_seed=1234, fused=True):
+                     kid_subsets=KID_SUBSETS, kid_subset_size=KID_SUBSET_SIZE, rng_seed=1234, fused=True, shard_counts=None):
     """FAD / KD / PRDC of (candidate vs reference) from this rank's row shards.
     Returns the same keys as ``AudioMetrics.evaluate`` on every rank.  With one rank the whole chain is one library
-    call (``evaluate_single``); fused=False keeps the entry points separate there too (per-entry timing in bench.py)."""
+    call (``evaluate_single``); fused=False keeps the entry points separate there too (per-entry timing in bench.py).
+    shard_counts = ([reference rows of rank 0, 1, ...], [candidate rows ...]) when the caller knows how the rows are dealt
+    (a fixed sharding rule): saves the count all-gather and its read-back, the only host synchronisation at the start of a
+    step."""
     if ops is None:
         from . import hip_ops as ops
     world, rank = _world(group)
     dev = ref_local.device
     if world == 1 and fused and hasattr(ops, "evaluate"):
         return evaluate_single(ref_local, cand_local, metrics, nearest_k, ops, kid_subsets, kid_subset_size, rng_seed)
-    if world > 1:
+    if shard_counts is not None:
+        ref_counts, cand_counts = [int(c) for c in shard_counts[0]], [int(c) for c in shard_counts[1]]
+        if len(ref_counts) != world or len(cand_counts) != world or ref_counts[rank] != ref_local.shape[0] \
+                or cand_counts[rank] != cand_local.shape[0]:
+            raise ValueError("shard_counts do not describe this process group's shards")
+        allc = None
+    elif world > 1:
         counts = torch.tensor([ref_local.shape[0], cand_local.shape[0]], dtype=torch.int64, device=dev)
         allc = torch.empty(world * 2, dtype=torch.int64, device=dev)
         _all_gather_into(allc, counts, world, group)
         allc = allc.view(world, 2).cpu().tolist()
     else:
         allc = [[ref_local.shape[0], cand_local.shape[0]]]
-    ref_counts, cand_counts = [c[0] for c in allc], [c[1] for c in allc]
+    if allc is not None:
+        ref_counts, cand_counts = [c[0] for c in allc], [c[1] for c in allc]
     n_ref, n_cand = sum(ref_counts), sum(cand_counts)
     if n_ref == 0 or n_cand == 0:                          # the same error on every rank (all of them hold the totals)
         raise ValueError(f"empty embedding set: {n_ref} reference and {n_cand} candidate rows over {world} ranks")
@@ -382,20 +392,33 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
         _all_reduce(mmds, world, group)
         kd_pending = mmds
 
+    # ONE read-back for everything that is already on the device: per-subset MMD^2 values, PRDC totals (the Frechet record
+    # lives on the side stream and is read by its own job - five doubles - after the side stream has been waited for)
+    pieces, layout = [], []
+    if kd_pending is not None:
+        pieces.append(kd_pending)
+        layout.append(("kd", kd_pending.numel()))
+    if prdc_pending is not None:
+        tot, rows, k = prdc_pending
+        pieces += [tot.to(torch.float64), rows.to(torch.float64)]          # exact: integer counts far below 2^53
+        layout += [("tot", tot.numel()), ("rows", rows.numel())]
+    host = torch.cat(pieces).cpu().numpy() if pieces else None
+    got, at = {}, 0
+    for name, count in layout:
+        got[name] = host[at:at + count]
+        at += count
     result = {}
     if fad_job is not None:
         result["fad"] = fad_job.result()["fd"]
     elif "fad" in metrics:
         result["fad"] = ops.frechet(mu_c, cov_c, mu_r, cov_r)["fd"]
     if kd_pending is not None:
-        mm = kd_pending.cpu().numpy()
+        mm = got["kd"]
         result["kernel_distance_mean"] = float(np.mean(mm))
         result["kernel_distance_std"] = float(np.std(mm))
     if prdc_pending is not None:
-        tot, rows, k = prdc_pending
-        tot, rows = tot.cpu().tolist(), rows.cpu().tolist()
-        n_prec, sum_cnt = int(tot[0]), int(tot[2])
-        n_rec, n_cov = int(rows[0]), int(rows[1])
+        n_prec, sum_cnt = int(got["tot"][0]), int(got["tot"][2])
+        n_rec, n_cov = int(got["rows"][0]), int(got["rows"][1])
         result.update(precision=n_prec / n_cand, recall=n_rec / n_ref,
-                      density=(1.0 / float(k)) * (sum_cnt / n_cand), coverage=n_cov / n_ref)
+                      density=(1.0 / float(prdc_pending[2])) * (sum_cnt / n_cand), coverage=n_cov / n_ref)
     return result

@@ -233,8 +233,11 @@ def main():
     ref, cand = make_sets(args.data)
     ref_l, cand_l = ref[lo:hi], cand[lo:hi]              # this rank's row shard (as its embedder would produce)
 
+    # the sharding rule is fixed (shard_bounds), so every rank knows every shard's size: no count exchange per step
+    shard_counts = ([shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0] for r in range(world)],) * 2
+
     def step():
-        return evaluate_sharded(ref_l, cand_l, metrics=("fad", "kd", "prdc"), nearest_k=k)
+        return evaluate_sharded(ref_l, cand_l, metrics=("fad", "kd", "prdc"), nearest_k=k, shard_counts=shard_counts)
 
     # ---- the timed region: K plain steps, nothing else (no event brackets, no statistics kernels)
     for _ in range(args.warmup):

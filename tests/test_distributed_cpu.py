@@ -35,6 +35,12 @@ def _worker(rank, world, port, n_ref, n_cand, d, k, out_q):
     cl, ch = shard_bounds(n_cand, world, rank)
     res = evaluate_sharded(torch.as_tensor(ref[rl:rh]), torch.as_tensor(cand[cl:ch]), nearest_k=k, ops=cpu_ops,
                            kid_subsets=6, kid_subset_size=200)
+    # the same with the shard sizes handed in (no count exchange): identical result
+    counts = ([shard_bounds(n_ref, world, r)[1] - shard_bounds(n_ref, world, r)[0] for r in range(world)],
+              [shard_bounds(n_cand, world, r)[1] - shard_bounds(n_cand, world, r)[0] for r in range(world)])
+    again = evaluate_sharded(torch.as_tensor(ref[rl:rh]), torch.as_tensor(cand[cl:ch]), nearest_k=k, ops=cpu_ops,
+                             kid_subsets=6, kid_subset_size=200, shard_counts=counts)
+    assert again == res, (again, res)
     out_q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
