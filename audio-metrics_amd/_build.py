@@ -1,5 +1,7 @@
 """Build the gfx950 C-ABI library in-tree with hipcc (cross-compiles without a GPU)."""
 import glob
+import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -28,13 +30,39 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def is_stale(lib_path=LIB_PATH):
-    if not os.path.exists(lib_path):
+def _inputs():
+    return sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + \
+        sorted(glob.glob(os.path.join(os.path.dirname(PKG_DIR), "include", "*.h")))
+
+
+def source_digest(extra=()):
+    """sha256 over the CONTENT of every source, header and flag that goes into a library: what decides whether a built
+    .so still belongs to the tree (modification times do not survive a checkout or a copy to another machine)."""
+    h = hashlib.sha256()
+    for flag in (*HIPCC_FLAGS, *extra):
+        h.update(flag.encode() + b"\0")
+    for path in _inputs():
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stamp_path(lib_path):
+    return lib_path + ".stamp.json"
+
+
+def is_stale(lib_path=LIB_PATH, extra=None):
+    """True when the library is missing or was built from other sources / flags than the tree holds now."""
+    if extra is None:
+        extra = ("-DAM_DEV_KNOBS",) if lib_path == DEV_LIB_PATH else ()
+    if not os.path.exists(lib_path) or not os.path.exists(_stamp_path(lib_path)):
         return True
-    t = os.path.getmtime(lib_path)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
-        glob.glob(os.path.join(os.path.dirname(PKG_DIR), "include", "*.h"))
-    return any(os.path.getmtime(p) > t for p in deps)
+    try:
+        with open(_stamp_path(lib_path)) as f:
+            return json.load(f).get("sources_sha256") != source_digest(extra)
+    except (OSError, ValueError):
+        return True
 
 
 def _start_objects(hipcc, obj_dir, extra):
@@ -47,7 +75,7 @@ def _start_objects(hipcc, obj_dir, extra):
     return procs
 
 
-def _finish(hipcc, procs, lib_path, verbose):
+def _finish(hipcc, procs, lib_path, verbose, extra=()):
     objs = []
     for cmd, obj, p in procs:
         out, _ = p.communicate()
@@ -60,6 +88,8 @@ def _finish(hipcc, procs, lib_path, verbose):
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed: %s\n%s" % (" ".join(link), r.stdout))
+    with open(_stamp_path(lib_path), "w") as f:
+        json.dump({"sources_sha256": source_digest(extra), "flags": [*HIPCC_FLAGS, *extra]}, f)
     return lib_path
 
 
@@ -70,11 +100,11 @@ def build_library(force=False, verbose=False, dev=True):
     hipcc = _hipcc()
     jobs = []
     if force or is_stale(LIB_PATH):
-        jobs.append((_start_objects(hipcc, os.path.join(LIB_DIR, "obj"), []), LIB_PATH))
+        jobs.append((_start_objects(hipcc, os.path.join(LIB_DIR, "obj"), []), LIB_PATH, ()))
     if dev and (force or is_stale(DEV_LIB_PATH)):
-        jobs.append((_start_objects(hipcc, os.path.join(LIB_DIR, "obj_dev"), ["-DAM_DEV_KNOBS"]), DEV_LIB_PATH))
-    for procs, path in jobs:
-        _finish(hipcc, procs, path, verbose)
+        jobs.append((_start_objects(hipcc, os.path.join(LIB_DIR, "obj_dev"), ["-DAM_DEV_KNOBS"]), DEV_LIB_PATH, ("-DAM_DEV_KNOBS",)))
+    for procs, path, extra in jobs:
+        _finish(hipcc, procs, path, verbose, extra)
     return LIB_PATH
 
 

@@ -35,6 +35,13 @@ def pytest_collection_modifyitems(config, items):
         if not os.path.exists(lib):
             raise pytest.UsageError(f"an MI355X is visible but {lib} has not been built: run `python __graft_entry__.py build` "
                                     "(the GPU parity tests are not skipped for a missing library)")
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("am_build", os.path.join(ROOT, "audio-metrics_amd", "_build.py"))
+        build = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(build)
+        if build.is_stale(build.LIB_PATH):
+            raise pytest.UsageError(f"{lib} was built from other sources than this tree holds (content hash in its .stamp.json): "
+                                    "run `python __graft_entry__.py build` - parity results of a stale library mean nothing")
         return
     skip = pytest.mark.skip(reason="needs an MI355X (torch.cuda.is_available() is False)")
     for item in gpu_items:
