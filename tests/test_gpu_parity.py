@@ -111,6 +111,18 @@ def test_knn_beyond_the_list_kernels_bit_exact(am, k):
             assert abs(got[key] - want[key]) <= max(REL * abs(want[key]), 2.0 / 650), (key, got[key], want[key])
 
 
+@pytest.mark.parametrize("k", [16, 20, 31])
+def test_knn_long_lists_on_mid_sized_sets_bit_exact(am, k):
+    """k + 1 > 16 at 8192 <= N < 32768 (no f16 filter sweep yet): the exact symmetric kernel would need 32 list registers
+    per row and lane and spills - such shapes take the general kernel (am_knn_path == 0); same bits as the C model."""
+    from oracle import exact
+    x = gi.randn(65, 9000, 128)
+    assert am.hip_ops.knn_path(9000, 9000, 128, k) == 0
+    assert am.hip_ops.knn_path(9000, 9000, 128, 15) == 1            # up to 16 slots: still the symmetric kernel
+    r = am.nearest_neighbour_distances(dev(x), k).cpu().numpy()
+    assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, k).view(np.uint32))
+
+
 def test_knn_rows_vs_other_columns(am):
     """row shard against a larger column set (the multi-GPU calling pattern)."""
     from oracle import exact
