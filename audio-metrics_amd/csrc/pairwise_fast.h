@@ -1128,7 +1128,13 @@ __global__ void knn_fast_select_kernel(const float* __restrict__ cand, const int
 
 static bool knn_fast_enabled(int64_t N, int D) {
     static const int on = env_int("AM_KNN_FAST", 1);
-    static const int min_rows = env_int("AM_KNN_FAST_MIN_ROWS", 32768);   // below: the exact symmetric kernel is faster (measured)
+    // Below: the exact kernels are faster.  Measured in round 3 (tools/size_sweep.py, k = 5, cold PRDC of two sets): the f16
+    // filter sweep wins from ~6000 rows at D = 512 (1.01 -> 0.74 ms at 6000, 3.6 -> 1.5 ms at 16 000, 11.2 -> 3.7 ms at 32 000)
+    // and from ~8000 rows at D = 128 (0.80 -> 0.71 ms at 8192, 4.0 -> 2.1 ms at 32 000).  Rounds 1-2 switched at 32 768 rows, a
+    // threshold measured on the 128-row engine before the 256-row engine, the queue pruning and the prepared sets existed:
+    // the sizes most evaluations have (8k - 32k clips) ran up to 3x slower than necessary.
+    static const int min_rows_env = env_int("AM_KNN_FAST_MIN_ROWS", 0);
+    const int64_t min_rows = min_rows_env > 0 ? min_rows_env : (D >= 256 ? 6144 : 8192);
     return on != 0 && N >= min_rows && D >= 32 && D <= FAST_MAX_DIM && N < ((int64_t)1 << 31);
 }
 

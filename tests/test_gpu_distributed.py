@@ -79,12 +79,13 @@ def test_sharded_evaluate_with_hip_kernels(n_ref, n_cand):
     assert abs(am.frechet_distance(a, b) - single["fad"]) <= 1e-5 * abs(single["fad"])
 
 
-@pytest.mark.parametrize("nparts,k,rows,path", [(2, 5, 9100, 1), (3, 10, 9100, 1), (8, 5, 9100, 1),
-                                                (2, 5, 33100, 3), (5, 10, 33100, 3)])
+@pytest.mark.parametrize("nparts,k,rows,path", [(2, 5, 9100, 3), (3, 10, 9100, 3), (8, 5, 9100, 3),
+                                                (2, 5, 33100, 3), (5, 10, 33100, 3), (3, 20, 9100, 2)])
 def test_partitioned_symmetric_knn_bit_identical(nparts, k, rows, path):
     """The multi-GPU form of the symmetric k-NN, emulated on one GPU: every part computed in turn, lists
-    stacked as the all-gather would, then merged - bit-identical to the single-GPU result.  9100 rows take the
-    exact symmetric kernel (path 1), 33100 rows the f16 filter sweep on the 256-row engine + exact verification (path 3)."""
+    stacked as the all-gather would, then merged - bit-identical to the single-GPU result.  Both sizes take the f16 filter
+    sweep + exact verification (path 3 on the 256-row engine; k = 20 needs 32-slot lists: the 128-row engine, path 2); the
+    partitioned form of the EXACT symmetric kernel is covered by test_partitioned_exact_symmetric_kernel below."""
     import numpy as np
     from audio_metrics_amd import hip_ops as ops
     x = torch.as_tensor(gi.randn(97, rows, 136)).to("cuda:0")
@@ -102,6 +103,31 @@ def test_partitioned_symmetric_knn_bit_identical(nparts, k, rows, path):
     lists[nparts - 1, 4000, 0] = float("nan")
     got = ops.knn_lists_finish(lists, x, k).cpu().numpy()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_partitioned_exact_symmetric_kernel():
+    """The partitioned form of the exact symmetric kernel (what the library takes where the f16 filter sweep does not apply:
+    D > 4096, or the A/B build with AM_KNN_FAST=0) - in a subprocess, the knob is process-wide."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests', 'golden')!r})\n"
+        "import inputs as gi\n"
+        "from audio_metrics_amd import hip_ops as ops\n"
+        "x = torch.as_tensor(gi.randn(97, 9100, 136)).to('cuda:0')\n"
+        "n, k = x.shape[0], 5\n"
+        "assert ops.knn_path(n, n, 136, k) == 1 and ops.knn_sym_eligible(n, 136, k)\n"
+        "want = ops.knn_radii(x, k).cpu().numpy()\n"
+        "for nparts in (2, 3, 8):\n"
+        "    bounds = torch.cat([ops.knn_bounds(x, k, n * p // nparts, n * (p + 1) // nparts - n * p // nparts) for p in range(nparts)])\n"
+        "    lists = torch.stack([ops.knn_sym_part(x, k, p, nparts, bounds) for p in range(nparts)])\n"
+        "    got = ops.knn_lists_finish(lists, x, k).cpu().numpy()\n"
+        "    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), nparts\n"
+        "print('partitioned exact ok')\n")
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AM_HIP_LIBRARY="dev", AM_KNN_FAST="0"),
+                         capture_output=True, text=True, timeout=600)
+    assert "partitioned exact ok" in res.stdout, res.stdout + res.stderr
 
 
 def test_sharded_evaluate_takes_symmetric_path():

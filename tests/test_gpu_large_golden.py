@@ -1,5 +1,5 @@
 """The PRODUCTION form of the PRDC kernels - the f16 filter sweeps on the 256 x 256 engine with exact f32 verification,
-taken from 32768 rows up (am_knn_path == am_prdc_path == 3) - against
+the path of every set of >= 6144 / 8192 rows (am_knn_path == am_prdc_path == 3) - against
 
   (a) outputs of the REFERENCE itself at sizes it can still run (tests/golden/prdc_large.npz, written by
       tests/golden/make_goldens.py prdc_large from /root/reference/src/audio_metrics/metrics/prdc.py:4-50): radii within

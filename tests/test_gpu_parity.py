@@ -113,12 +113,13 @@ def test_knn_beyond_the_list_kernels_bit_exact(am, k):
 
 @pytest.mark.parametrize("k", [16, 20, 31])
 def test_knn_long_lists_on_mid_sized_sets_bit_exact(am, k):
-    """k + 1 > 16 at 8192 <= N < 32768 (no f16 filter sweep yet): the exact symmetric kernel would need 32 list registers
-    per row and lane and spills - such shapes take the general kernel (am_knn_path == 0); same bits as the C model."""
+    """k + 1 > 16 below the f16 filter sweep's threshold: the exact symmetric kernel would need 32 list registers per row
+    and lane and spills - such shapes take the general kernel (am_knn_path == 0); same bits as the C model."""
     from oracle import exact
-    x = gi.randn(65, 9000, 128)
-    assert am.hip_ops.knn_path(9000, 9000, 128, k) == 0
-    assert am.hip_ops.knn_path(9000, 9000, 128, 15) == 1            # up to 16 slots: still the symmetric kernel
+    x = gi.randn(65, 7000, 128)
+    assert am.hip_ops.knn_path(7000, 7000, 128, k) == 0
+    assert am.hip_ops.knn_path(9000, 9000, 128, k) == 2             # with the f16 filter sweep the lists only steer: 128-row engine
+    assert am.hip_ops.knn_path(9000, 9000, 128, 10) == 3
     r = am.nearest_neighbour_distances(dev(x), k).cpu().numpy()
     assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, k).view(np.uint32))
 
@@ -428,9 +429,10 @@ def test_knn_symmetric_fallbacks_agree():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = dict(os.environ, AB_ROWS="9000", AB_DIM="160", AB_K="5", AB_REPS="1")
     outs = []
+    exact = {"AM_KNN_FAST": "0"}                      # the exact kernels (9000 x 160 takes the f16 filter path since round 3)
     fast = {"AM_KNN_FAST_MIN_ROWS": "1000"}           # the f16 filter + exact verification path (pairwise_fast.h)
-    for extra in ({"AM_KNN_SYM_MIN_ROWS": "100000000"}, {}, {"AM_KNN_SYM_CAP": "2"}, {"AM_KNN_SYM_QCAP": "16"},
-                  fast, dict(fast, AM_KNN_SYM_CAP="2"), dict(fast, AM_KNN_SYM_QCAP="16"),
+    for extra in (dict(exact, AM_KNN_SYM_MIN_ROWS="100000000"), exact, dict(exact, AM_KNN_SYM_CAP="2"), dict(exact, AM_KNN_SYM_QCAP="16"),
+                  {}, fast, dict(fast, AM_KNN_SYM_CAP="2"), dict(fast, AM_KNN_SYM_QCAP="16"),
                   dict(fast, AM_KNN_SYM_QCAP="16", AM_KNN_FAST_OVCAP="64")):
         res = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_knn.py")], env=knob_env(base, extra),
                              capture_output=True, text=True, timeout=600)
