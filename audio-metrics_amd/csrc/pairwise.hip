@@ -924,7 +924,7 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
     p.kcap = kcap_for(k + 1);
     // the mirrored-candidate machinery costs per PAIR, the saved MFMA work scales with D: worth it for
     // wide embeddings and enough rows (measured crossover, tools/ab_knn.py)
-    p.sym = self && D >= sym_min_dim && N >= 2 * TB && (N >= sym_min || knn_fast_enabled(N, D));
+    p.sym = self && N >= 2 * TB && ((D >= sym_min_dim && N >= sym_min) || knn_fast_enabled(N, D));
     // k + 1 > 16 needs 32 list registers per row and lane: the exact symmetric kernel then spills 1.4 KB per lane and runs
     // 4x SLOWER than the general kernel (measured: 19.7 vs 5.2 ms at 20 000 x 512, 432 vs 91 ms at 100 000 x 512, k = 16 / 20 /
     // 31) - such k take the symmetric plan only where it leads to the f16 filter sweep (whose lists only steer)

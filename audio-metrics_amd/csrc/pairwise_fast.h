@@ -1133,8 +1133,10 @@ static bool knn_fast_enabled(int64_t N, int D) {
     // and from ~8000 rows at D = 128 (0.80 -> 0.71 ms at 8192, 4.0 -> 2.1 ms at 32 000).  Rounds 1-2 switched at 32 768 rows, a
     // threshold measured on the 128-row engine before the 256-row engine, the queue pruning and the prepared sets existed:
     // the sizes most evaluations have (8k - 32k clips) ran up to 3x slower than necessary.
+    // Narrow rows (32 <= D < 128: what n_pca leaves) were excluded altogether ("the saved MFMA work scales with D"): from
+    // 16 384 rows the sweep wins there too - 8.3 -> 2.9 ms at 50 000 x 64, 29.2 -> 7.8 ms at 100 000 x 64, break-even at 16 000.
     static const int min_rows_env = env_int("AM_KNN_FAST_MIN_ROWS", 0);
-    const int64_t min_rows = min_rows_env > 0 ? min_rows_env : (D >= 256 ? 6144 : 8192);
+    const int64_t min_rows = min_rows_env > 0 ? min_rows_env : (D >= 256 ? 6144 : D >= 128 ? 8192 : 16384);
     return on != 0 && N >= min_rows && D >= 32 && D <= FAST_MAX_DIM && N < ((int64_t)1 << 31);
 }
 

@@ -173,7 +173,7 @@ int am_kd_rbf_f32(const float* X, int64_t N1, int64_t ldx,
  *   Distances follow torch.cdist's matmul form  sqrt(max(|x|^2+|y|^2-2x.y, 0))
  *   in f32; no N x M matrix is materialised.  1 <= k, k+1 <= M (k > AM_MAX_K: one row at a time on the vector ALUs,
  *   same values; a correctness path - the reference's evaluate() caps k at 10).
- *   Y == X with >= 6144 rows (D >= 256) / 8192 rows (128 <= D < 256), D <= 4096, runs as a scaled-f16 MFMA FILTER sweep over half of the tile pairs
+ *   Y == X with >= 6144 rows (D >= 256) / 8192 rows (128 <= D < 256) / 16384 rows (32 <= D < 128), D <= 4096, runs as a scaled-f16 MFMA FILTER sweep over half of the tile pairs
  *   followed by an f32 evaluation - with the arithmetic of the exact kernel - of the pairs its error bound cannot
  *   rule out (csrc/pairwise_fast.h): the radii are bit-identical to the exact kernels', which remain the path for
  *   the other shapes and the automatic per-row fallback.

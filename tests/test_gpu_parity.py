@@ -124,6 +124,23 @@ def test_knn_long_lists_on_mid_sized_sets_bit_exact(am, k):
     assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, k).view(np.uint32))
 
 
+@pytest.mark.parametrize("n,d,k", [(17000, 64, 5), (16400, 40, 10), (6200, 256, 5), (8300, 130, 3)])
+def test_knn_filter_sweep_at_its_lower_thresholds_bit_exact(am, n, d, k):
+    """The f16 filter sweep + exact verification just above the row counts where it takes over (round 3: 6144 rows for
+    D >= 256, 8192 for 128 <= D < 256, 16 384 for the narrow rows n_pca leaves) - radii bit-identical to the C model of the exact
+    arithmetic, no row falls back."""
+    from oracle import exact
+    ops = am.hip_ops
+    x = gi.randn(66, n, d)
+    assert ops.knn_path(n, n, d, k) == 3
+    ops.filter_stats_enable("cuda:0", True)
+    r = am.nearest_neighbour_distances(dev(x), k).cpu().numpy()
+    stats = ops.filter_stats_read("cuda:0")
+    ops.filter_stats_enable("cuda:0", False)
+    assert stats["knn_calls"] == 1 and stats["knn_fallback_rows"] == 0, stats
+    assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, k).view(np.uint32))
+
+
 def test_knn_rows_vs_other_columns(am):
     """row shard against a larger column set (the multi-GPU calling pattern)."""
     from oracle import exact

@@ -12,8 +12,10 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(n_cases):
-    rows = rnd.choice([6200, 8200, 9001, 12000, 20000, 33000, 34567, 40000, 47001, 52000, 65536, 81000, 100000])
-    dim = rnd.choice([64, 67, 96, 128, 130, 200, 256, 257, 384, 512])
+    rows = rnd.choice([int(v) for v in os.environ["FUZZ_ROWS"].split(",")] if os.environ.get("FUZZ_ROWS") else
+                      [6200, 8200, 9001, 12000, 20000, 33000, 34567, 40000, 47001, 52000, 65536, 81000, 100000])
+    dim = rnd.choice([int(v) for v in os.environ["FUZZ_DIMS"].split(",")] if os.environ.get("FUZZ_DIMS") else
+                     [64, 67, 96, 128, 130, 200, 256, 257, 384, 512])
     k = rnd.choice([1, 3, 5, 8, 10])
     data = rnd.choice(os.environ.get("FUZZ_DATA", "randn,clustered,scales,lowrank,unit,dups").split(","))
     rows2 = rnd.choice([rows, rows, max(600, rows // 7), min(100000, rows * 2), 3001])      # candidate rows (membership only)
