@@ -300,8 +300,8 @@ int64_t wide_grouped_blocks(int64_t row_blocks, int nchunks, int grp_rows);
 int launch_cross_wide(bool want_min, unsigned blocks, const float* Rb, int64_t Nr, int64_t ldr, const float* rnorm, const float* rthr,
                       const float* Cb, int64_t Nc, int64_t ldc, const float* cnorm, const float* cthr, int Dh, int nchunks,
                       int grp_rows, const unsigned* maxn, unsigned* rmin_approx, unsigned* row_any, unsigned* row_cover,
-                      int32_t* col_count, uint2* wgq, int qcap, int* wgq_count, uint2* ovq, int* ov_count, int ovcap, int* fail,
-                      float fc, hipStream_t st);
+                      int32_t* col_count, uint2* wgq, int qcap, int* wgq_count, uint2* items, uint2* ovq, int* ov_count, int ovcap,
+                      int* fail, float fc, hipStream_t st);
 int launch_cross_wide_sample(const float* Rb, int64_t Nr, int64_t ldr, const float* rnorm, const float* Cb, int64_t Nc, int64_t ldc,
                              const float* cnorm, const float* cthr, int Dh, int stride, int nchunks, const unsigned* maxn,
                              unsigned* row_any, float fc, hipStream_t st);

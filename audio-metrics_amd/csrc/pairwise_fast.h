@@ -441,40 +441,92 @@ __device__ __forceinline__ void cross_apply(float t, int64_t j, unsigned jflag, 
     }
 }
 
-// exact evaluation of the regions of cross_wide_kernel: one queued pair per thread, both rows from global memory
+// Exact dot products of 64 pairs, one per lane, with COALESCED row fetches (shared by the two verification kernels).
+// A wave takes 64 pairs at a time.  Its 128 rows are fetched in 128-byte pieces (8 lanes per row piece, 8 rows per load
+// instruction) into the wave's own LDS tile, then lane p reads the two pieces of pair p back and runs the 32 products of the
+// chain in the exact engine's order 8c+s, 8c+4+s (row stride 36 floats: the reads are bank-conflict free).  One 16-byte load
+// per lane and row - the first version of both kernels - makes every load instruction touch 64 different cache lines: the
+// texture-address unit, not the memory, then bounds the kernel (4.4x slower per pair, measured on the membership queue of
+// the CLAP-shaped sets: 1.2 ms for 0.96 M pairs against 0.31 ms for 0.74 M in the k-NN verification).
+constexpr int VERIFY_LD = 36;                                       // floats per 32-float piece in LDS
+constexpr size_t VERIFY_LDS_BYTES = (size_t)4 * 128 * VERIFY_LD * sizeof(float);   // 4 waves x 128 rows
+
+// ia / ib: this lane's row of A / of B (any valid row for lanes without a pair); tile: the wave's 128 x VERIFY_LD floats
+__device__ __forceinline__ float wave_pair_dot(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                               unsigned ia, unsigned ib, int D, float* tile, int lane) {
+    const int dp = (D + 7) / 8 * 8;
+    const int grp = lane >> 3, slot = lane & 7;
+    // the row this lane fetches in load instruction rr: tile row rr * 8 + grp (rows 0..63: A rows of the pairs, 64..127: B rows)
+    const float* src[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int trow = rr * 8 + grp;
+        const unsigned idx = (unsigned)__shfl((int)(trow < 64 ? ia : ib), trow & 63);
+        src[rr] = trow < 64 ? A + (int64_t)idx * lda : B + (int64_t)idx * ldb;
+    }
+    float acc = 0.f;
+    f32x4 piece[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) piece[rr] = load_k4(src[rr], slot * 4, D);
+    for (int c = 0; c < dp; c += 32) {
+        __builtin_amdgcn_wave_barrier();                         // the previous piece has been consumed (same wave: LDS ops stay in order)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr)
+            *reinterpret_cast<f32x4*>(tile + (rr * 8 + grp) * VERIFY_LD + slot * 4) = piece[rr];
+        if (c + 32 < dp) {                                       // the next piece is on its way while this one is multiplied
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) piece[rr] = load_k4(src[rr], c + 32 + slot * 4, D);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float* ua = tile + lane * VERIFY_LD;
+        const float* va = tile + (64 + lane) * VERIFY_LD;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(ua + 4 * q), u1 = *reinterpret_cast<const f32x4*>(ua + 4 * q + 4);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(va + 4 * q), v1 = *reinterpret_cast<const f32x4*>(va + 4 * q + 4);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                acc = fmaf(v0[s2], u0[s2], acc);
+                acc = fmaf(v1[s2], u1[s2], acc);
+            }
+        }
+    }
+    return acc;
+}
+
+// exact evaluation of the regions of cross_wide_kernel: a wave takes 64 queued pairs at a time (wave_pair_dot).  The work
+// items (region, first entry) were listed by the filter kernel itself, so the grid is the same for ten entries per region
+// (independent sets: one workgroup per region would leave three of four waves and most of the LDS idle) and for thousands.
+constexpr unsigned CROSS_VERIFY_GRID = 1024;
 __global__ void __launch_bounds__(256) cross_verify_regions_kernel(const float* __restrict__ R, int64_t ldr,
                                                                    const float* __restrict__ rnorm, const float* __restrict__ rthr,
                                                                    const float* __restrict__ C, int64_t ldc,
                                                                    const float* __restrict__ cnorm, const float* __restrict__ cthr,
                                                                    int D, const uint2* __restrict__ wgq, int qcap,
-                                                                   const int* __restrict__ wgq_count, int32_t* __restrict__ col_count,
+                                                                   const int* __restrict__ wgq_count, const uint2* __restrict__ items,
+                                                                   const int* __restrict__ item_count, int32_t* __restrict__ col_count,
                                                                    unsigned* __restrict__ row_min_bits,
                                                                    unsigned* __restrict__ row_any, unsigned* __restrict__ row_cover) {
-    const int n = wgq_count[blockIdx.x];
-    const uint2* q = wgq + (int64_t)blockIdx.x * qcap;
-    const int dp = (D + 7) / 8 * 8;
-    for (int e = threadIdx.x; e < n; e += 256) {
-        const uint2 v = q[e];
-        const int64_t i = v.x, j = v.y & ~FAST_COUNTED;
-        const float* x = R + i * ldr;
-        const float* y = C + j * ldc;
-        float acc = 0.f;
-        for (int c = 0; c < dp; c += 8) {
-            const f32x4 y0 = load_k4(y, c, D), y1 = load_k4(y, c + 4, D);
-            const f32x4 x0 = load_k4(x, c, D), x1 = load_k4(x, c + 4, D);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc = fmaf(y0[s], x0[s], acc);
-                acc = fmaf(y1[s], x1[s], acc);
-            }
+    extern __shared__ __attribute__((aligned(16))) float vlds[];
+    const int nitems = *item_count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* tile = vlds + wave * 128 * VERIFY_LD;
+    for (int it = blockIdx.x * 4 + wave; it < nitems; it += gridDim.x * 4) {      // (wave-uniform: every lane of a wave takes part)
+        const uint2 item = items[it];
+        const int e = (int)item.y + lane;
+        const bool valid = e < wgq_count[item.x];
+        const uint2 v = valid ? wgq[(int64_t)item.x * qcap + e] : make_uint2(0u, 0u);
+        const unsigned i = v.x, j = v.y & ~FAST_COUNTED;
+        const float acc = wave_pair_dot(R, ldr, C, ldc, i, j, D, tile, lane);
+        if (valid) {
+            const float t = fmaxf(fmaf(-2.f, acc, rnorm[i] + cnorm[j]), 0.f);
+            float mn = INFINITY;
+            bool any = false, cov = false;
+            cross_apply(t, j, v.y, rthr[i], cthr, col_count, mn, any, cov);
+            if (row_min_bits != nullptr) atomicMin(row_min_bits + i, __float_as_uint(mn));
+            if (any) atomicOr(row_any + i, 1u);
+            if (cov) atomicOr(row_cover + i, 1u);
         }
-        const float t = fmaxf(fmaf(-2.f, acc, rnorm[i] + cnorm[j]), 0.f);
-        float mn = INFINITY;
-        bool any = false, cov = false;
-        cross_apply(t, j, v.y, rthr[i], cthr, col_count, mn, any, cov);
-        if (row_min_bits != nullptr) atomicMin(row_min_bits + i, __float_as_uint(mn));
-        if (any) atomicOr(row_any + i, 1u);
-        if (cov) atomicOr(row_cover + i, 1u);
     }
 }
 
@@ -656,8 +708,8 @@ static CrossFastPlan plan_cross_fast(int64_t Nr, int64_t Nc) {
 struct CrossFastBuffers {
     uint16_t *rb, *cb;
     unsigned *maxn, *rmin_approx;
-    uint2 *wgq, *ovq;
-    int *wgq_count, *ov_count;      // ov_count[0] = overflow entries, ov_count[1] = fail flag
+    uint2 *wgq, *ovq, *items;       // items: (region, first entry) per batch of 64 entries (wide path)
+    int *wgq_count, *ov_count;      // ov_count[0] = overflow entries, ov_count[1] = fail flag, ov_count[2] = number of items
 };
 
 static CrossFastBuffers carve_cross_fast(Carver& c, int64_t Nr, int64_t Nc, int D, const CrossFastPlan& p) {
@@ -668,6 +720,7 @@ static CrossFastBuffers carve_cross_fast(Carver& c, int64_t Nr, int64_t Nc, int 
     b.rmin_approx = c.take<unsigned>(Nr);
     b.wgq = c.take<uint2>((size_t)p.blocks * p.qcap);
     b.ovq = c.take<uint2>((size_t)p.ovcap);
+    b.items = c.take<uint2>((size_t)p.blocks * ((p.qcap + 63) / 64));
     b.wgq_count = c.take<int>(p.blocks);
     b.ov_count = c.take<int>(4);
     return b;
@@ -743,13 +796,14 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
     if (p.wide) {
         clock_begin(AM_KERNEL_PRDC_CROSS, st);
         if ((rc = launch_cross_wide(want_min, (unsigned)p.blocks, Rb, Nr, ldb / 2, rn, rt, Cb, Nc, ldb / 2, cn, ct, Dh, p.nchunks,
-                                    p.grp_rows, b.maxn, b.rmin_approx, rany, rcov, col_count, b.wgq, p.qcap, b.wgq_count, b.ovq,
-                                    b.ov_count, p.ovcap, fail, fast_c(D), st)) != AM_OK)
+                                    p.grp_rows, b.maxn, b.rmin_approx, rany, rcov, col_count, b.wgq, p.qcap, b.wgq_count, b.items,
+                                    b.ovq, b.ov_count, p.ovcap, fail, fast_c(D), st)) != AM_OK)
             return rc;
         clock_end(AM_KERNEL_PRDC_CROSS, st);
         clock_begin(AM_KERNEL_PRDC_VERIFY, st);
-        hipLaunchKernelGGL(cross_verify_regions_kernel, dim3((unsigned)p.blocks), dim3(256), 0, st, R, ldr, rn, rt, C, ldc, cn, ct, D,
-                           b.wgq, p.qcap, b.wgq_count, col_count, rmin_or_null, rany, rcov);
+        AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&cross_verify_regions_kernel), (int)VERIFY_LDS_BYTES));
+        hipLaunchKernelGGL(cross_verify_regions_kernel, dim3(CROSS_VERIFY_GRID), dim3(256), VERIFY_LDS_BYTES, st, R, ldr, rn, rt, C, ldc,
+                           cn, ct, D, b.wgq, p.qcap, b.wgq_count, b.items, b.ov_count + 2, col_count, rmin_or_null, rany, rcov);
         clock_end(AM_KERNEL_PRDC_VERIFY, st);
     } else {
         clock_begin(AM_KERNEL_PRDC_CROSS, st);
@@ -1023,22 +1077,13 @@ __global__ void __launch_bounds__(256) knn_fast_prune_kernel(const float* __rest
         if (fv[s] <= thr) pairs[at++] = make_uint2((unsigned)i, fi[s]);
 }
 
-// One pair per lane; each lane walks its two rows with the exact engine's
-// fmaf chain (t(a,b) == t(b,a) bit for bit: products commute and the inner order is the same).  Consecutive pairs
-// share their first row (the list is written row by row), so those reads coalesce; the partner rows come from L2 /
-// Infinity Cache.
+// One pair per lane, 64 pairs per wave at a time (wave_pair_dot): the exact engine's fmaf chain (t(a,b) == t(b,a) bit for
+// bit: products commute and the inner order is the same).  Consecutive pairs share their first row (the list is written
+// row by row); the partner rows come from L2 / Infinity Cache.
 __device__ __forceinline__ void knn_file(float* __restrict__ cand, int* __restrict__ cnt, int cap, int64_t row, float t) {
     const int slot = atomicAdd(cnt + row, 1);
     if (slot < cap) cand[row * (int64_t)cap + slot] = t;
 }
-
-// A wave takes 64 pairs at a time.  Its 128 rows are fetched in 128-byte pieces with COALESCED loads (8 lanes per row
-// piece, 8 rows per instruction) into the wave's own LDS tile, then lane p reads the two pieces of pair p back and runs
-// the 32 products of the chain (row stride 36 floats: the reads are bank-conflict free).  One 16-byte load per lane and
-// row, as in the first version of this kernel, makes every load instruction touch 64 different cache lines: the
-// texture-address unit, not the memory, then bounds the kernel (0.30 ms for 92 k pairs on a 1/8 share).
-constexpr int VERIFY_LD = 36;                                       // floats per 32-float piece in LDS
-constexpr size_t VERIFY_LDS_BYTES = (size_t)4 * 128 * VERIFY_LD * sizeof(float);   // 4 waves x 128 rows
 
 __global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __restrict__ X, int64_t ld,
                                                               const float* __restrict__ xnorm, int D,
@@ -1047,46 +1092,14 @@ __global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __res
                                                               int cap) {
     extern __shared__ __attribute__((aligned(16))) float vlds[];
     const int n = min(*pair_count, pair_cap);
-    const int dp = (D + 7) / 8 * 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* tile = vlds + wave * 128 * VERIFY_LD;                     // rows 0..63: first rows of the pairs, 64..127: second rows
-    const int grp = lane >> 3, slot = lane & 7;
     for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64; base < n; base += (int64_t)gridDim.x * 256) {
         const int64_t e = base + lane;
         uint2 p = e < n ? pairs[e] : make_uint2(FAST_HOLE, 0u);
         const bool hole = p.x == FAST_HOLE;
         if (hole) p = make_uint2(0u, 0u);
-        // the row this lane fetches in load instruction rr: tile row rr * 8 + grp
-        const float* src[16];
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int trow = rr * 8 + grp;
-            const unsigned idx = (unsigned)__shfl((int)(trow < 64 ? p.x : p.y), trow & 63);
-            src[rr] = X + (int64_t)idx * ld;
-        }
-        float acc = 0.f;
-        for (int c = 0; c < dp; c += 32) {
-            f32x4 piece[16];
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) piece[rr] = load_k4(src[rr], c + slot * 4, D);
-            __builtin_amdgcn_wave_barrier();                         // the previous piece has been consumed (same wave: LDS ops stay in order)
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr)
-                *reinterpret_cast<f32x4*>(tile + (rr * 8 + grp) * VERIFY_LD + slot * 4) = piece[rr];
-            __builtin_amdgcn_wave_barrier();
-            const float* ua = tile + lane * VERIFY_LD;
-            const float* va = tile + (64 + lane) * VERIFY_LD;
-#pragma unroll
-            for (int q = 0; q < 8; q += 2) {
-                const f32x4 u0 = *reinterpret_cast<const f32x4*>(ua + 4 * q), u1 = *reinterpret_cast<const f32x4*>(ua + 4 * q + 4);
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(va + 4 * q), v1 = *reinterpret_cast<const f32x4*>(va + 4 * q + 4);
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    acc = fmaf(v0[s2], u0[s2], acc);
-                    acc = fmaf(v1[s2], u1[s2], acc);
-                }
-            }
-        }
+        const float acc = wave_pair_dot(X, ld, X, ld, p.x, p.y, D, tile, lane);
         if (!hole) knn_file(cand, cnt2, cap, p.x, fmaxf(fmaf(-2.f, acc, xnorm[p.x] + xnorm[p.y]), 0.f));
     }
 }

@@ -238,8 +238,8 @@ cross_wide_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const f
                   const float* __restrict__ cnorm, const float* __restrict__ cthr, int Dh, int nchunks, int grp_rows,
                   const unsigned* __restrict__ maxn, unsigned* __restrict__ rmin_approx, unsigned* __restrict__ row_any,
                   unsigned* __restrict__ row_cover, int32_t* __restrict__ col_count, uint2* __restrict__ wgq, int qcap,
-                  int* __restrict__ wgq_count, uint2* __restrict__ ovq, int* __restrict__ ov_count, int ovcap,
-                  int* __restrict__ fail, float fc) {
+                  int* __restrict__ wgq_count, uint2* __restrict__ items, uint2* __restrict__ ovq, int* __restrict__ ov_count,
+                  int ovcap, int* __restrict__ fail, float fc) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const WLane L;
     const WideWork w = wide_work((Nc + WTB - 1) / WTB, nchunks, (Nr + WTB - 1) / WTB, grp_rows);
@@ -307,15 +307,25 @@ cross_wide_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const f
         }
     }
     __syncthreads();
-    if (L.tid == 0) wgq_count[blockIdx.x] = *qn < qcap ? *qn : qcap;
+    // the region's entries in batches of 64, appended to the list of work items of cross_verify_regions_kernel
+    // (ov_count[2] = number of items; the order of the list does not matter: the verification only feeds integer atomics)
+    if (L.tid == 0) {
+        const int n = *qn < qcap ? *qn : qcap, nb = (n + 63) / 64;
+        wgq_count[blockIdx.x] = n;
+        qn[0] = n;
+        qn[1] = nb > 0 ? atomicAdd(ov_count + 2, nb) : 0;
+    }
+    __syncthreads();
+    const int n = qn[0], base = qn[1];
+    for (int t = L.tid; t * 64 < n; t += WTHREADS) items[base + t] = make_uint2(blockIdx.x, (unsigned)(t * 64));
 }
 
 
 int launch_cross_wide(bool want_min, unsigned blocks, const float* Rb, int64_t Nr, int64_t ldr, const float* rnorm, const float* rthr,
                       const float* Cb, int64_t Nc, int64_t ldc, const float* cnorm, const float* cthr, int Dh, int nchunks,
                       int grp_rows, const unsigned* maxn, unsigned* rmin_approx, unsigned* row_any, unsigned* row_cover,
-                      int32_t* col_count, uint2* wgq, int qcap, int* wgq_count, uint2* ovq, int* ov_count, int ovcap, int* fail,
-                      float fc, hipStream_t st) {
+                      int32_t* col_count, uint2* wgq, int qcap, int* wgq_count, uint2* items, uint2* ovq, int* ov_count, int ovcap,
+                      int* fail, float fc, hipStream_t st) {
     AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&cross_wide_kernel<true>), (int)WIDE_CROSS_LDS_BYTES));
     AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&cross_wide_kernel<false>), (int)WIDE_CROSS_LDS_BYTES));
 #ifdef AM_DEV_KNOBS
@@ -324,7 +334,7 @@ int launch_cross_wide(bool want_min, unsigned blocks, const float* Rb, int64_t N
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(WTHREADS), WIDE_CROSS_LDS_BYTES, st, Rb, Nr, ldr, rnorm, rthr, Cb, Nc, ldc,
                            cnorm, cthr, Dh, nchunks, grp_rows, maxn, rmin_approx, row_any, row_cover, col_count, wgq, qcap,
-                           wgq_count, ovq, ov_count, ovcap, fail, fc);
+                           wgq_count, items, ovq, ov_count, ovcap, fail, fc);
     };
     if (want_min) launch(&cross_wide_kernel<true>);
     else launch(&cross_wide_kernel<false>);
