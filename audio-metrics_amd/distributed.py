@@ -40,13 +40,26 @@ def _world(group):
     return 1, 0
 
 
+# Test hook (tests/test_gpu_distributed.py): with True, a process group of ONE rank still issues every collective and takes
+# the partitioned k-NN path.  A 1-GPU box cannot host two RCCL ranks, so this is how the RCCL branch of this module
+# (all_gather_into_tensor, asynchronous work handles, the ordering of the communication stream against the compute and
+# side streams) is executed before the first multi-GPU run.  Never set by the product.
+COLLECTIVES_AT_WORLD_ONE = False
+
+
+def _alone(world):
+    """No exchange needed: one rank (and the test hook is off)."""
+    if world == 1 and COLLECTIVES_AT_WORLD_ONE and dist.is_available() and dist.is_initialized():
+        return False
+    return world == 1
+
 def shard_bounds(n, world, rank):
     """Contiguous row range [lo, hi) of `rank` (rows_g = [g*N/G, (g+1)*N/G))."""
     return n * rank // world, n * (rank + 1) // world
 
 
 def _all_reduce(t, world, group):
-    if world > 1:
+    if not _alone(world):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
@@ -71,7 +84,8 @@ class _Gathered:
     def __init__(self, local, counts, world, group, async_op=True):
         self.counts, self.world, self.local = counts, world, local
         self.work = None
-        if world == 1:
+        self.alone = _alone(world)
+        if self.alone:
             return
         width = tuple(local.shape[1:])
         cmax = max(counts)
@@ -85,7 +99,7 @@ class _Gathered:
         self._pad = pad                                   # stays alive until the collective has run
 
     def rows(self):
-        if self.world == 1:
+        if self.alone:
             return self.local
         if self.work is not None:
             self.work.wait()
@@ -103,7 +117,7 @@ def _all_gather_rows(local, counts, world, group):
 def global_count(n_local, device, group=None):
     """Total number of rows over the ranks (every rank must call)."""
     world, _ = _world(group)
-    if world == 1:
+    if _alone(world):
         return int(n_local)
     t = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
     _all_reduce(t, world, group)
@@ -119,7 +133,7 @@ def local_rows(data, group=None):
     world, _ = _world(group)
     rows = None if data is None else data.embeddings
     stores = data is not None and bool(data.store_embeddings)
-    if world == 1:
+    if _alone(world):
         if rows is None:
             raise ValueError("the metric needs the stored embeddings of a set that kept none")
         return rows
@@ -186,7 +200,7 @@ def merged_stats(data, group=None, ops=None):
     if ops is None:
         from . import hip_ops as ops
     world, _ = _world(group)
-    if world == 1:
+    if _alone(world):
         return data
     dev = data.device
     n_local = len(data)
@@ -225,7 +239,7 @@ def sharded_radii(local, full, counts, k, ops, world, rank, group, prepared=None
     n, d = full.shape
     lo = sum(counts[:rank])
     hi = lo + counts[rank]
-    if world > 1 and min(counts) > 0 and hasattr(ops, "knn_sym_part") and ops.knn_sym_eligible(n, d, k):
+    if not _alone(world) and min(counts) > 0 and hasattr(ops, "knn_sym_part") and ops.knn_sym_eligible(n, d, k):
         extra = {} if prepared is None else {"prepared": prepared}
         bounds = _all_gather_rows(ops.knn_bounds(full, k, lo, counts[rank], **extra), counts, world, group)
         lists = ops.knn_sym_part(full, k, rank, world, bounds, **extra)
@@ -233,7 +247,7 @@ def sharded_radii(local, full, counts, k, ops, world, rank, group, prepared=None
         _all_gather_into(all_lists.view(-1), lists.view(-1), world, group)
         r_full = ops.knn_lists_finish(all_lists, full, k)
         return r_full[lo:hi], r_full
-    if world == 1 and prepared is not None:
+    if _alone(world) and prepared is not None:
         r_local = ops.knn_radii(full, k, prepared=prepared)
     elif local.shape[0] > 0:
         r_local = ops.knn_radii(local, k, columns=full)
@@ -307,7 +321,7 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
         from . import hip_ops as ops
     world, rank = _world(group)
     dev = ref_local.device
-    if world == 1 and fused and hasattr(ops, "evaluate"):
+    if _alone(world) and fused and hasattr(ops, "evaluate"):
         return evaluate_single(ref_local, cand_local, metrics, nearest_k, ops, kid_subsets, kid_subset_size, rng_seed)
     if shard_counts is not None:
         ref_counts, cand_counts = [int(c) for c in shard_counts[0]], [int(c) for c in shard_counts[1]]
@@ -315,7 +329,7 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
                 or cand_counts[rank] != cand_local.shape[0]:
             raise ValueError("shard_counts do not describe this process group's shards")
         allc = None
-    elif world > 1:
+    elif not _alone(world):
         counts = torch.tensor([ref_local.shape[0], cand_local.shape[0]], dtype=torch.int64, device=dev)
         allc = torch.empty(world * 2, dtype=torch.int64, device=dev)
         _all_gather_into(allc, counts, world, group)

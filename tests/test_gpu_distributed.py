@@ -212,3 +212,64 @@ def test_overlapped_frechet_solve_gives_the_same_result():
     without = evaluate_sharded(r, c, nearest_k=3, kid_subsets=6, kid_subset_size=500, ops=SyncOps(), fused=False)
     for res in with_overlap:
         assert res == without
+
+
+_RCCL_ONE_RANK = r"""
+import json, os, sys
+import torch
+import torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+import inputs as gi
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+import audio_metrics_amd as am
+from audio_metrics_amd import distributed as D
+out = {}
+for name, rows, dim, k in (("small", 2500, 96, 4), ("partitioned", 33000, 128, 5)):
+    ref, cand = (torch.as_tensor(a).to(dev) for a in gi.pair("randn", 95, rows, rows - 37, dim))
+    want = D.evaluate_sharded(ref, cand, nearest_k=k, kid_subsets=8, kid_subset_size=300)          # one fused library call
+    D.COLLECTIVES_AT_WORLD_ONE = True
+    for rep in range(3):                                    # repeated: stale buffers / stream-order slips show up as a changing result
+        got = D.evaluate_sharded(ref, cand, nearest_k=k, kid_subsets=8, kid_subset_size=300)
+        out[f"{name}_{rep}"] = {"want": want, "got": got}
+    # the stats-only front end: (n, mean, cov) triples through the all-gather
+    data = am.AudioMetricsData(store_embeddings=False); data.add(ref)
+    merged = D.merged_stats(data)
+    out[f"{name}_stats"] = {"n": int(merged.n), "mean_diff": float((merged.mean - data.mean).abs().max()),
+                            "cov_diff": float((merged.cov - data.cov).abs().max())}
+    assert D.global_count(rows, dev) == rows
+    D.COLLECTIVES_AT_WORLD_ONE = False
+torch.cuda.synchronize()
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL1 " + json.dumps(out))
+"""
+
+
+def test_collectives_over_rccl_in_a_group_of_one():
+    """The RCCL branch of distributed.py (all_gather_into_tensor, asynchronous work handles waited on the compute stream, the
+    fused all-reduces, the partitioned k-NN with its two all-gathers) executed on the real transport library: a process
+    group of ONE rank over "nccl" with the module's test hook forcing every collective.  Two RCCL ranks cannot share the
+    1-GPU box, so this is everything of the multi-GPU launch but the wire."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, root, str(_free_port())], capture_output=True, text=True,
+                         timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("RCCL1 ")][0]
+    out = json.loads(line[len("RCCL1 "):])
+    for name, rec in out.items():
+        if name.endswith("_stats"):
+            assert rec["n"] in (2500, 33000) and rec["mean_diff"] == 0.0 and rec["cov_diff"] == 0.0, (name, rec)
+            continue
+        want, got = rec["want"], rec["got"]
+        for key in ("precision", "recall", "density", "coverage"):
+            assert got[key] == want[key], (name, key)
+        assert abs(got["fad"] - want["fad"]) <= 1e-5 * abs(want["fad"]), (name, got["fad"], want["fad"])
+        assert abs(got["kernel_distance_mean"] - want["kernel_distance_mean"]) <= 1e-9, name
+        assert abs(got["kernel_distance_std"] - want["kernel_distance_std"]) <= 1e-9, name
