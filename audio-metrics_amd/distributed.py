@@ -71,6 +71,28 @@ def _flat_gather_supported(group):
     return "nccl" in str(dist.get_backend(group))
 
 
+_BULK = {}
+
+
+def _bulk_group(group):
+    """A SECOND communicator over the same ranks for the two big row gathers (205 MB per set at 2 x 100k x 512).
+    The collectives of one communicator run in issue order on one stream: with a single one the 400 KB all-gathers of the
+    reference set's k-NN (bounds, lists) would queue behind the candidate set's row gather, so both gathers had to be
+    waited for before any pairwise kernel could start.  On their own communicator the candidate rows travel while the
+    reference set's radii are computed.  Only for the default group (``new_group`` must be entered by every process of
+    the job, which this function cannot promise for a caller's sub-group): a sub-group keeps one communicator."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return group
+    default = dist.group.WORLD
+    if group is not None and group is not default:
+        return group
+    cached = _BULK.get("pair")
+    if cached is None or cached[0] is not default:
+        cached = (default, dist.new_group())
+        _BULK["pair"] = cached
+    return cached[1]
+
+
 def _all_gather_into(out, local, world, group, async_op=False):
     if _flat_gather_supported(group):
         return dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=async_op)
@@ -84,6 +106,7 @@ class _Gathered:
     def __init__(self, local, counts, world, group, async_op=True):
         self.counts, self.world, self.local = counts, world, local
         self.work = None
+        self._rows = None
         self.alone = _alone(world)
         if self.alone:
             return
@@ -101,13 +124,17 @@ class _Gathered:
     def rows(self):
         if self.alone:
             return self.local
+        if self._rows is not None:
+            return self._rows
         if self.work is not None:
             self.work.wait()
             self.work = None
         cmax = max(self.counts)
         if all(c == cmax for c in self.counts):
-            return self.out
-        return torch.cat([self.out[r * cmax:r * cmax + self.counts[r]] for r in range(self.world)])
+            self._rows = self.out
+        else:
+            self._rows = torch.cat([self.out[r * cmax:r * cmax + self.counts[r]] for r in range(self.world)])
+        return self._rows
 
 
 def _all_gather_rows(local, counts, world, group):
@@ -353,8 +380,9 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
     if "fad" in metrics:
         means = global_means_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group)
     if need_full:
-        ref_g = _Gathered(ref_local, ref_counts, world, group)
-        cand_g = _Gathered(cand_local, cand_counts, world, group)
+        bulk = group if _alone(world) else _bulk_group(group)          # (every rank enters: collective on first use)
+        ref_g = _Gathered(ref_local, ref_counts, world, bulk)
+        cand_g = _Gathered(cand_local, cand_counts, world, bulk)
 
     # statistics; the Frechet solve goes to a side stream right away (its stopping rule runs on the device, so
     # the host just enqueues it) and overlaps the PRDC chain issued next
@@ -365,18 +393,19 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
         starter = getattr(ops, "frechet_async", None)
         fad_job = starter(mu_c, cov_c, mu_r, cov_r) if starter is not None else None
 
-    if need_full:
-        ref_full, cand_full = ref_g.rows(), cand_g.rows()
-
     prdc_pending = None
     if "prdc" in metrics:
         k = nearest_k
         # norms, maxima and scaled f16 copies of the two gathered sets: once per evaluate, shared by the k-NN entry points
-        # and the membership counts (the reference shard of this rank is a row range of the prepared reference set)
+        # and the membership counts (the reference shard of this rank is a row range of the prepared reference set).
+        # The reference set's radii are under way before the candidate rows are waited for: their gather (second
+        # communicator) overlaps the reference set's sweep.
         prepare = getattr(ops, "prepare", None)
+        ref_full = ref_g.rows()
         prep_r = prepare(ref_full) if prepare is not None else None
-        prep_c = prepare(cand_full) if prepare is not None else None
         r_ref_l, _ = sharded_radii(ref_local, ref_full, ref_counts, k, ops, world, rank, group, prep_r)
+        cand_full = cand_g.rows()
+        prep_c = prepare(cand_full) if prepare is not None else None
         _, r_cand = sharded_radii(cand_local, cand_full, cand_counts, k, ops, world, rank, group, prep_c)
         packed = torch.zeros(n_cand + 2, dtype=torch.int32, device=dev)        # column counts | #rows any | #rows covered
         if ref_local.shape[0] > 0:
@@ -398,6 +427,7 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
             m = max(1, min(n_ref, n_cand) // 2)
         idx1, idx2 = subset_indices(n_cand, n_ref, kid_subsets, m, rng_seed)     # features_1 = candidate
         mmds = torch.zeros(kid_subsets, dtype=torch.float64, device=dev)
+        ref_full, cand_full = ref_g.rows(), cand_g.rows()
         if rank < kid_subsets:                                 # this rank's subsets: rank, rank + world, ...
             upload = getattr(ops, "upload_host_array", None) or _plain_upload
             part = ops.kd_poly(cand_full, ref_full, upload(idx1[rank::world], dev), upload(idx2[rank::world], dev),
