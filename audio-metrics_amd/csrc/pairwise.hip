@@ -1350,11 +1350,19 @@ static int knn_bounds_impl(const float* X, int64_t N, int64_t ld, int D, int k, 
         const float* Xb = reinterpret_cast<const float*>(prep != nullptr ? prep->half : xb);
         auto go = [&](auto kcap_tag) -> int {
             constexpr int KC = decltype(kcap_tag)::value;
-            int r2 = launch_knn_vt<KC, EV_FAST, false>(Xb + row0 * ldh, nrows, ldh, xn + row0, Xb, N, ldh, xn, (int)ldh, p.pre_chunks,
+            int chunks = p.pre_chunks, r2;
+            if (p.tile_rows == WIDE_TILE_ROWS && (KC == 6 || KC == 11)) {
+                // the shard's rows against every pre_stride-th 256-row tile on the 256-row engine, as on one GPU
+                const int64_t samples = ceil_div(ceil_div(N, WIDE_TILE_ROWS), p.pre_stride);
+                chunks = std::min(wide_sample_chunks(ceil_div(nrows, WIDE_TILE_ROWS), samples), p.pre_chunks);
+                r2 = launch_knn_wide_sample(KC, Xb, N, ldh, xn, (int)ldh, p.pre_stride, chunks, maxn, partial, row0, nrows, st);
+            } else {
+                r2 = launch_knn_vt<KC, EV_FAST, false>(Xb + row0 * ldh, nrows, ldh, xn + row0, Xb, N, ldh, xn, (int)ldh, p.pre_chunks,
                                                        p.pre_stride, partial, st, maxn);
+            }
             if (r2 != AM_OK) return r2;
             hipLaunchKernelGGL(knn_merge_kernel<KC>, dim3((unsigned)ceil_div(nrows, 256)), dim3(256), 0, st, partial, nrows,
-                               p.pre_chunks, k + 1, 1, out_bound_sq);
+                               chunks, k + 1, 1, out_bound_sq);
             hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(nrows, 256)), dim3(256), 0, st, out_bound_sq,
                                out_bound_sq, xn + row0, nrows, maxn, fast_c(D));
             AM_LAUNCH_CHECK();

@@ -306,7 +306,7 @@ int launch_cross_wide_sample(const float* Rb, int64_t Nr, int64_t ldr, const flo
                              const float* cnorm, const float* cthr, int Dh, int stride, int nchunks, const unsigned* maxn,
                              unsigned* row_any, float fc, hipStream_t st);
 int launch_knn_wide_sample(int kcap, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, int Dh, int stride, int nchunks,
-                           const unsigned* maxn, float* partial, hipStream_t st);
+                           const unsigned* maxn, float* partial, int64_t row0, int64_t nrows, hipStream_t st);
 int launch_knn_wide(int kcap, unsigned nwg, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, float* thr, int Dh,
                     int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
                     uint2* wgq, float* wgv, int qcap, int* wgq_count, int part, int nparts, float fc, uint2* ovq, float* ovv,

@@ -1183,6 +1183,21 @@ static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan&
 // bounds_in != nullptr: upper bounds B_i of the rows' final values already computed (partitioned form:
 // am_knn_bounds_f32 of every rank, all-gathered) -> filter bound B_i + E_i;
 // out_lists != nullptr: partitioned form, emit per-row lists instead of radii.
+// chunks per row block of the wide sample pass: the split of a row block's `samples` sampled column tiles that leaves the
+// shortest schedule on 256 CUs (rounds of workgroups x tiles per workgroup)
+static int wide_sample_chunks(int64_t row_blocks, int64_t samples) {
+    int chunks = 1;
+    int64_t best_cost = INT64_MAX;
+    for (int c = 1; c <= 8 && c <= samples; ++c) {
+        const int64_t cost = ceil_div(row_blocks * c, 256) * ceil_div(samples, c);
+        if (cost < best_cost) {
+            best_cost = cost;
+            chunks = c;
+        }
+    }
+    return chunks;
+}
+
 template <int KCAP>
 static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, const KnnPlan& p, const KnnBuffers& b,
                         const KnnFastBuffers& f, float* out_r, hipStream_t st, int part = 0, int nparts = 1,
@@ -1208,14 +1223,9 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     } else {
         int sample_chunks = p.pre_chunks;
         if (p.tile_rows == WIDE_TILE_ROWS) {              // the sample pass on the 256-row engine: every pre_stride-th 256-row tile
-            // chunks per row block: the split that leaves the shortest schedule on 256 CUs (rounds x tiles per workgroup)
             const int64_t rb = ceil_div(N, WIDE_TILE_ROWS), samples = ceil_div(rb, p.pre_stride);
-            int64_t best_cost = INT64_MAX;
-            for (int c = 1; c <= 8 && c <= samples; ++c) {
-                const int64_t cost = ceil_div(rb * c, 256) * ceil_div(samples, c);
-                if (cost < best_cost) { best_cost = cost; sample_chunks = c; }
-            }
-            if ((rc = launch_knn_wide_sample(KCAP, Xb, N, ldh, b.xn, Dh, p.pre_stride, sample_chunks, maxn, b.partial, st)) != AM_OK)
+            sample_chunks = wide_sample_chunks(rb, samples);
+            if ((rc = launch_knn_wide_sample(KCAP, Xb, N, ldh, b.xn, Dh, p.pre_stride, sample_chunks, maxn, b.partial, 0, N, st)) != AM_OK)
                 return rc;
         } else if ((rc = launch_knn_vt<KCAP, EV_FAST, false>(Xb, N, ldh, b.xn, Xb, N, ldh, b.xn, Dh, p.pre_chunks, p.pre_stride,
                                                              b.partial, st, maxn)) != AM_OK) {

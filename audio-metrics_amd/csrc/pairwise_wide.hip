@@ -612,7 +612,7 @@ constexpr size_t KNN_SAMPLE_LDS_BYTES = (WENGINE_LDS_WORDS + 4 * WTB) * sizeof(f
 template <int KCAP>
 __global__ void __launch_bounds__(WTHREADS, 1)
 knn_wide_sample_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float* __restrict__ xnorm, int Dh, int stride,
-                       int nchunks, const unsigned* __restrict__ maxn, float* __restrict__ partial) {
+                       int nchunks, const unsigned* __restrict__ maxn, float* __restrict__ partial, int64_t row0, int64_t nrows) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const WLane L;
     const int64_t T = (N + WTB - 1) / WTB;
@@ -627,12 +627,12 @@ knn_wide_sample_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, con
     epi.dsc = half_unscale(maxn[2], maxn[2]);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int64_t i = pb * WTB + L.wn * 64 + nt * 32 + L.r;
+        const int64_t i = row0 + pb * WTB + L.wn * 64 + nt * 32 + L.r;         // rows [row0, row0 + nrows) of the set (a rank's shard)
         epi.xn[nt] = i < N ? xnorm[i] : INFINITY;
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = INFINITY;
     }
-    if (s1 > s0) wide_pipeline(Xb, N, ldh, StridedTiles{s0, stride}, Xb, N, ldh, pb * WTB, (int)(s1 - s0), Dh, lds, L, epi);
+    if (s1 > s0) wide_pipeline(Xb, N, ldh, StridedTiles{s0, stride}, Xb, N, ldh, row0 + pb * WTB, (int)(s1 - s0), Dh, lds, L, epi);
     __syncthreads();
     float* mg = lds;                                   // [256][4][KCAP]
 #pragma unroll
@@ -643,14 +643,14 @@ knn_wide_sample_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, con
     }
     __syncthreads();
     if (L.tid < WTB) {
-        const int64_t i = pb * WTB + L.tid;
-        if (i < N) {
+        const int64_t i = pb * WTB + L.tid;                    // (relative to row0)
+        if (i < nrows) {
             const float* src = mg + L.tid * 4 * KCAP;
             float m[KCAP];
 #pragma unroll
             for (int s = 0; s < KCAP; ++s) m[s] = src[s];
             for (int s = KCAP; s < 4 * KCAP; ++s) list_insert<KCAP>(m, src[s]);
-            float* out = partial + ((int64_t)chunk * N + i) * KCAP;
+            float* out = partial + ((int64_t)chunk * nrows + i) * KCAP;
 #pragma unroll
             for (int s = 0; s < KCAP; ++s) out[s] = m[s];
         }
@@ -659,20 +659,20 @@ knn_wide_sample_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, con
 
 template <int KCAP>
 static int launch_knn_wide_sample_t(const float* Xb, int64_t N, int64_t ldh, const float* xnorm, int Dh, int stride, int nchunks,
-                                    const unsigned* maxn, float* partial, hipStream_t st) {
+                                    const unsigned* maxn, float* partial, int64_t row0, int64_t nrows, hipStream_t st) {
     AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_wide_sample_kernel<KCAP>), (int)KNN_SAMPLE_LDS_BYTES));
-    const unsigned blocks = (unsigned)(ceil_div(N, WTB) * nchunks);
+    const unsigned blocks = (unsigned)(ceil_div(nrows, WTB) * nchunks);
     hipLaunchKernelGGL(knn_wide_sample_kernel<KCAP>, dim3(blocks), dim3(WTHREADS), KNN_SAMPLE_LDS_BYTES, st, Xb, N, ldh, xnorm, Dh, stride,
-                       nchunks, maxn, partial);
+                       nchunks, maxn, partial, row0, nrows);
     AM_LAUNCH_CHECK();
     return AM_OK;
 }
 
 int launch_knn_wide_sample(int kcap, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, int Dh, int stride, int nchunks,
-                           const unsigned* maxn, float* partial, hipStream_t st) {
-    if (kcap == 6) return launch_knn_wide_sample_t<6>(Xb, N, ldh, xnorm, Dh, stride, nchunks, maxn, partial, st);
+                           const unsigned* maxn, float* partial, int64_t row0, int64_t nrows, hipStream_t st) {
+    if (kcap == 6) return launch_knn_wide_sample_t<6>(Xb, N, ldh, xnorm, Dh, stride, nchunks, maxn, partial, row0, nrows, st);
     AM_REQUIRE(kcap == 11, AM_ERR_UNSUPPORTED_K, "the wide sample pass holds lists of 6 or 11 entries (got %d)", kcap);
-    return launch_knn_wide_sample_t<11>(Xb, N, ldh, xnorm, Dh, stride, nchunks, maxn, partial, st);
+    return launch_knn_wide_sample_t<11>(Xb, N, ldh, xnorm, Dh, stride, nchunks, maxn, partial, row0, nrows, st);
 }
 
 template <int KCAP>
