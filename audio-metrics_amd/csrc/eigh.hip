@@ -5,15 +5,16 @@
 // Eigensolver: one-sided BLOCK Jacobi (Hestenes) in f64.  W starts as A (rows = columns, A is symmetric), V as the
 // identity; W = V A throughout.  At convergence the rows of W are mutually orthogonal: rows of V are the eigenvectors, and
 // the eigenvalue of row i is the Rayleigh quotient W_i . V_i (signed, unlike |W_i|).
-// Rows are grouped in blocks of 16.  A round pairs the blocks by the round-robin tournament (one workgroup per block
-// pair, mb - 1 rounds per sweep); a workgroup makes the 32 rows of its pair mutually orthogonal in one go:
-//   G = R R^T (32 x 32 Gram matrix of its W rows, on the f64 matrix cores), a two-sided cyclic Jacobi of G in LDS that
-//   accumulates the rotations into J (G is tiny: 31 x 16 rotations per inner sweep, no row-length work), then R <- J^T R
-//   for its rows of W and of V (f64 matrix cores again).
+// Rows are grouped in blocks of 16.  A round pairs the blocks by the round-robin tournament (mb - 1 rounds per sweep) and
+// makes the 32 rows of every pair mutually orthogonal in one go:
+//   G = R R^T (32 x 32 Gram matrix of the pair's W rows, on the f64 matrix cores), a two-sided cyclic Jacobi of G in LDS that
+//   accumulates the rotations into J (G is tiny: 16 x 16 rotations per visit, no row-length work), then R <- J^T R for
+//   the pair's rows of W and of V (f64 matrix cores again).
 // Round 2 rotated ONE row pair per workgroup and needed D - 1 = 511 launches of a latency-bound kernel per sweep (42 ms
-// at D = 512); here a sweep is 31 launches.  The rounds of several sweeps are enqueued ahead: a round kernel of sweep s
-// returns at once when sweep s - 1 applied no rotation (counter on the device), so the host synchronises once per block
-// of sweeps - normally once per solve - instead of once per sweep.  All reductions run in a fixed order (deterministic).
+// at D = 512); here a sweep is 31 rounds of three launches (Gram / inner solve / row update: the first and the last are
+// spread over 8 workgroups per pair).  The rounds of several sweeps are enqueued ahead: a kernel of sweep s returns at once
+// when sweep s - 1 applied no rotation (counter on the device), so the host synchronises once per block of sweeps -
+// normally once per solve - instead of once per sweep.  All reductions run in a fixed order (deterministic).
 #include "am_common.h"
 #include <math.h>
 #include <stdlib.h>
@@ -93,164 +94,243 @@ __device__ __forceinline__ double rcp_f64(double y) {
 }
 
 constexpr int JB = 16;            // rows per block
-constexpr int JP = 2 * JB;        // rows a workgroup orthogonalises
+constexpr int JP = 2 * JB;        // rows a block pair orthogonalises
 constexpr int JLD = JP + 1;       // LDS row stride of the 32 x 32 matrices (doubles)
+constexpr int GRAM_SLICES = 8;    // workgroups that share the Gram matrix of one block pair (column slices)
+constexpr int APPLY_SLICES = 8;   // workgroups that share the row update of one block pair (16-column strips dealt round-robin)
+constexpr int APPLY_STRIPS = 2;   // strips a wave updates at a time
 
-// round `round` of sweep `sweep`: block pair i = (player(i), player(mb - 1 - i)) of the tournament over mb = number of
-// blocks rounded up to even (player(0) = mb - 1 fixed, the others rotate); a block index >= nb is a bye
-__global__ void __launch_bounds__(256) jacobi_block_round_kernel(double* __restrict__ W, double* __restrict__ V, int n, int nb, int mb,
-                                                                 int round, int sweep, double tol, const double* __restrict__ scale,
-                                                                 unsigned* __restrict__ rotations) {
-    if (sweep > 0 && rotations[sweep - 1] == 0u) return;           // the previous sweep found every pair orthogonal: done
-    // rows whose squared norm is below (1e-14 trace A)^2 are numerically zero (null directions of a rank-deficient A: their
-    // content is rounding noise, whose mutual angles never settle - 3x the sweeps on a Gram matrix of D/3 rows)
-    const double floor2 = (1e-14 * *scale) * (1e-14 * *scale), tol2 = tol * tol;
-    __shared__ double G[JP][JLD], J[JP][JLD];
-    __shared__ int applied;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    auto player = [](int slot, int m, int r) { return slot == 0 ? m - 1 : (slot - 1 + r) % (m - 1); };
-    int bp = player(blockIdx.x, mb, round), bq = player(mb - 1 - blockIdx.x, mb, round);
-    if (bp > bq) { const int t = bp; bp = bq; bq = t; }
-    if (bp >= nb) return;
+// Block pair `slot` of round `round`: (player(slot), player(mb - 1 - slot)) of the round-robin tournament over mb = number of
+// blocks rounded up to even (player(0) = mb - 1 fixed, the others rotate); a block index >= nb is a bye.
+__device__ __forceinline__ int tournament_player(int slot, int m, int r) { return slot == 0 ? m - 1 : (slot - 1 + r) % (m - 1); }
+
+struct BlockPair {
+    int bp, bq, n, nb;
+    __device__ BlockPair(int slot, int mb, int round, int n_, int nb_) : n(n_), nb(nb_) {
+        bp = tournament_player(slot, mb, round);
+        bq = tournament_player(mb - 1 - slot, mb, round);
+        if (bp > bq) { const int t = bp; bp = bq; bq = t; }
+    }
+    __device__ bool bye() const { return bp >= nb; }
     // local row r of the pair -> global row (or -1)
-    auto grow = [&](int r) {
+    __device__ int row(int r) const {
         const int b = r < JB ? bp : bq;
         const int g = b * JB + (r & (JB - 1));
         return (b < nb && g < n) ? g : -1;
-    };
-    // ---- 1. G = R R^T on v_mfma_f64_16x16x4_f64: wave w owns the 16 x 16 tile (w >> 1, w & 1)
-    {
-        const int ti = wave >> 1, tj = wave & 1;
-        const int ra = grow(ti * JB + l15), rb = grow(tj * JB + l15);
-        const double* wa = W + (int64_t)(ra < 0 ? 0 : ra) * n;
-        const double* wb = W + (int64_t)(rb < 0 ? 0 : rb) * n;
-        f64x4e acc = {0, 0, 0, 0};
-        // The sum over k may run in any order as long as both operands use the same one: lane (l15, l4) takes the four
-        // consecutive elements k0 + 4 l4 .. + 3 of its row per 16-element chunk (one 32-byte load per operand, 128 B per row
-        // and instruction), eight chunks in flight - a load-then-MFMA loop was one exposed L2 round trip per MFMA, 128 of
-        // them in a row: 60 of the 75 us of a round.
-        const bool vec = (n % 4) == 0;
-        for (int k0 = 0; k0 < n; k0 += 128) {
-            double av[8][4], bw[8][4];
+    }
+};
+
+// A round of a sweep is three launches (round 3 had one workgroup per block pair do all of it - 16 CUs of 256 busy, 42 us per
+// round at D = 512 of which 12 us were f64 MFMA time of ONE CU and as much again its load latency):
+//   1. jacobi_gram_kernel   partial Gram matrices of the pair's 32 rows of W, one per column slice      (pairs x 8 workgroups)
+//   2. jacobi_inner_kernel  G = sum of the partials; two-sided Jacobi of G in LDS, rotations accumulated in J      (pairs)
+//   3. jacobi_apply_kernel  rows <- J^T rows for W and V, the 16-column strips dealt over the workgroups  (pairs x 8 workgroups)
+// Every kernel of sweep s returns at once when sweep s - 1 applied no rotation.
+
+// ---- 1. Gpart[pair][slice] = R[:, slice] R[:, slice]^T on v_mfma_f64_16x16x4_f64: wave w owns the 16 x 16 tile (w >> 1, w & 1)
+__global__ void __launch_bounds__(256) jacobi_gram_kernel(const double* __restrict__ W, int n, int nb, int mb, int round, int sweep,
+                                                          const unsigned* __restrict__ rotations, double* __restrict__ Gpart) {
+    if (sweep > 0 && rotations[sweep - 1] == 0u) return;           // the previous sweep found every pair orthogonal: done
+    const BlockPair bpair(blockIdx.x, mb, round, n, nb);
+    if (bpair.bye()) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ti = wave >> 1, tj = wave & 1;
+    const int ra = bpair.row(ti * JB + l15), rb = bpair.row(tj * JB + l15);
+    const double* wa = W + (int64_t)(ra < 0 ? 0 : ra) * n;
+    const double* wb = W + (int64_t)(rb < 0 ? 0 : rb) * n;
+    const int kslice = ((n + GRAM_SLICES - 1) / GRAM_SLICES + 15) / 16 * 16;
+    const int kbeg = blockIdx.y * kslice, kend = min(n, kbeg + kslice);
+    f64x4e acc = {0, 0, 0, 0};
+    // The sum over k may run in any order as long as both operands use the same one: lane (l15, l4) takes the four
+    // consecutive elements k0 + 4 l4 .. + 3 of its row per 16-element chunk (one 32-byte load per operand, 128 B per row
+    // and instruction), eight chunks in flight - a load-then-MFMA loop is one exposed L2 round trip per MFMA.
+    const bool vec = (n % 4) == 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 128) {
+        double av[8][4], bw[8][4];
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) {
-                const int k = k0 + ch * 16 + l4 * 4;
-                if (vec && k + 3 < n) {
-                    const f64x4e a4 = ra >= 0 ? *reinterpret_cast<const f64x4e*>(wa + k) : f64x4e{0, 0, 0, 0};
-                    const f64x4e b4 = rb >= 0 ? *reinterpret_cast<const f64x4e*>(wb + k) : f64x4e{0, 0, 0, 0};
+        for (int ch = 0; ch < 8; ++ch) {
+            const int k = k0 + ch * 16 + l4 * 4;
+            if (vec && k + 3 < kend) {
+                const f64x4e a4 = ra >= 0 ? *reinterpret_cast<const f64x4e*>(wa + k) : f64x4e{0, 0, 0, 0};
+                const f64x4e b4 = rb >= 0 ? *reinterpret_cast<const f64x4e*>(wb + k) : f64x4e{0, 0, 0, 0};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { av[ch][j] = a4[j]; bw[ch][j] = b4[j]; }
-                } else {
+                for (int j = 0; j < 4; ++j) { av[ch][j] = a4[j]; bw[ch][j] = b4[j]; }
+            } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        av[ch][j] = (ra >= 0 && k + j < n) ? wa[k + j] : 0.0;
-                        bw[ch][j] = (rb >= 0 && k + j < n) ? wb[k + j] : 0.0;
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    av[ch][j] = (ra >= 0 && k + j < kend) ? wa[k + j] : 0.0;
+                    bw[ch][j] = (rb >= 0 && k + j < kend) ? wb[k + j] : 0.0;
                 }
             }
-#pragma unroll
-            for (int ch = 0; ch < 8; ++ch)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ch][j], bw[ch][j], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) G[ti * JB + l4 + 4 * r][tj * JB + l15] = acc[r];       // C layout: row = (lane >> 4) + 4 reg, column = lane & 15
+        for (int ch = 0; ch < 8; ++ch)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ch][j], bw[ch][j], acc, 0, 0, 0);
     }
-    for (int e = tid; e < JP * JP; e += 256) J[e / JP][e % JP] = (e / JP == e % JP) ? 1.0 : 0.0;
+    double* out = Gpart + ((int64_t)blockIdx.x * GRAM_SLICES + blockIdx.y) * (JP * JP);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(ti * JB + l4 + 4 * r) * JP + tj * JB + l15] = acc[r];   // C layout: row = (lane >> 4) + 4 reg, column = lane & 15
+}
+
+// ---- 2. two-sided cyclic Jacobi of the pair's Gram matrix in LDS, rotations accumulated in J (written to Jout; applied[pair] = 1
+//         when any rotation was applied).
+// An inner round rotates 16 disjoint index pairs g = (p_g, q_g).  Thread (a, b) = (tid >> 4, tid & 15) owns the 2 x 2 block of G
+// with rows {p_a, q_a} and columns {p_b, q_b}: G_ab <- R_a^T G_ab R_b, and the same block of J: J_ab <- J_ab R_b.  Every thread
+// derives the two rotations it needs itself from the six diagonal-block entries (the same arithmetic on the same inputs in
+// every thread that needs a rotation: all of them agree), and the matrices ping-pong between two LDS copies - so a round is ONE
+// LDS round trip, one rsqrt chain and one barrier (round 3 rotated rows, barrier, then columns, barrier, with the pair's sixteen
+// threads waiting for the chain in between: 0.87 us per inner round, 14 of the 42 us of a visit).
+// ONE inner sweep per visit: the pair's rows meet again in the next outer sweep, and a full diagonalisation of G here (5-8 inner
+// sweeps while the off-diagonal mass is large) costs more than the outer sweeps it saves - measured 54 ms against 28.
+__global__ void __launch_bounds__(256) jacobi_inner_kernel(const double* __restrict__ Gpart, int n, int nb, int mb, int round, int sweep,
+                                                           double tol, const double* __restrict__ scale, unsigned* __restrict__ rotations,
+                                                           double* __restrict__ Jout, int* __restrict__ applied_out) {
+    if (sweep > 0 && rotations[sweep - 1] == 0u) return;
+    const BlockPair bpair(blockIdx.x, mb, round, n, nb);
+    if (bpair.bye()) return;
+    // rows whose squared norm is below (1e-14 trace A)^2 are numerically zero (null directions of a rank-deficient A: their
+    // content is rounding noise, whose mutual angles never settle - 3x the sweeps on a Gram matrix of D/3 rows)
+    const double floor2 = (1e-14 * *scale) * (1e-14 * *scale), tol2 = tol * tol;
+    __shared__ double G[2][JP][JLD], J[2][JP][JLD];
+    __shared__ int applied;
+    const int tid = threadIdx.x;
+    const double* gp = Gpart + (int64_t)blockIdx.x * GRAM_SLICES * (JP * JP);
+    for (int e = tid; e < JP * JP; e += 256) {
+        double g = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < GRAM_SLICES; ++sl) g += gp[sl * (JP * JP) + e];          // fixed order: deterministic
+        G[0][e / JP][e % JP] = g;
+        J[0][e / JP][e % JP] = (e / JP == e % JP) ? 1.0 : 0.0;
+    }
+    if (tid == 0) applied = 0;
     __syncthreads();
-    // ---- 2. two-sided cyclic Jacobi of G in LDS, rotations accumulated in J.  Thread group g = tid >> 4 (16 threads of
-    //         one wave) owns the index pair g of the inner round; thread l of it the columns / rows l and l + 16.
-    // ONE inner sweep per visit: the pair's rows meet again in the next outer sweep, and a full diagonalisation of G here
-    // (5-8 inner sweeps while the off-diagonal mass is large) costs more than the outer sweeps it saves - measured 54 ms
-    // against 7 at D = 512.  An inner round is latency-bound (three dependent LDS round trips, an f64 sqrt / divide chain,
-    // two barriers): ~0.45 us.
-    const int grp = tid >> 4, l = tid & 15;
-    bool any_first = false;
-    for (int isweep = 0; isweep < 1; ++isweep) {
-        if (tid == 0) applied = 0;
-        __syncthreads();
-        for (int ir = 0; ir < JP - 1; ++ir) {
-            int p = player(grp, JP, ir), q = player(JP - 1 - grp, JP, ir);
+    // Index pairs of a visit: in round 0 of a sweep (every block is in exactly one pair there) all 32 * 31 / 2 pairs of the
+    // 32 rows, 31 inner rounds; in the other rounds only the 16 x 16 pairs ACROSS the two blocks (16 inner rounds: row g
+    // of the first block with row (g + ir) mod 16 of the second) - the pairs inside a block have met in round 0, and
+    // rotating them again in each of the 31 visits of a sweep buys nothing (19 -> 16 ms at D = 512, one sweep more).
+    const bool all_pairs = round == 0;
+    const int inner_rounds = all_pairs ? JP - 1 : JB;
+    const int ga = tid >> 4, gb = tid & 15;
+    auto index_pair = [&](int g, int ir, int& p, int& q) {
+        if (all_pairs) {
+            p = tournament_player(g, JP, ir);
+            q = tournament_player(JP - 1 - g, JP, ir);
             if (p > q) { const int t = p; p = q; q = t; }
-            const double gpp = G[p][p], gqq = G[q][q], gpq = G[p][q];
-            double c = 1.0, sn = 0.0;
-            if (gpq * gpq > tol2 * (gpp * gqq) && fmin(gpp, gqq) > floor2) {      // not yet orthogonal, neither row (numerically) zero
-                // t = tan(theta) = sign(d) 2 g_pq / (|d| + sqrt(d^2 + 4 g_pq^2)), d = g_qq - g_pp; c = 1 / sqrt(1 + t^2); s = c t.
-                // The library sqrt and divide are ~200-cycle sequences each and this chain sits between two barriers 31 times
-                // per visit: hardware reciprocal (square root) estimates with two Newton steps instead (full f64 accuracy:
-                // c^2 + s^2 = 1 to 1e-16, which is what keeps V orthonormal).
-                const double d = gqq - gpp, g2 = 2.0 * gpq;
-                const double y = fma(d, d, g2 * g2);
-                const double h = y * rsqrt_f64(y);
-                const double t = (d >= 0 ? g2 : -g2) * rcp_f64(fabs(d) + h);
-                c = rsqrt_f64(fma(t, t, 1.0));
-                sn = c * t;
-                if (l == 0) applied = 1;
-            }
-            // rows p, q (the 16 threads of a group sit in one wave: all of them have read the three entries above before any
-            // of them writes; other groups never write these three)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = l + 16 * h;
-                const double a = G[p][k], b = G[q][k];
-                G[p][k] = c * a - sn * b;
-                G[q][k] = sn * a + c * b;
-            }
-            __syncthreads();
-            // columns p, q of G and of J
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = l + 16 * h;
-                const double a = G[k][p], b = G[k][q];
-                G[k][p] = c * a - sn * b;
-                G[k][q] = sn * a + c * b;
-                const double x = J[k][p], y = J[k][q];
-                J[k][p] = c * x - sn * y;
-                J[k][q] = sn * x + c * y;
-            }
-            __syncthreads();
+        } else {
+            p = g;
+            q = JB + ((g + ir) & (JB - 1));
         }
-        const bool again = applied != 0;
-        if (isweep == 0) any_first = again;
+    };
+    // tan(theta) = sign(d) 2 g_pq / (|d| + h), h = sqrt(d^2 + 4 g_pq^2), d = g_qq - g_pp, in the form that needs two reciprocal
+    // square roots and no division: c^2 = (1 + |d| / h) / 2, c = c^2 / sqrt(c^2), s = sign(d) g_pq / (h sqrt(c^2)) - and
+    // c^2 + s^2 = ((1 + x)^2 + (1 - x^2)) / (2 (1 + x)) = 1 for x = |d| / h.  The library sqrt and divide are ~200-cycle
+    // sequences each and this chain is the critical path of an inner round: hardware estimates with two Newton steps instead
+    // (full f64 accuracy: c^2 + s^2 = 1 to 1e-16, which is what keeps V orthonormal).
+    auto rotation = [&](double gpp, double gqq, double gpq, double& c, double& sn) {
+        c = 1.0;
+        sn = 0.0;
+        if (gpq * gpq > tol2 * (gpp * gqq) && fmin(gpp, gqq) > floor2) {      // not yet orthogonal, neither row (numerically) zero
+            const double d = gqq - gpp, g2 = 2.0 * gpq;
+            const double rh = rsqrt_f64(fma(d, d, g2 * g2));
+            const double c2 = fma(0.5 * fabs(d), rh, 0.5);
+            const double rc = rsqrt_f64(c2);
+            c = c2 * rc;
+            sn = (d >= 0 ? gpq : -gpq) * rh * rc;
+            return true;
+        }
+        return false;
+    };
+    bool mine = false;
+    int cur = 0;
+    for (int ir = 0; ir < inner_rounds; ++ir, cur ^= 1) {
+        int pa, qa, pb, qb;
+        index_pair(ga, ir, pa, qa);
+        index_pair(gb, ir, pb, qb);
+        const double (*Gc)[JLD] = G[cur];
+        const double (*Jc)[JLD] = J[cur];
+        double ca, sa, cb, sb;
+        const bool ra = rotation(Gc[pa][pa], Gc[qa][qa], Gc[pa][qa], ca, sa);
+        rotation(Gc[pb][pb], Gc[qb][qb], Gc[pb][qb], cb, sb);
+        if (ga == gb && ra) mine = true;
+        // rows {pa, qa} x columns {pb, qb}: rows first (R_a^T from the left: new row p = c p - s q, new row q = s p + c q), then columns
+        const double g00 = Gc[pa][pb], g01 = Gc[pa][qb], g10 = Gc[qa][pb], g11 = Gc[qa][qb];
+        const double r00 = ca * g00 - sa * g10, r01 = ca * g01 - sa * g11;
+        const double r10 = sa * g00 + ca * g10, r11 = sa * g01 + ca * g11;
+        double (*Gn)[JLD] = G[cur ^ 1];
+        Gn[pa][pb] = cb * r00 - sb * r01;
+        Gn[pa][qb] = sb * r00 + cb * r01;
+        Gn[qa][pb] = cb * r10 - sb * r11;
+        Gn[qa][qb] = sb * r10 + cb * r11;
+        // J <- J R: columns {pb, qb} of rows {pa, qa}
+        const double j00 = Jc[pa][pb], j01 = Jc[pa][qb], j10 = Jc[qa][pb], j11 = Jc[qa][qb];
+        double (*Jn)[JLD] = J[cur ^ 1];
+        Jn[pa][pb] = cb * j00 - sb * j01;
+        Jn[pa][qb] = sb * j00 + cb * j01;
+        Jn[qa][pb] = cb * j10 - sb * j11;
+        Jn[qa][qb] = sb * j10 + cb * j11;
         __syncthreads();
-        if (!again) break;
     }
-    if (!any_first) return;                                          // the 32 rows were orthogonal already: nothing to apply
-    if (tid == 0) atomicAdd(rotations + sweep, 1u);
-    // ---- 3. rows <- J^T rows for W and V: out[r'][c] = sum_r J[r][r'] in[r][c].  A wave takes 16-column strips; it loads the
-    //         strip's 32 x 16 block (eight k-steps of four rows), forms both 16-row output tiles, stores them back.
-    // (four strips per pass: 32 loads in flight and eight independent MFMA chains instead of one strip's 8 and 2)
-    const int strips = (n + 15) / 16;
-    for (int st0 = wave * 4; st0 < 2 * strips; st0 += 16) {
-        double bv[4][8];
+    if (mine) applied = 1;
+    __syncthreads();
+    const bool any = applied != 0;
+    if (tid == 0) {
+        applied_out[blockIdx.x] = any ? 1 : 0;
+        if (any) atomicAdd(rotations + sweep, 1u);
+    }
+    if (!any) return;                                                // the 32 rows were orthogonal already: nothing to apply
+    double* jo = Jout + (int64_t)blockIdx.x * (JP * JP);
+    for (int e = tid; e < JP * JP; e += 256) jo[e] = J[cur][e / JP][e % JP];
+}
+
+// ---- 3. rows <- J^T rows for W and V: out[r'][c] = sum_r J[r][r'] in[r][c].  A wave takes APPLY_STRIPS 16-column strips at a time: it
+//         loads the strips' 32 x 16 blocks (eight k-steps of four rows), forms both 16-row output tiles of each, stores them
+//         back (16 loads in flight and four independent MFMA chains; 128 workgroups per round at D = 512).
+__global__ void __launch_bounds__(256) jacobi_apply_kernel(double* __restrict__ W, double* __restrict__ V, int n, int nb, int mb,
+                                                           int round, int sweep, const unsigned* __restrict__ rotations,
+                                                           const double* __restrict__ Jin, const int* __restrict__ applied_in) {
+    if (sweep > 0 && rotations[sweep - 1] == 0u) return;
+    const BlockPair bpair(blockIdx.x, mb, round, n, nb);
+    if (bpair.bye() || applied_in[blockIdx.x] == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const double* Jm = Jin + (int64_t)blockIdx.x * (JP * JP);
+    double j0[8], j1[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+    for (int ks = 0; ks < 8; ++ks) {
+        j0[ks] = Jm[(ks * 4 + l4) * JP + l15];
+        j1[ks] = Jm[(ks * 4 + l4) * JP + JB + l15];
+    }
+    const int strips = (n + 15) / 16;
+    for (int st0 = (blockIdx.y * 4 + wave) * APPLY_STRIPS; st0 < 2 * strips; st0 += APPLY_SLICES * 4 * APPLY_STRIPS) {
+        double bv[APPLY_STRIPS][8];
+#pragma unroll
+        for (int u = 0; u < APPLY_STRIPS; ++u) {
             const int st = st0 + u;
             const double* M = st < strips ? W : V;
             const int c = (st % strips) * 16 + l15;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const int g = grow(ks * 4 + l4);
+                const int g = bpair.row(ks * 4 + l4);
                 bv[u][ks] = (st < 2 * strips && g >= 0 && c < n) ? M[(int64_t)g * n + c] : 0.0;
             }
         }
-        f64x4e acc[4][2];
+        f64x4e acc[APPLY_STRIPS][2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < APPLY_STRIPS; ++u)
 #pragma unroll
             for (int to = 0; to < 2; ++to) acc[u][to] = f64x4e{0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const double j0 = J[ks * 4 + l4][l15], j1 = J[ks * 4 + l4][JB + l15];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(j0, bv[u][ks], acc[u][0], 0, 0, 0);
-                acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(j1, bv[u][ks], acc[u][1], 0, 0, 0);
+            for (int u = 0; u < APPLY_STRIPS; ++u) {
+                acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(j0[ks], bv[u][ks], acc[u][0], 0, 0, 0);
+                acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(j1[ks], bv[u][ks], acc[u][1], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < APPLY_STRIPS; ++u) {
             const int st = st0 + u;
             if (st >= 2 * strips) continue;
             double* M = st < strips ? W : V;
@@ -259,7 +339,7 @@ __global__ void __launch_bounds__(256) jacobi_block_round_kernel(double* __restr
             for (int to = 0; to < 2; ++to)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int g = grow(to * JB + l4 + 4 * r);
+                    const int g = bpair.row(to * JB + l4 + 4 * r);
                     if (g >= 0 && c < n) M[(int64_t)g * n + c] = acc[u][to][r];
                 }
         }
@@ -341,6 +421,10 @@ extern "C" size_t am_eigh_workspace_bytes(int D) {
     c.take<unsigned>(64);              // rotation counters, one per sweep
     c.take<double>(1);                 // trace of A
     c.take<int>(D);                    // initial row order
+    const size_t pairs = (size_t)((D + JB - 1) / JB + 1) / 2;
+    c.take<double>(pairs * GRAM_SLICES * JP * JP);   // partial Gram matrices of a round
+    c.take<double>(pairs * JP * JP);                 // accumulated rotations of a round
+    c.take<int>(pairs);                              // block pairs that rotated in a round
     return c.off;
 }
 
@@ -357,6 +441,10 @@ extern "C" int am_eigh_sym_f64(const double* A, int D, double* evals, double* ev
     unsigned* rotations = c.take<unsigned>(64);
     double* scale = c.take<double>(1);
     int* rank = c.take<int>(D);
+    const size_t pairs = (size_t)((D + JB - 1) / JB + 1) / 2;
+    double* Gpart = c.take<double>(pairs * GRAM_SLICES * JP * JP);
+    double* Jbuf = c.take<double>(pairs * JP * JP);
+    int* applied = c.take<int>(pairs);
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
     hipLaunchKernelGGL(jacobi_rank_kernel, dim3((unsigned)ceil_div(D, 256)), dim3(256), 0, st, A, D, rank);
     hipLaunchKernelGGL(jacobi_init_kernel, dim3((unsigned)std::min<int64_t>(1024, ceil_div((int64_t)D * D, 256))), dim3(256), 0, st, A, D,
@@ -372,8 +460,13 @@ extern "C" int am_eigh_sym_f64(const double* A, int D, double* evals, double* ev
     for (int done = 0; done < max_sweeps && !converged;) {
         const int block = std::min(done == 0 ? 12 : 6, max_sweeps - done);
         for (int sweep = done; sweep < done + block; ++sweep)
-            for (int round = 0; round < mb - 1; ++round)
-                hipLaunchKernelGGL(jacobi_block_round_kernel, dim3(mb / 2), dim3(256), 0, st, W, V, D, nb, mb, round, sweep, tol, scale, rotations);
+            for (int round = 0; round < mb - 1; ++round) {
+                hipLaunchKernelGGL(jacobi_gram_kernel, dim3(mb / 2, GRAM_SLICES), dim3(256), 0, st, W, D, nb, mb, round, sweep, rotations, Gpart);
+                hipLaunchKernelGGL(jacobi_inner_kernel, dim3(mb / 2), dim3(256), 0, st, Gpart, D, nb, mb, round, sweep, tol, scale, rotations,
+                                   Jbuf, applied);
+                hipLaunchKernelGGL(jacobi_apply_kernel, dim3(mb / 2, APPLY_SLICES), dim3(256), 0, st, W, V, D, nb, mb, round, sweep, rotations,
+                                   Jbuf, applied);
+            }
         AM_LAUNCH_CHECK();
         done += block;
         AM_HIP_TRY(hipMemcpyAsync(counts, rotations, (size_t)done * sizeof(unsigned), hipMemcpyDeviceToHost, st));
