@@ -1,3 +1,4 @@
+// (also: FOUR waves per CU, 128 x 128 per wave with the 256 accumulators in AGPRs - 8 fragment reads per 16 MFMAs)
 // Microbenchmark: does a 256 x 256 x 64 stage run faster with SIXTEEN waves per CU (1024-thread workgroup, four waves per
 // SIMD, 64 accumulator registers per wave) than with the wide engine's eight?  Same bytes through the LDS-DMA path (64 KB
 // per stage), same 256 MFMAs (v_mfma_f32_32x32x16_f16) per stage and CU, same vmcnt(0) + barrier per stage; fragment reads
@@ -21,7 +22,7 @@ __global__ void __launch_bounds__(NW * 64, 1) stage_kernel(const float* __restri
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int PIECES = 64 / NW;                    // DMA instructions per wave and stage (1 KB each)
-    constexpr int MT = NW == 8 ? 4 : 2, NT = 2;        // MFMA tiles per wave: 4 x 2 (128 x 64) or 2 x 2 (64 x 64)
+    constexpr int MT = NW == 16 ? 2 : 4, NT = NW == 4 ? 4 : 2;   // MFMA tiles per wave: 4 x 4 (128 x 128, accumulators in AGPRs), 4 x 2 (128 x 64) or 2 x 2 (64 x 64)
     const int srow = lane >> 3, chunk = lane & 7;      // a piece = 8 rows x 128 B
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -32,9 +33,9 @@ __global__ void __launch_bounds__(NW * 64, 1) stage_kernel(const float* __restri
             for (int j = 0; j < 16; ++j) acc[i][n][j] = 0.f;
     const int64_t nblk = src_rows / ROWS;
     // fragment rows of this wave inside the stage: Q rows 0..255, P rows 256..511
-    const int wm = NW == 8 ? wave >> 2 : wave >> 2, wn = wave & 3;     // 8 waves: 2 x 4 of (128 x 64); 16 waves: 4 x 4 of (64 x 64)
+    const int wm = NW == 4 ? wave >> 1 : wave >> 2, wn = NW == 4 ? wave & 1 : wave & 3;   // 4 waves: 2 x 2 of (128 x 128); 8: 2 x 4 of (128 x 64); 16: 4 x 4 of (64 x 64)
     const int r = lane & 31, h = lane >> 5;
-    const int qrow = (wm * (MT * 32) + r) * 32, prow = (256 + wn * 64 + r) * 32;
+    const int qrow = (wm * (MT * 32) + r) * 32, prow = (256 + wn * (NT * 32) + r) * 32;
     auto issue = [&](int g) {
         const int64_t blk = ((int64_t)blockIdx.x * 7 + (g >> 3) * 13) % nblk;
         const int kslab = g & 7;
@@ -111,6 +112,7 @@ int main() {
         for (int64_t i = 0; i < rows * 256; ++i) { s = s * 1664525u + 1013904223u; hsrc[i] = (s & 0x3fff3fffu) | 0x30003000u; }
         hipMemcpy(src, hsrc, rows * 1024, hipMemcpyHostToDevice);
         free(hsrc);
+        run<4>(src, rows, ld_words, out, src_mb);
         run<8>(src, rows, ld_words, out, src_mb);
         run<16>(src, rows, ld_words, out, src_mb);
         hipFree(src); hipFree(out);
