@@ -368,8 +368,57 @@ def gen_pca():
     print("pca singular values", out["fit1/singular_values_"], out["fit2/singular_values_"])
 
 
+# (seed of the global generator or None, explicit seed or None, items, buffer_size, min_age) per case
+STREAM_CASES = {
+    "global_small": (11, None, 40, 8, 0),
+    "global_aged": (5, None, 257, 100, 99),
+    "seeded": (None, 3, 1000, 100, 10),
+    "seeded_tiny_buffer": (None, 7, 50, 1, 0),
+    "short_input": (2, None, 5, 100, 3),
+    "age_beyond_buffer": (None, 9, 300, 10, 1000),
+    "empty": (1, None, 0, 10, 0),
+}
+SLICER_CASES = {            # (samples, win_dur, sr, hop_dur, drop_last)
+    "exact": (160000, 5.0, 16000, None, True),
+    "remainder": (170001, 5.0, 16000, None, True),
+    "short_dropped": (1000, 5.0, 16000, None, True),
+    "short_kept": (1000, 5.0, 16000, None, False),
+    "overlap": (48000, 1.0, 16000, 0.25, True),
+    "hop_longer": (100000, 0.5, 16000, 1.7, True),
+}
+
+
+def gen_util():
+    """Output sequences of the reference's stream helpers (util/shuffle.py:5-86, util/audio.py:1-14): the emitted order of
+    shuffle_stream for a given generator state, the (start, length) of every window of audio_slicer."""
+    import importlib.util
+    import random
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    r_shuffle, r_audio = load("ref_shuffle", "util/shuffle.py"), load("ref_audio", "util/audio.py")
+    out = {"versions": VERSIONS}
+    for name, (gseed, seed, n, buf, age) in STREAM_CASES.items():
+        if gseed is not None:
+            random.seed(gseed)
+        order = list(r_shuffle.shuffle_stream(iter(range(n)), buffer_size=buf, seed=seed, min_age=age))
+        out[f"stream/{name}/order"] = np.asarray(order, dtype=np.int64)
+        out[f"stream/{name}/params"] = np.asarray([-1 if gseed is None else gseed, -1 if seed is None else seed, n, buf, age],
+                                                  dtype=np.int64)
+        out[f"stream/{name}/next_draw"] = np.asarray([random.random()])      # the global generator's state afterwards
+    for name, (n, win, sr, hop, drop) in SLICER_CASES.items():
+        item = np.arange(n, dtype=np.int64)
+        wins = list(r_audio.audio_slicer(item, win, sr, hop_dur=hop, drop_last=drop))
+        out[f"slicer/{name}/windows"] = np.asarray([[w[0], len(w)] for w in wins], dtype=np.int64).reshape(-1, 2)
+        out[f"slicer/{name}/params"] = np.asarray([n, win, sr, -1.0 if hop is None else hop, float(drop)])
+    np.savez_compressed(os.path.join(HERE, "util.npz"), **out)
+    print("util", len(out) - 1, "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["stats", "fad", "kd", "prdc", "apa", "pca", "mix", "e2e"]
+    which = sys.argv[1:] or ["stats", "fad", "kd", "prdc", "apa", "pca", "mix", "util", "e2e"]
     for w in which:
         globals()[f"gen_{w}"]()
     print("done", VERSIONS)
