@@ -93,6 +93,22 @@ def _bulk_group(group):
     return cached[1]
 
 
+def warm_up_communicators(device, group=None):
+    """Create the second communicator and run one tiny collective on each of the two (every rank must call).  RCCL builds
+    a communicator lazily at its first collective (hundreds of milliseconds): a caller that times its first evaluate -
+    bench.py with --warmup 0 - pays that outside the timed region this way."""
+    world, _ = _world(group)
+    if _alone(world):
+        return
+    bulk = _bulk_group(group)
+    one = torch.ones(1, dtype=torch.float32, device=device)
+    out = torch.empty(world, dtype=torch.float32, device=device)
+    _all_gather_into(out, one, world, bulk)
+    _all_reduce(one, world, group)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
 def _all_gather_into(out, local, world, group, async_op=False):
     if _flat_gather_supported(group):
         return dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=async_op)

@@ -206,8 +206,10 @@ def main():
 
     import audio_metrics_amd as am
     from audio_metrics_amd import hip_ops as ops
-    from audio_metrics_amd.distributed import evaluate_sharded, shard_bounds
+    from audio_metrics_amd.distributed import evaluate_sharded, shard_bounds, warm_up_communicators
     am._lib.load()                                       # no HIP library -> fail here, loudly
+    if world > 1:
+        warm_up_communicators(dev)                       # both communicators exist before anything is timed (also with --warmup 0)
     import inputs as gi
 
     def fence():
