@@ -45,14 +45,31 @@ EMPTY_REFERENCE = ("The reference dataset is empty. This can have various causes
                    "    (You can specify your own `win_dur` when instantiating AudioMetrics)")
 
 
-def _visible_devices(device_indices):
+def _visible_devices(device_indices, one_process_per_gpu=False, embedder=None):
+    """The GPUs the embedder replicas run on, the reference's rule (util/gpu_parallel.py:24-28, audio_metrics.py:276-279):
+    ``None`` -> EVERY visible GPU; a non-empty sequence -> exactly those; an empty (falsy, not None) one -> no replica
+    handler at all: the embedder runs where it lives.  The first device of the list is this object's home (statistics,
+    stored rows, metric kernels): with ``None`` the thread's current device leads, the others follow in index order.
+    One process per GPU (``process_group``): the launcher gave every rank ITS device, so ``None`` means that device only
+    - all ranks replicating onto all GPUs would be world x world replicas."""
     if not torch.cuda.is_available():
         raise RuntimeError("No GPUs found, cannot compute audio metrics")            # gpu_parallel.py:27-28
+    current = torch.cuda.current_device()
     if device_indices is None:
-        return [torch.device("cuda", torch.cuda.current_device())]
+        if one_process_per_gpu:
+            return [torch.device("cuda", current)]
+        count = torch.cuda.device_count()
+        if count <= 0:
+            raise RuntimeError("No GPUs found, cannot use `gpu_parallel()`")
+        return [torch.device("cuda", i) for i in [current] + [i for i in range(count) if i != current]]
     devices = [torch.device("cuda", int(i)) for i in device_indices]
     if not devices:
-        raise RuntimeError("No GPUs found, cannot compute audio metrics")
+        home = None
+        if embedder is not None and not isinstance(embedder, str):
+            home = embedder.get_device()
+        if home is None or home.type != "cuda":
+            return [torch.device("cuda", current)]
+        return [torch.device("cuda", current if home.index is None else home.index)]
     return devices
 
 
@@ -70,7 +87,7 @@ class AudioMetrics:
 
     def __init__(self, metrics=["apa", "fad"], n_pca=None, device_indices=None, embedder=None, mix_function=None,
                  win_dur=5.0, input_sr=None, process_group=None):
-        self._devices = _visible_devices(device_indices)
+        self._devices = _visible_devices(device_indices, process_group is not None, embedder)
         self.device = self._devices[0]                 # where statistics, stored rows and metric kernels live
         self._group = process_group
         self.metrics = metrics
@@ -79,8 +96,6 @@ class AudioMetrics:
         self.input_sr = input_sr
         for name in PROJECTIONS:
             setattr(self, name, None if n_pca is None else IncrementalPCA(n_components=n_pca, device=self.device))
-        if n_pca is not None and process_group is not None:
-            raise NotImplementedError("n_pca is not supported together with process_group")
         self.embedder = self.get_embedder(embedder) if embedder is None or isinstance(embedder, str) else embedder
         # resolved (and, for the library's own names, checked for its dependencies) here rather than at the first mix
         self.mix_function = self.get_mix_function(mix_function)
@@ -163,8 +178,20 @@ class AudioMetrics:
     # ------------------------------------------------------------ PCA projection (audio_metrics.py:163-209)
     def _through(self, projection, data, store):
         out = AudioMetricsData(store, device=self.device)
+        if self._group is not None and (data is None or data.embeddings is None or data.embeddings.shape[0] == 0):
+            return out                                      # a rank that was fed no audio projects nothing
         out.add(projection.transform(data.embeddings))
         return out
+
+    def _fit(self, projection, data):
+        """partial_fit on the whole set (projection.py:6-46 via audio_metrics.py:170,188).  One process per GPU: the set is
+        the union of the ranks' shards - its statistics travel in two all-reduces and every rank runs the same fit."""
+        if self._group is None:
+            projection.partial_fit(data.embeddings)
+            return
+        from . import distributed
+        rows = distributed.local_rows(data, self._group)
+        projection.partial_fit(rows, batch_stats=distributed.global_stats(rows, self._group))
 
     def _projected(self, projection_name, names, candidate, store):
         """(references of `names`..., candidate) in the space of `projection_name`; the projected reference sets
@@ -174,7 +201,7 @@ class AudioMetrics:
             return [getattr(self, n) for n in names] + [candidate]
         shadows = [REFERENCE_SETS[n].shadow for n in names]
         if getattr(self, shadows[0]) is None:
-            projection.partial_fit(getattr(self, names[0]).embeddings)
+            self._fit(projection, getattr(self, names[0]))
             for n, shadow in zip(names, shadows):
                 setattr(self, shadow, self._through(projection, getattr(self, n), store))
         return [getattr(self, s) for s in shadows] + [self._through(projection, candidate, store)]
@@ -233,6 +260,10 @@ class AudioMetrics:
             if "prdc" in wanted:
                 slot = "radii_%d" % k
                 if slot in side.radii:
+                    # the cache survives appends (reference quirk, data.py:60-66 vs 68-72): radii of FEWER rows than the set
+                    # now holds cannot go through the raw-pointer call - the per-metric runner raises the shape error
+                    if side.radii[slot].numel() != side.embeddings.shape[0]:
+                        return None
                     g["radii"] = side.radii[slot]
                 else:
                     g["radii_out"] = torch.empty(side.embeddings.shape[0], dtype=torch.float32, device=self.device)

@@ -137,10 +137,16 @@ extern "C" int am_evaluate_f32(const float* ref, int64_t n_ref, int64_t ld_ref, 
         }
     }
     // (events are per call: two host threads may evaluate on one device at the same time, each on its own streams)
-    hipEvent_t ev_stats = nullptr, ev_fad = nullptr;
+    // (destroyed on every way out: an entry point below may return an error between creation and the waits)
+    struct EventGuard {
+        hipEvent_t e = nullptr;
+        ~EventGuard() {
+            if (e) (void)hipEventDestroy(e);                         // (released once the recorded work has completed)
+        }
+    } ev_stats, ev_fad;
     if (what & AM_EVAL_FAD) {
-        AM_HIP_TRY(hipEventCreateWithFlags(&ev_stats, hipEventDisableTiming));
-        AM_HIP_TRY(hipEventRecord(ev_stats, st));
+        AM_HIP_TRY(hipEventCreateWithFlags(&ev_stats.e, hipEventDisableTiming));
+        AM_HIP_TRY(hipEventRecord(ev_stats.e, st));
     }
 
     // ---- PRDC on the caller's stream
@@ -181,17 +187,15 @@ extern "C" int am_evaluate_f32(const float* ref, int64_t n_ref, int64_t ld_ref, 
     // ---- Frechet blocks: enqueued LAST by the host (the caller's stream already holds the long kernels, so the GPU never
     //      waits for these launches), executed on the side stream as soon as the statistics exist
     if (what & AM_EVAL_FAD) {
-        AM_HIP_TRY(hipStreamWaitEvent(side, ev_stats, 0));
-        AM_HIP_TRY(hipEventDestroy(ev_stats));                       // (released once the recorded work has completed)
+        AM_HIP_TRY(hipStreamWaitEvent(side, ev_stats.e, 0));
         const int block = am_frechet_first_block(), max_iter = 64;
         for (int first = 0; first < 2 * block; first += block)
             if ((rc = am_frechet_enqueue_f64(mean[1], cov[1], mean[0], cov[0], D, first, block, max_iter, 1e-13, L.fad_out,
                                              L.ws_fad, L.fad_ws, side_stream)) != AM_OK)
                 return rc;
-        AM_HIP_TRY(hipEventCreateWithFlags(&ev_fad, hipEventDisableTiming));
-        AM_HIP_TRY(hipEventRecord(ev_fad, side));
-        AM_HIP_TRY(hipStreamWaitEvent(st, ev_fad, 0));
-        AM_HIP_TRY(hipEventDestroy(ev_fad));
+        AM_HIP_TRY(hipEventCreateWithFlags(&ev_fad.e, hipEventDisableTiming));
+        AM_HIP_TRY(hipEventRecord(ev_fad.e, side));
+        AM_HIP_TRY(hipStreamWaitEvent(st, ev_fad.e, 0));
     }
     hipLaunchKernelGGL(eval_pack_kernel, dim3(1), dim3(64), 0, st, L.fad_out, L.totals, out, what);
     AM_LAUNCH_CHECK();

@@ -458,7 +458,10 @@ static int run_kd(const float* X, int64_t N1, int64_t ldx, const float* Y, int64
         double* partial = c.take<double>((size_t)S * per_subset);
         uint16_t* planes = c.take<uint16_t>((size_t)S * 2 * MP * 2 * DP);
         float* unscale = c.take<float>((size_t)S * 2 * MP);
-        if (c.ok()) {                                     // (a workspace sized by the D-less am_kd_workspace_bytes: f32 form below)
+        // the form is a function of the SHAPES alone (identical inputs give identical bits whatever buffer they come with): a
+        // workspace sized by the D-less am_kd_workspace_bytes is an error here, not a switch to the f32 kernel
+        AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small for the split-f16 form these shapes take: need %zu bytes "
+                   "(am_kd_poly_workspace_bytes), have %zu", c.off, ws_bytes);
         const int64_t rows = (int64_t)S * 2 * MP;
         hipLaunchKernelGGL(kd_split_gather_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, X, ldx, Y, ldy, D, DP, idx1,
                            idx2, S, m, MP, planes, unscale);
@@ -470,7 +473,6 @@ static int run_kd(const float* X, int64_t N1, int64_t ldx, const float* Y, int64
         hipLaunchKernelGGL(kd_finish_kernel, dim3((unsigned)ceil_div(S, 64)), dim3(64), 0, st, partial, S, m, T, ntri, out_mmd);
         AM_LAUNCH_CHECK();
         return AM_OK;
-        }
     }
     const int T = (int)ceil_div(m, TB);
     const int ntri = T * (T + 1) / 2;
@@ -519,8 +521,9 @@ static int run_kd(const float* X, int64_t N1, int64_t ldx, const float* Y, int64
 using namespace am;
 
 extern "C" size_t am_kd_workspace_bytes(int S, int m) {
-    // the f32 form's workspace (this query does not know the feature width; with it am_kd_poly_f32 runs the f32 kernel -
-    // am_kd_poly_workspace_bytes sizes the split-f16 form)
+    // the f32 form's workspace: enough for every shape that does NOT take the split-f16 form (m < 512, D < 128 or D > 8192,
+    // degree != 3).  This query does not know the feature width; am_kd_poly_workspace_bytes(S, m, D) is the one that is
+    // right for every shape, and am_kd_poly_f32 returns AM_ERR_WORKSPACE (with the size it needs) for a short buffer.
     if (S < 1 || m < 1) return 0;
     const int T = (int)ceil_div(m, TB);
     Carver c(nullptr, 0);

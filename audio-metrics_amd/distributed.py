@@ -74,18 +74,22 @@ def _flat_gather_supported(group):
 _BULK = {}
 
 
-def _bulk_group(group):
-    """A SECOND communicator over the same ranks for the two big row gathers (205 MB per set at 2 x 100k x 512).
-    The collectives of one communicator run in issue order on one stream: with a single one the 400 KB all-gathers of the
-    reference set's k-NN (bounds, lists) would queue behind the candidate set's row gather, so both gathers had to be
-    waited for before any pairwise kernel could start.  On their own communicator the candidate rows travel while the
-    reference set's radii are computed.  Only for the default group (``new_group`` must be entered by every process of
-    the job, which this function cannot promise for a caller's sub-group): a sub-group keeps one communicator."""
+def enable_bulk_communicator(group=None):
+    """OPTIONAL second communicator over the same ranks for the two big row gathers (205 MB per set at 2 x 100k x 512) -
+    a setup-time COLLECTIVE: every process of the job must call it (``dist.new_group``), once, before the first evaluate;
+    it is never created behind the caller's back.  Default: off.
+    The collectives of one communicator run in issue order on one stream.  With a single communicator (the default)
+    ``evaluate_sharded`` therefore issues the candidate rows' gather right BEHIND the reference set's bounds exchange, so
+    that it travels under the reference set's sweep and only the reference set's list exchange queues behind it; with the
+    second communicator the candidate rows start travelling a little earlier (under the statistics kernels and the
+    bounds pre-pass).  The price of the second one is two RCCL communicators with collectives in flight on one device at
+    the same time - safe only as long as both kernels can be resident together - which is why it has to be asked for.
+    Only for the default group (a sub-group keeps one communicator)."""
     if not (dist.is_available() and dist.is_initialized()):
-        return group
+        return None
     default = dist.group.WORLD
     if group is not None and group is not default:
-        return group
+        return None
     cached = _BULK.get("pair")
     if cached is None or cached[0] is not default:
         cached = (default, dist.new_group())
@@ -93,20 +97,44 @@ def _bulk_group(group):
     return cached[1]
 
 
+def disable_bulk_communicator():
+    """Back to one communicator (collective in the sense that every rank must do the same)."""
+    cached = _BULK.pop("pair", None)
+    if cached is not None and dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group(cached[1])
+
+
+def _bulk_group(group):
+    """The second communicator when ``enable_bulk_communicator`` created one for this group, else None."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    default = dist.group.WORLD
+    if group is not None and group is not default:
+        return None
+    cached = _BULK.get("pair")
+    if cached is None or cached[0] is not default:
+        return None
+    return cached[1]
+
+
 def warm_up_communicators(device, group=None):
-    """Create the second communicator and run one tiny collective on each of the two (every rank must call).  RCCL builds
-    a communicator lazily at its first collective (hundreds of milliseconds): a caller that times its first evaluate -
-    bench.py with --warmup 0 - pays that outside the timed region this way."""
+    """One tiny collective on every communicator evaluate_sharded will use (every rank must call).  RCCL builds a
+    communicator lazily at its first collective (hundreds of milliseconds): a caller that times its first evaluate -
+    bench.py with --warmup 0 - pays that outside the timed region this way.  Returns the number of ranks the all-reduce
+    saw (a sum of ones: what the launcher promised must be what RCCL connected)."""
     world, _ = _world(group)
     if _alone(world):
-        return
-    bulk = _bulk_group(group)
+        return 1
     one = torch.ones(1, dtype=torch.float32, device=device)
     out = torch.empty(world, dtype=torch.float32, device=device)
-    _all_gather_into(out, one, world, bulk)
+    _all_gather_into(out, one, world, group)
+    bulk = _bulk_group(group)
+    if bulk is not None:
+        _all_gather_into(out, one, world, bulk)
     _all_reduce(one, world, group)
     if device.type == "cuda":
         torch.cuda.synchronize(device)
+    return int(round(float(one.item())))
 
 
 def _all_gather_into(out, local, world, group, async_op=False):
@@ -180,7 +208,12 @@ def local_rows(data, group=None):
         if rows is None:
             raise ValueError("the metric needs the stored embeddings of a set that kept none")
         return rows
-    dev = data.device if data is not None else torch.device("cpu")
+    if data is not None:
+        dev = data.device
+    elif _flat_gather_supported(group):                    # RCCL reduces device tensors only
+        dev = torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = torch.device("cpu")
     t = torch.tensor([0 if rows is None else rows.shape[1], 0 if stores else 1], dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     width, someone_keeps_none = (int(v) for v in t.cpu().tolist())
@@ -223,6 +256,28 @@ def global_stats_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group):
     mean_r, mean_c = global_means_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group)
     cov_r, cov_c = global_covariances_pair(ref_local, cand_local, mean_r, mean_c, n_ref, n_cand, ops, world, group)
     return (mean_r, cov_r), (mean_c, cov_c)
+
+
+def global_stats(local, group=None, ops=None):
+    """(n, mean f64[D], unbiased covariance f64[D, D]) of ONE row-sharded set (every rank must call; a rank may hold zero
+    rows): row count and column sums in one all-reduce, centred scatters in a second - the statistics IncrementalPCA's
+    partial_fit needs of the union of the shards (projection.py:6-46 fits on the whole reference set)."""
+    if ops is None:
+        from . import hip_ops as ops
+    world, _ = _world(group)
+    d, dev = local.shape[1], local.device
+    head = torch.zeros(d + 1, dtype=torch.float64, device=dev)
+    if local.shape[0] > 0:
+        head[:d] = ops.colsum(local)
+        head[d] = float(local.shape[0])
+    _all_reduce(head, world, group)
+    n = int(round(float(head[d].item())))
+    if n == 0:
+        raise ValueError(f"empty embedding set over {world} ranks")
+    mean = head[:d] / float(n)
+    sc = ops.scatter(local, mean) if local.shape[0] > 0 else torch.zeros((d, d), dtype=torch.float64, device=dev)
+    _all_reduce(sc, world, group)
+    return n, mean, sc / float(max(n - 1, 1))
 
 
 class _Stats:
@@ -274,8 +329,10 @@ def merged_stats(data, group=None, ops=None):
     return _Stats(n or None, mean, cov)
 
 
-def sharded_radii(local, full, counts, k, ops, world, rank, group, prepared=None):
+def sharded_radii(local, full, counts, k, ops, world, rank, group, prepared=None, after_first_exchange=None):
     """k-NN radii of a row-sharded set whose gathered copy `full` every rank holds.
+    after_first_exchange: called once, right behind the first collective this function issues (the bounds all-gather of the
+    partitioned form; at the start otherwise) - where the caller queues a long transfer that may run under the sweep.
     Returns (radii of this rank's rows, radii of all rows).  Wide, large sets take the partitioned symmetric
     kernel (half the tile pairs; rank r owns a contiguous range of the 128-row blocks; per-row lists all-gathered
     and merged); otherwise every rank runs the general kernel on its row shard against all columns."""
@@ -285,11 +342,15 @@ def sharded_radii(local, full, counts, k, ops, world, rank, group, prepared=None
     if not _alone(world) and min(counts) > 0 and hasattr(ops, "knn_sym_part") and ops.knn_sym_eligible(n, d, k):
         extra = {} if prepared is None else {"prepared": prepared}
         bounds = _all_gather_rows(ops.knn_bounds(full, k, lo, counts[rank], **extra), counts, world, group)
+        if after_first_exchange is not None:
+            after_first_exchange()
         lists = ops.knn_sym_part(full, k, rank, world, bounds, **extra)
         all_lists = torch.empty((world, *lists.shape), dtype=lists.dtype, device=lists.device)
         _all_gather_into(all_lists.view(-1), lists.view(-1), world, group)
         r_full = ops.knn_lists_finish(all_lists, full, k)
         return r_full[lo:hi], r_full
+    if after_first_exchange is not None:
+        after_first_exchange()
     if _alone(world) and prepared is not None:
         r_local = ops.knn_radii(full, k, prepared=prepared)
     elif local.shape[0] > 0:
@@ -386,19 +447,31 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
         raise ValueError(f"empty embedding set: {n_ref} reference and {n_cand} candidate rows over {world} ranks")
     d = ref_local.shape[1]
 
-    # 1) the 8 KB column-sum all-reduce goes FIRST: the collectives of one process group run in issue order on one
-    #    communication stream, so anything issued behind the 410 MB gather waits for all of it - and the centred scatter
-    #    kernels need the global means.  2) the big exchange is started (asynchronously).  3) the scatter kernels run on
-    #    the compute stream while the gather is in flight; their 4 MB all-reduce queues behind it, which is fine: only the
-    #    Frechet solve on the side stream waits for it.
+    # 1) the 8 KB column-sum all-reduce goes FIRST: the collectives of one communicator run in issue order on one
+    #    communication stream, so anything issued behind a 205 MB gather waits for all of it - and the centred scatter
+    #    kernels need the global means.  2) the reference rows' gather is started (asynchronously).  3) the scatter kernels
+    #    run on the compute stream while it is in flight; their 4 MB all-reduce queues behind it, which is fine: only the
+    #    Frechet solve on the side stream waits for it.  4) the candidate rows' gather: with PRDC it is issued right behind
+    #    the reference set's bounds exchange (start_cand below) and travels under the reference set's sweep - issued here,
+    #    on the same communicator, that 400 KB exchange would wait for all 205 MB of it; without PRDC (KD only), or on the
+    #    optional second communicator (enable_bulk_communicator), it starts at once.
     need_full = ("kd" in metrics) or ("prdc" in metrics)
     means = None
     if "fad" in metrics:
         means = global_means_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group)
+    ref_g = cand_g = bulk = None
     if need_full:
-        bulk = group if _alone(world) else _bulk_group(group)          # (every rank enters: collective on first use)
-        ref_g = _Gathered(ref_local, ref_counts, world, bulk)
-        cand_g = _Gathered(cand_local, cand_counts, world, bulk)
+        bulk = None if _alone(world) else _bulk_group(group)
+        ref_g = _Gathered(ref_local, ref_counts, world, bulk if bulk is not None else group)
+
+    def start_cand():
+        nonlocal cand_g
+        if cand_g is None:
+            cand_g = _Gathered(cand_local, cand_counts, world, bulk if bulk is not None else group)
+        return cand_g
+
+    if need_full and (bulk is not None or "prdc" not in metrics):
+        start_cand()
 
     # statistics; the Frechet solve goes to a side stream right away (its stopping rule runs on the device, so
     # the host just enqueues it) and overlaps the PRDC chain issued next
@@ -414,13 +487,14 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
         k = nearest_k
         # norms, maxima and scaled f16 copies of the two gathered sets: once per evaluate, shared by the k-NN entry points
         # and the membership counts (the reference shard of this rank is a row range of the prepared reference set).
-        # The reference set's radii are under way before the candidate rows are waited for: their gather (second
-        # communicator) overlaps the reference set's sweep.
+        # The reference set's radii are under way before the candidate rows are waited for: their gather overlaps the
+        # reference set's sweep.
         prepare = getattr(ops, "prepare", None)
         ref_full = ref_g.rows()
         prep_r = prepare(ref_full) if prepare is not None else None
-        r_ref_l, _ = sharded_radii(ref_local, ref_full, ref_counts, k, ops, world, rank, group, prep_r)
-        cand_full = cand_g.rows()
+        r_ref_l, _ = sharded_radii(ref_local, ref_full, ref_counts, k, ops, world, rank, group, prep_r,
+                                   after_first_exchange=start_cand)
+        cand_full = start_cand().rows()
         prep_c = prepare(cand_full) if prepare is not None else None
         _, r_cand = sharded_radii(cand_local, cand_full, cand_counts, k, ops, world, rank, group, prep_c)
         packed = torch.zeros(n_cand + 2, dtype=torch.int32, device=dev)        # column counts | #rows any | #rows covered
@@ -443,7 +517,7 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
             m = max(1, min(n_ref, n_cand) // 2)
         idx1, idx2 = subset_indices(n_cand, n_ref, kid_subsets, m, rng_seed)     # features_1 = candidate
         mmds = torch.zeros(kid_subsets, dtype=torch.float64, device=dev)
-        ref_full, cand_full = ref_g.rows(), cand_g.rows()
+        ref_full, cand_full = ref_g.rows(), start_cand().rows()
         if rank < kid_subsets:                                 # this rank's subsets: rank, rank + world, ...
             upload = getattr(ops, "upload_host_array", None) or _plain_upload
             part = ops.kd_poly(cand_full, ref_full, upload(idx1[rank::world], dev), upload(idx2[rank::world], dev),

@@ -210,40 +210,55 @@ def rendered_batches(source, batch_size=32, ring=4, guards=None):
     """``batches_of(source, ...)`` with the copy into the batch buffer done by the worker that mixed the window: a job
     knows its (batch, row) position when it is created - jobs are numbered in emission order - so the consumer thread only
     hands out rows and collects finished batches.  (Copying 32 x 960 KB per batch on the consumer thread was a third of
-    the pipeline's wall time once mixing itself ran on the pool.)  Stems-only streams (nothing to mix) and window streams
-    of mixed shapes / dtypes fall back to ``batches_of``."""
+    the pipeline's wall time once mixing itself ran on the pool.)  The batch buffers take the dtype and length of the first
+    RENDERED window (a mix function may return float64 for float32 input, or float for integer PCM - the mixers divide);
+    the first window is therefore rendered on the consumer thread.  Stems-only streams (nothing to mix) and mixers whose
+    output is not a 1-D array go through ``batches_of``; a later window whose rendered length differs is a ValueError that
+    names both shapes (the reference's np.stack fails on it too, embed.py:218-225)."""
     if source.apa_mode is None:
         yield from batches_of(source, batch_size, ring=ring, guards=guards)
         return
     workers = source.mix_workers
     lookahead = 2 * max(workers, 1) + 2
-    buffers = []                                   # ring of [batch_size, n] arrays
-    state = {"shape": None, "dtype": None}
+    jobs = iter(source._jobs())
+    try:
+        first_job = next(jobs)
+    except StopIteration:
+        return
+    first_category, first_samples = source._render(first_job)
+    first_samples = np.asarray(first_samples)
+    if first_samples.ndim != 1:
+        from itertools import chain
+        rest = ordered_map(source._render, jobs, workers, lookahead)
+        yield from batches_of(chain([(first_category, first_samples)], rest), batch_size, ring=ring, guards=guards)
+        return
+    out_len, out_dtype = first_samples.shape[0], first_samples.dtype
+    buffers = []                                   # ring of [batch_size, out_len] arrays
 
-    def buffer_for(batch_no, n, dtype):
+    def buffer_for(batch_no):
         slot = batch_no % ring
         if slot >= len(buffers):
-            buffers.append(np.empty((batch_size, n), dtype=dtype))
+            buffers.append(np.empty((batch_size, out_len), dtype=out_dtype))
         return slot, buffers[slot]
+
+    def copy_in(samples, dst):
+        samples = np.asarray(samples)
+        if samples.shape != dst.shape:
+            raise ValueError(f"mixed windows of different shapes in one stream: the first one rendered to {dst.shape} "
+                             f"({dst.dtype}), a later one to {samples.shape} ({samples.dtype})")
+        t0 = time.perf_counter()
+        np.copyto(dst, samples, casting="unsafe")      # (a dtype that differs from the first window's is converted to it)
+        _tick("batch_copy_in_workers", t0)
 
     def render_into(job, dst):
         category, samples = source._render(job)
-        samples = np.asarray(samples)
-        if samples.shape != dst.shape or samples.dtype != dst.dtype:
-            raise _ShapeChanged()
-        t0 = time.perf_counter()
-        np.copyto(dst, samples)
-        _tick("batch_copy_in_workers", t0)
+        copy_in(samples, dst)
         return int(category)
-
-    class _ShapeChanged(Exception):
-        pass
 
     pool = ThreadPoolExecutor(max_workers=max(workers, 1), thread_name_prefix="am-mix")
     try:
-        pending = deque()                          # (future, batch number, row)
-        tags, count, batch_no = [], 0, 0
-        current_slot = None
+        pending = deque()                          # (future or finished tag, batch number, row)
+        tags, batch_no = [], 0
 
         def finish_batch(rows_in_batch, slot):
             batch = {"audio": buffers[slot][:rows_in_batch], "category": np.array(tags[:rows_in_batch]), "_slot": slot}
@@ -252,23 +267,17 @@ def rendered_batches(source, batch_size=32, ring=4, guards=None):
 
         def drain(limit):
             # collect finished jobs in order until at most `limit` are pending; yields complete batches
-            nonlocal count
             while len(pending) > limit:
                 fut, bno, row = pending.popleft()
                 t0 = time.perf_counter()
-                tags.append(fut.result())
+                tags.append(fut if isinstance(fut, int) else fut.result())
                 _tick("mix_wait", t0)
                 if row == batch_size - 1:
                     yield finish_batch(batch_size, bno % ring)
 
         row = 0
-        for job in source._jobs():
-            window = job[1]
-            n, dtype = window.shape[0], window.dtype
-            if state["shape"] is None:
-                state["shape"], state["dtype"] = n, dtype
-            elif (n, dtype) != (state["shape"], state["dtype"]):
-                raise ValueError("windows of different lengths or dtypes in one stream")
+        from itertools import chain
+        for job in chain([None], jobs):            # None = the window already rendered above
             if row == 0:
                 # the buffer this batch goes to may still be read by the device copy of the batch that used it `ring` batches ago
                 slot = batch_no % ring
@@ -276,8 +285,12 @@ def rendered_batches(source, batch_size=32, ring=4, guards=None):
                 if guard is not None:
                     guard.synchronize()
                 # and every job writing to it must have been collected (they have: ring > batches in flight in `pending`)
-            slot, buf = buffer_for(batch_no, n, dtype)
-            pending.append((pool.submit(render_into, job, buf[row]), batch_no, row))
+            slot, buf = buffer_for(batch_no)
+            if job is None:
+                copy_in(first_samples, buf[row])
+                pending.append((int(first_category), batch_no, row))
+            else:
+                pending.append((pool.submit(render_into, job, buf[row]), batch_no, row))
             row += 1
             if row == batch_size:
                 row, batch_no = 0, batch_no + 1

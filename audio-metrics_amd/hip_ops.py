@@ -611,8 +611,19 @@ def _eval_workspace(nbytes, device):
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _EVAL_WS.get(key)
     if ws is None or ws.numel() < nbytes:
+        _EVAL_WS.pop(key, None)                                  # (the old block goes back to the allocator first)
+        ws = None
         ws = _EVAL_WS[key] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
     return ws
+
+
+def release_workspaces(device=None):
+    """Hand the cached evaluate workspaces (1.2 GB per (device, stream) at 2 x 100k x 512, 19.6 GB at 2 x 1M) back to
+    torch's caching allocator - for callers that run one large evaluate and then need the memory for something else.
+    The next evaluate allocates again.  `device`: only that GPU's."""
+    index = None if device is None else torch.device(device).index
+    for key in [k for k in _EVAL_WS if index is None or k[0] == index]:
+        del _EVAL_WS[key]
 
 
 def evaluate(ref, cand, what, nearest_k=5, idx_cand=None, idx_ref=None, gamma=None, coef0=1.0, degree=3,
@@ -635,13 +646,19 @@ def evaluate(ref, cand, what, nearest_k=5, idx_cand=None, idx_ref=None, gamma=No
         s, m = idx_cand.shape
     keep = []
 
-    def side(given):
+    def side(given, rows):
+        # the C ABI reads and writes raw pointers: every tensor is checked against the shape the chain assumes for it
         if not given:
             return None
         st = _lib.EvaluateSideStruct()
         for key in ("mean", "cov", "mean_out", "cov_out"):
             t = given.get(key)
             if t is not None:
+                want = (d,) if key.startswith("mean") else (d, d)
+                if tuple(t.shape) != want:
+                    raise ValueError(f"{key} has shape {tuple(t.shape)}, the embeddings need {want}")
+                if key.endswith("_out") and (t.dtype != torch.float64 or not t.is_contiguous()):
+                    raise ValueError(f"{key} must be a contiguous f64 tensor (the chain writes into it)")
                 t = _f64(t, key)
                 if t.device != dev:
                     raise ValueError(f"{key} lives on {t.device}, the embeddings on {dev}")
@@ -653,11 +670,13 @@ def evaluate(ref, cand, what, nearest_k=5, idx_cand=None, idx_ref=None, gamma=No
                 _require_cuda(t, key)
                 if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
                     raise ValueError(f"{key} must be a contiguous f32 tensor on {dev}")
+                if t.numel() != rows:
+                    raise ValueError(f"radius / embedding shapes do not match: {key} holds {t.numel()} values, the set {rows} rows")
                 keep.append(t)
                 setattr(st, key, t.data_ptr())
         return st
 
-    s_ref, s_cand = side(given_ref), side(given_cand)
+    s_ref, s_cand = side(given_ref, n_ref), side(given_cand, n_cand)
     with torch.cuda.device(dev):
         main = torch.cuda.current_stream(dev)
         side_stream = _SIDE_STREAMS.get(("fad", dev.index))

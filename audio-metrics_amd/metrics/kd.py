@@ -55,32 +55,42 @@ def subset_indices_native(n_samples_1, n_samples_2, kid_subsets, kid_subset_size
     return idx1, idx2
 
 
-_NATIVE_DRAW_CHECKED = False
+_NATIVE_DRAW_OK = None           # None: not checked yet in this process
 
 
-def _check_native_draw():
+def _native_draw_usable():
     """Once per process: am_kd_draw_indices must reproduce numpy on both of its branches (Floyd, tail shuffle) and across
-    consecutive draws.  A numpy release that changes Generator.choice makes this a HARD error (no silent second path):
-    the KD values are defined by numpy's draw sequence (kd.py:176,185-186), and tests/test_kd_draw_cpu.py pins the numpy
-    versions the restatement has been checked against."""
-    global _NATIVE_DRAW_CHECKED
-    if _NATIVE_DRAW_CHECKED:
-        return
-    for n1, n2, s, m, seed in ((20011, 777, 3, 37, 1234), (12000, 30000, 2, 700, 7)):
-        a = subset_indices_native(n1, n2, s, m, seed)
-        b = subset_indices_numpy(n1, n2, s, m, seed)
-        if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])):
-            raise RuntimeError(f"am_kd_draw_indices does not reproduce numpy {np.__version__}'s Generator.choice; "
-                               "the kernel-distance subsets would differ from the reference's")
-    _NATIVE_DRAW_CHECKED = True
+    consecutive draws.  numpy's own call IS the definition of the subsets (kd.py:176,185-186): when a numpy release changes
+    Generator.choice (or its bit-generator state layout) the restatement is set aside with ONE warning and every table comes
+    from numpy itself - slower by ~10 ms per evaluate, never different from the reference.  tests/test_kd_draw_cpu.py pins
+    the numpy versions the restatement has been checked against."""
+    global _NATIVE_DRAW_OK
+    if _NATIVE_DRAW_OK is not None:
+        return _NATIVE_DRAW_OK
+    ok = True
+    try:
+        for n1, n2, s, m, seed in ((20011, 777, 3, 37, 1234), (12000, 30000, 2, 700, 7)):
+            a = subset_indices_native(n1, n2, s, m, seed)
+            b = subset_indices_numpy(n1, n2, s, m, seed)
+            ok = ok and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    except (RuntimeError, KeyError, TypeError) as e:              # unexpected bit-generator state layout
+        ok = False
+        logging.getLogger(__name__).debug("native KD draw unusable: %s", e)
+    if not ok:
+        import warnings
+        warnings.warn(f"audio_metrics_amd: am_kd_draw_indices does not reproduce numpy {np.__version__}'s Generator.choice; "
+                      "the kernel-distance subsets are drawn with numpy's own calls instead (same values as the reference, "
+                      "about 10 ms slower per evaluate)", RuntimeWarning, stacklevel=3)
+    _NATIVE_DRAW_OK = ok
+    return ok
 
 
 def subset_indices(n_samples_1, n_samples_2, kid_subsets, kid_subset_size, rng_seed):
-    """The reference's index table (kd.py:176,185-186).  Row counts that do not fit 32 bits use numpy's own calls (the
-    native restatement covers numpy's 32-bit bounded-draw path only)."""
-    if max(n_samples_1, n_samples_2) >= 0xFFFFFFFF:
+    """The reference's index table (kd.py:176,185-186).  Row counts that do not fit 32 bits, seeds that are not plain
+    integers and a numpy whose draws the native restatement does not reproduce use numpy's own calls (the restatement
+    covers numpy's 32-bit bounded-draw path only)."""
+    if max(n_samples_1, n_samples_2) >= 0xFFFFFFFF or not _native_draw_usable():
         return subset_indices_numpy(n_samples_1, n_samples_2, kid_subsets, kid_subset_size, rng_seed)
-    _check_native_draw()
     return subset_indices_native(n_samples_1, n_samples_2, kid_subsets, kid_subset_size, rng_seed)
 
 

@@ -41,9 +41,16 @@ class IncrementalPCA:
             self._device = x.device
         return ops.as_matrix(x)
 
-    def partial_fit(self, X, y=None, check_input=True):
+    def partial_fit(self, X, y=None, check_input=True, batch_stats=None):
+        """scikit-learn's incremental update from one batch.  batch_stats = (n, mean f64[D], cov f64[D, D]) of the batch when
+        the caller already holds them - the row-sharded form (one process per GPU): the batch is the union of every rank's
+        rows, its statistics come from two all-reduces (distributed.global_stats) and the fit below, a function of those
+        statistics and the previous state only, runs replicated on every rank; X is then this rank's shard (possibly
+        empty) and is used for its width only."""
         X = self._to_device(X)
         n_samples, n_features = X.shape
+        if batch_stats is not None:
+            n_samples = int(batch_stats[0])
         first_pass = getattr(self, "components_", None) is None
         if self.n_components is None:
             self.n_components_ = min(n_samples, n_features) if first_pass else self.components_.shape[0]
@@ -56,7 +63,10 @@ class IncrementalPCA:
         else:
             self.n_components_ = self.n_components
 
-        mean_b, cov_b = ops.stats(X)                          # f64 on the device
+        if batch_stats is not None:
+            mean_b, cov_b = (ensure_tensor(t).to(X.device, torch.float64) for t in batch_stats[1:])
+        else:
+            mean_b, cov_b = ops.stats(X)                      # f64 on the device
         if n_samples > 1:
             scatter_b = cov_b * float(n_samples - 1)
         else:

@@ -4,6 +4,7 @@
 configs[2]), on N GPUs of one node.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          # starts its own N ranks (child process: torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
     python bench.py --config e2e          # BASELINE configs[4] shape: audio -> embedder -> APA + FAD (see run_e2e)
@@ -157,6 +158,78 @@ def stream_add(am, x, batch, store, reps=1):
             "rows": n, "batch": batch, "store_embeddings": bool(store)}
 
 
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` invoked plainly (no launcher in the environment): start the N ranks as a CHILD process -
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` - before this process has touched the
+    GPU, let the child write rank 0's JSON line to our stdout, and exit with its code.  (A child, never an exec: replacing
+    a process that has initialised the GPU takes the box down on this pool; this one has not - `import torch` does not -
+    but a child is right either way.)  The reference's multi-GPU entry needs no launcher either (util/gpu_parallel.py:79-118)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC is the only form the host driver supports
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n_ranks, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def library_stamp():
+    """sha256 over the sources / headers / flags the LOADED library was built from (lib/*.so.stamp.json)."""
+    from audio_metrics_amd import _build, _lib
+    try:
+        with open(_build._stamp_path(_lib.library_path())) as f:
+            return json.load(f).get("sources_sha256")
+    except (OSError, ValueError):
+        return None
+
+
+def recorded_traffic(kernel, stamp):
+    """(bytes per launch or None, provenance) of `kernel` from profiles/traffic.json: PMC counters (FETCH_SIZE x 2 +
+    WRITE_SIZE, separate --pmc passes) cannot be collected inside an unprofiled bench run, so the figure is a RECORD of the
+    profile named in the table - valid only for the library it was measured on: when the loaded library was built from
+    other sources than the profiled one, `traffic` is null and the provenance says so."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None, {"table": None}
+    entry = table.get("kernels", {}).get(kernel)
+    if entry is None:
+        return None, {"table": "profiles/traffic.json", "kernel": kernel, "state": "no record for this kernel"}
+    same = stamp is not None and entry.get("sources_sha256") == stamp
+    source = {"table": "profiles/traffic.json", "profile": entry.get("profile"), "measured_on_sources_sha256": entry.get("sources_sha256"),
+              "loaded_sources_sha256": stamp, "l2_hit": entry.get("l2_hit"),
+              "state": "recorded on this library" if same else "STALE: the loaded library was built from other sources than the "
+                       "profiled one - re-run tools/profile_bench.sh + tools/update_traffic.py"}
+    return (entry.get("bytes_per_launch") if same else None), source
+
+
+def first_call(step, fence, samples=3):
+    """A step that finds NOTHING from an earlier one but the loaded code objects: the KD index table is drawn and uploaded
+    again, the evaluate workspace and every other block come fresh from hipMalloc (torch.cuda.empty_cache()).  Never
+    `value`; reported beside it so that what `value` leaves out is a number, not a sentence."""
+    from audio_metrics_amd import hip_ops as ops
+    from audio_metrics_amd.metrics import kd
+    times = []
+    for _ in range(samples):
+        kd._DEVICE_TABLES.clear()
+        ops.release_workspaces()
+        fence()
+        torch.cuda.empty_cache()
+        fence()
+        t0 = time.perf_counter()
+        step()
+        fence()
+        times.append((time.perf_counter() - t0) * 1e3)
+    return {"ms": times, "ms_min": min(times), "ms_mean": sum(times) / len(times),
+            "what": "one cold evaluate() after clearing the KD index-table cache, the cached evaluate workspace and torch's "
+                    "caching allocator (hipMalloc of ~1.2 GB + table draw and upload are inside)"}
+
+
 def timed_steps(step, fence, steps, warmup):
     for _ in range(warmup):
         result = step()
@@ -182,14 +255,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--pairs", type=int, default=2000, help="--config e2e: audio pairs per side")
+    ap.add_argument("--bulk-communicator", action="store_true",
+                    help="row gathers on a second RCCL communicator (distributed.enable_bulk_communicator; default: one)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))                # plain `python bench.py --gpus N`: the ranks run in a child
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        sys.exit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     # Test hooks (tests/test_gpu_distributed.py runs the N=2 launch on a 1-GPU box): AM_BENCH_DEVICE pins every
     # rank to one device, AM_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on the same GPU.
     device_index = int(os.environ.get("AM_BENCH_DEVICE", local_rank))
@@ -206,10 +282,17 @@ def main():
 
     import audio_metrics_amd as am
     from audio_metrics_amd import hip_ops as ops
-    from audio_metrics_amd.distributed import evaluate_sharded, shard_bounds, warm_up_communicators
+    from audio_metrics_amd.distributed import enable_bulk_communicator, evaluate_sharded, shard_bounds, warm_up_communicators
     am._lib.load()                                       # no HIP library -> fail here, loudly
+    n_ranks_seen = 1
     if world > 1:
-        warm_up_communicators(dev)                       # both communicators exist before anything is timed (also with --warmup 0)
+        if args.bulk_communicator:
+            enable_bulk_communicator()
+        # every communicator exists and has carried a collective before anything is timed (also with --warmup 0); the
+        # all-reduce of ones is what the line reports as n_ranks_seen
+        n_ranks_seen = warm_up_communicators(dev)
+        if n_ranks_seen != world:
+            sys.exit(f"the process group connected {n_ranks_seen} ranks, the launcher promised {world}")
     import inputs as gi
 
     def fence():
@@ -347,11 +430,7 @@ def main():
         flop_alg = 2.0 * rows_local * n * d
         t_tiles = (n + 255) // 256 if knn_path == 3 else (n + 127) // 128
         knn_exec = ((t_tiles // 2 + 1) / t_tiles) if knn_path in (1, 2, 3) else 1.0
-        try:                                                # PMC-derived HBM-side bytes per launch, recorded from profiles/
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                traffic_table = json.load(f).get("bytes_per_launch", {})
-        except OSError:
-            traffic_table = {}
+        stamp = library_stamp()
 
         def roof(kernel, path, ms, lps, exec_frac, entry, entry_ms):
             peak = peak_of[path]
@@ -359,8 +438,9 @@ def main():
             executed = algorithmic * exec_frac
             # `frac` is the MATRIX-PIPE figure: flops the kernel really issues / time / peak.  The algorithmic rate (SURVEY
             # 8(d) counts every (row, column) pair) is kept beside it; for the symmetric sweep it is about twice as high.
+            traffic, traffic_source = recorded_traffic(kernel, stamp) if world == 1 else (None, {"state": "recorded for one rank only"})
             return {"bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak,
-                    "traffic": traffic_table.get(kernel) if world == 1 else None,
+                    "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": kernel, "mfma": mfma_of[path], "entry_point": entry, "launch_ms": ms, "launches_per_step": lps,
                     "entry_ms": entry_ms, "executed_flop_per_launch": flop_alg * exec_frac,
                     "algorithmic_flop_per_launch": flop_alg, "algorithmic_tflops": algorithmic,
@@ -384,6 +464,19 @@ def main():
             if launches:
                 verify[label] = {"launch_ms": total / launches, "launches_per_step": launches / probe_steps,
                                  "bound": "hbm/L2 gather: two 4*D-byte rows per surviving pair, one fmaf chain per lane"}
+        # the whole step against the matrix peak (SURVEY 8(d) algorithmic work: statistics of both sets, the KD Gram blocks and
+        # the three pairwise passes, no symmetry credit; the Frechet solve - 10 iterations x 8e8 f64 flop - is left out)
+        step_flop = 2 * 2.0 * n * d * d + 100 * 3 * 2.0 * 1000 * 1000 * d + 3 * 2.0 * n * n * d
+        step_rate = step_flop / (elapsed / args.steps) / 1e12
+        roofline_step = {"algorithmic_flop_per_step": step_flop, "algorithmic_tflops": step_rate,
+                         "peak": F16_MFMA_PEAK_TFLOPS, "frac": step_rate / F16_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": step_rate / F32_MFMA_PEAK_TFLOPS,
+                         "note": "algorithmic flop of one step (2*2*N*D^2 + S*3*2*m^2*D + 3*2*N^2*D) / ms_per_step, all ranks together, "
+                                 "against the dense f16 MFMA peak of ONE GPU x n_gpus; the tile kernels are f16 filters with exact "
+                                 "f32 verification, which is how the rate can exceed the f32 MFMA peak"}
+        if world > 1:
+            roofline_step["peak"] = F16_MFMA_PEAK_TFLOPS * world
+            roofline_step["frac"] = step_rate / (F16_MFMA_PEAK_TFLOPS * world)
+            roofline_step["frac_of_f32_mfma_peak"] = step_rate / (F32_MFMA_PEAK_TFLOPS * world)
         entry_sum = sum(tot for name, (c, tot) in kern.items() if name != "am_frechet_enqueue_f64") / probe_steps
         host_gap = {"ms_per_step": elapsed / args.steps * 1e3, "sum_main_stream_entry_ms": entry_sum,
                     "ms_per_step_minus_entries": elapsed / args.steps * 1e3 - entry_sum,
@@ -396,6 +489,7 @@ def main():
             "value": args.steps * 2 * n / elapsed,
             "unit": "embeddings/s",
             "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -410,9 +504,22 @@ def main():
                        "inputs": ("numpy PCG64 seed %d: reference randn, candidate randn*1.05+0.05" % gi.BENCH_SEED) if args.data == "randn"
                                  else ("numpy PCG64 seed %d: unit-norm rows of randn+0.5 / randn+0.55 (CLAP-shaped)" % gi.BENCH_SEED),
                        "sharding": f"rows/{world}",
-                       "arithmetic": "results are the exact f32 values (bit-identical to the f32-MFMA kernels); the PRDC tile "
-                                     "kernels pre-filter on f16 MFMA with f32 accumulation where am_knn_path/am_prdc_path >= 2"},
+                       "arithmetic": "PRDC: results are the exact f32 values (bit-identical to the f32-MFMA kernels); the tile kernels "
+                                     "pre-filter on f16 MFMA with f32 accumulation where am_knn_path/am_prdc_path >= 2 and every "
+                                     "undecided pair is re-evaluated with the exact f32 fmaf chain.  KD (subsets of >= 512 rows, "
+                                     "D >= 128, degree 3): every gathered row is split into two f16 planes (hi = rn16(x), lo = "
+                                     "rn16(x - hi), ~22 significant bits) and the dot products are <hi,hi'> + <lo,hi'> + <hi,lo'> "
+                                     "on the f16 MFMA with f32 accumulation: error of a dot product <= ~3 * 2^-22 |x||y| (one f32 "
+                                     "rounding's worth; the reference forms them in f32 too), kernel values and all sums in f64.  "
+                                     "Statistics: exact f32 products on the f32 MFMA, f64 accumulation.  FAD: f64 throughout.",
+                       "persisting": "between steps nothing of the RESULT is cached (statistics, radii, counts, KD values and the "
+                                     "Frechet solve are recomputed); what survives is allocation and setup: torch's caching "
+                                     "allocator and the evaluate workspace (hip_ops._eval_workspace), the KD subset index table "
+                                     "on the device (a pure function of (n1, n2, S, m, seed): metrics/kd.py device_subset_indices), "
+                                     "code objects and - with several ranks - the communicators.  `first_call` times a step "
+                                     "without them."},
             "roofline": main,
+            "roofline_step": roofline_step,
             "other_tile_kernel": other,
             "other_kernels": verify,
             "filter": dict(per_step(filter_stats, probe_steps), knn_path=knn_path, prdc_path=cross_path,
@@ -429,6 +536,7 @@ def main():
             "variants": variants,
         }
         if world == 1:
+            out["first_call"] = first_call(step, fence)
             out["warm"] = warm_evaluate(am, ref, cand, k, max(1, min(args.steps, 3)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ref, cand, k)
@@ -490,7 +598,9 @@ def run_e2e(args, am, dev, world, rank, fence):
     am_embed.PROFILE = stage = {}                      # stage clock of the front end (embed.py)
     embedder = Timed(dim=512, sr=sr, device=dev)
     group = dist.group.WORLD if world > 1 else None
-    metric = am.AudioMetrics(metrics=["apa", "fad"], embedder=embedder, mix_function="P0", device_indices=[dev.index],
+    # device_indices=None, the reference's default: every visible GPU inside one process (util/gpu_parallel.py:24-25); with one
+    # process per GPU (process_group) this rank's device
+    metric = am.AudioMetrics(metrics=["apa", "fad"], embedder=embedder, mix_function="P0", device_indices=None,
                              win_dur=float(seconds), process_group=group)
     random.seed(1234 + rank)
     host = {"t": 0.0}
@@ -529,9 +639,10 @@ def run_e2e(args, am, dev, world, rank, fence):
             "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"APA+FAD end-to-end, {pairs} reference + {pairs} candidate pairs of ({sr * seconds}, 2) f32 "
-                                   "randn audio at 48 kHz (BASELINE.json configs[4] shape, reduced pair count), "
+                                   "randn audio at 48 kHz (BASELINE.json configs[4]" + ("" if pairs >= 10000 else " shape, reduced pair count") + "), "
                                    "SyntheticEmbedder (NOT CLAP: laion_clap and its checkpoint are not installable here)",
-                       "pairs_per_side": pairs, "sharding": f"pairs/{world}", "mix_function": "P0"},
+                       "pairs_per_side": pairs, "sharding": f"pairs/{world}", "mix_function": "P0",
+                       "embedder_devices": [str(d_) for d_ in metric._pool.devices]},
             "breakdown_s": {
                 "total": elapsed, "host_audio_synthesis": synth,
                 "host_mix_wait": stage.get("mix_wait", 0.0),                      # the consumer waiting for mixed windows

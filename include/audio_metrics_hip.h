@@ -138,11 +138,14 @@ double am_apa_f64(double d_y_x, double d_y_xp, double d_x_xp);
  *   Dot products in f32 on the matrix cores, kernel values and sums in f64.
  *   The index table is drawn by the caller (numpy PCG64, kd.py:176,185-186).
  * ------------------------------------------------------------------------- */
-size_t am_kd_workspace_bytes(int S, int m);               /* f32-MFMA form only                                         */
-size_t am_kd_poly_workspace_bytes(int S, int m, int D);   /* + the split-f16 form (m >= 512, D >= 128): three f16 MFMA
-                                                             stages per slab on two f16 planes of every gathered row,
-                                                             error of a dot product <= ~3 * 2^-22 |x||y|; am_kd_poly_f32
-                                                             takes it when the workspace has this size                  */
+/*   Two forms, selected by the SHAPES alone (never by the buffer handed in):
+ *     m >= 512, 128 <= D <= 8192, degree == 3: split-f16 form - every gathered row as two f16 planes, three f16 MFMA
+ *       stages per 64-element slab on the 256 x 256 engine, error of a dot product <= ~3 * 2^-22 |x||y|;
+ *     everything else (and the RBF kernel): f32 MFMA on the 128 x 128 engine.
+ *   am_kd_poly_workspace_bytes(S, m, D) is right for every shape.  am_kd_workspace_bytes(S, m) predates the split form
+ *   and covers the f32 form only: am_kd_poly_f32 answers a too-small workspace with AM_ERR_WORKSPACE. */
+size_t am_kd_workspace_bytes(int S, int m);
+size_t am_kd_poly_workspace_bytes(int S, int m, int D);
 int am_kd_poly_f32(const float* X, int64_t N1, int64_t ldx,
                    const float* Y, int64_t N2, int64_t ldy, int D,
                    const int64_t* idx1, const int64_t* idx2, int S, int m,
@@ -274,8 +277,9 @@ int am_prdc_reduce(const int32_t* col_count, int64_t Nc,
  *   am_eigh_sym_f64  eigen-decomposition of a symmetric POSITIVE SEMI-DEFINITE D x D matrix (the Gram matrix of the
  *                    stacked, centred batch whose SVD scikit-learn takes): evals[D] in DESCENDING order, evecs[D][D]
  *                    with row i = eigenvector i (unit norm; sign not normalised - the caller applies scikit-learn's
- *                    svd_flip).  One-sided Jacobi in f64; SYNCHRONISES `stream` once per sweep (fitting happens once
- *                    per reference set, not per evaluate).  AM_ERR_NO_CONVERGENCE after max_sweeps (<= 0: 40).
+ *                    svd_flip).  One-sided block Jacobi in f64; SYNCHRONISES `stream` once per BLOCK of enqueued
+ *                    sweeps (12, then 6 at a time: normally once per solve - the kernels of a sweep return at once when
+ *                    the sweep before it applied no rotation; fitting happens once per reference set, not per evaluate).  AM_ERR_NO_CONVERGENCE after max_sweeps (<= 0: 40).
  *   am_project_f64   out[N][p] (f64) = (X[n][:] - mean[:]) . components[j][:]  - IncrementalPCA.transform - on the f64
  *                    matrix cores; X is the N x D f32 embedding matrix, mean f64[D], components f64[p][D].
  * ------------------------------------------------------------------------- */

@@ -137,3 +137,44 @@ def test_rank_without_rows_takes_part_in_the_evaluation():
     assert results[0] == results[1]
     for key, w in want.items():
         assert abs(results[0][key] - w) <= max(2e-5 * abs(w), 5e-7), (key, results[0][key], w)
+
+
+def _global_stats_worker(rank, world, port, n, d, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_ops
+    from audio_metrics_amd.distributed import global_stats
+    x = torch.as_tensor(gi.pair("shifted", 93, n, n, d)[0])
+    # rank 0 holds everything but three rows, rank 1 three rows; then rank 1 holds nothing at all
+    for cut in (n - 3, n):
+        local = x[:cut] if rank == 0 else x[cut:]
+        count, mean, cov = global_stats(local, dist.group.WORLD, ops=cpu_ops)
+        out_q.put((rank, cut, count, mean.numpy(), cov.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_stats_of_one_sharded_set():
+    """The statistics the row-sharded PCA fit consumes (n_pca under a process group): count + column sums in one all-reduce,
+    centred scatters in a second; a rank without rows contributes zeros."""
+    n, d, world = 300, 12, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_global_stats_worker, args=(r, world, port, n, d, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=90) for _ in range(2 * world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x = torch.as_tensor(gi.pair("shifted", 93, n, n, d)[0]).double()
+    for rank, cut, count, mean, cov in got:
+        assert count == n
+        np.testing.assert_allclose(mean, x.mean(0).numpy(), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(cov, torch.cov(x.T).numpy(), rtol=1e-10, atol=1e-13)

@@ -153,10 +153,11 @@ def test_sharded_evaluate_takes_symmetric_path():
         assert results[0][key] == single[key], key
 
 
-@pytest.mark.parametrize("ranks,rows,dim", [(2, 3000, 64), (2, 9000, 128), (8, 66000, 128)])
-def test_bench_multi_rank_launch(ranks, rows, dim):
+@pytest.mark.parametrize("ranks,rows,dim,plain", [(2, 3000, 64, False), (2, 3000, 64, True), (2, 9000, 128, False),
+                                                  (8, 66000, 128, True)])
+def test_bench_multi_rank_launch(ranks, rows, dim, plain):
     """bench.py launched the way the driver launches it for N=2 (torch.distributed.run, one JSON line from
-    rank 0).  Both ranks share cuda:0 over gloo (bench.py's AM_BENCH_* test hooks); 9000x128 is eligible for the
+    rank 0) - and `plain`: invoked as `python bench.py --gpus N` with no launcher (it then starts the ranks itself).  Both ranks share cuda:0 over gloo (bench.py's AM_BENCH_* test hooks); 9000x128 is eligible for the
     partitioned symmetric k-NN, 3000x64 takes the general kernel on row shards.  The N-rank result must equal the
     1-rank result of the same command.  The 8-rank case at 66000 x 128 is the driver's 8-GPU launch in every respect but the
     transport: am_knn_path == 3 (the f16 filter sweep on the 256-row engine, partitioned eight ways), prepared sets shared
@@ -166,10 +167,17 @@ def test_bench_multi_rank_launch(ranks, rows, dim):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--steps", "1", "--warmup", "1", "--rows", str(rows), "--dim", str(dim), "--no-cpu-baseline"]
     env = dict(os.environ, AM_BENCH_DEVICE="0", AM_BENCH_BACKEND="gloo")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
-                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-                          os.path.join(root, "bench.py"), "--gpus", str(ranks)] + common,
-                         env=env, capture_output=True, text=True, timeout=900)
+    if plain:
+        # `python bench.py --gpus N` with no launcher around it: bench.py starts its own ranks in a child process and
+        # passes rank 0's line and the exit code through
+        env.pop("WORLD_SIZE", None)
+        two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks)] + common,
+                             env=env, capture_output=True, text=True, timeout=900)
+    else:
+        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                              "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                              os.path.join(root, "bench.py"), "--gpus", str(ranks)] + common,
+                             env=env, capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, two.stdout[-2000:]
@@ -179,6 +187,7 @@ def test_bench_multi_rank_launch(ranks, rows, dim):
     assert one.returncode == 0, one.stderr[-2000:]
     out1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert out2["n_gpus"] == ranks and out1["n_gpus"] == 1
+    assert out2["n_ranks_seen"] == ranks and out1["n_ranks_seen"] == 1      # what the process group connected, not what was asked for
     if rows >= 32768 and dim >= 128:
         assert out2["filter"]["knn_path"] == 3 and out2["filter"]["knn_fallback_rows"] == 0, out2["filter"]
     for key in ("metric", "value", "unit", "ms_per_step", "scaling", "roofline", "config"):
@@ -233,10 +242,14 @@ for name, rows, dim, k in (("small", 2500, 96, 4), ("partitioned", 33000, 128, 5
     ref, cand = (torch.as_tensor(a).to(dev) for a in gi.pair("randn", 95, rows, rows - 37, dim))
     want = D.evaluate_sharded(ref, cand, nearest_k=k, kid_subsets=8, kid_subset_size=300)          # one fused library call
     D.COLLECTIVES_AT_WORLD_ONE = True
-    D.warm_up_communicators(dev)                            # (bench.py's call: second communicator + one collective on each)
-    for rep in range(3):                                    # repeated: stale buffers / stream-order slips show up as a changing result
-        got = D.evaluate_sharded(ref, cand, nearest_k=k, kid_subsets=8, kid_subset_size=300)
-        out[f"{name}_{rep}"] = {"want": want, "got": got}
+    for comms in (1, 2):                                    # the default single communicator, then the optional second one
+        if comms == 2:
+            assert D.enable_bulk_communicator() is not None
+        assert D.warm_up_communicators(dev) == 1            # (bench.py's call: one collective on every communicator; ranks seen)
+        for rep in range(3):                                # repeated: stale buffers / stream-order slips show up as a changing result
+            got = D.evaluate_sharded(ref, cand, nearest_k=k, kid_subsets=8, kid_subset_size=300)
+            out[f"{name}_{comms}c_{rep}"] = {"want": want, "got": got}
+    D.disable_bulk_communicator()
     # the stats-only front end: (n, mean, cov) triples through the all-gather
     data = am.AudioMetricsData(store_embeddings=False); data.add(ref)
     merged = D.merged_stats(data)

@@ -75,7 +75,7 @@ def test_embedder_exception_reaches_the_caller():
         m.add_reference([x[:, 1] for x in _audio()[0]])
 
 
-def _rank_worker(rank, world, port, backend, out_q):
+def _rank_worker(rank, world, port, backend, out_q, metrics=("fad", "kd", "prdc"), n_pca=None, contiguous=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -90,41 +90,59 @@ def _rank_worker(rank, world, port, backend, out_q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     import audio_metrics_amd as am
     ref, cand = _audio()
-    ref, cand = [x[:, 1] for x in ref], [x[:, 1] for x in cand]          # stems only: no shuffled pairing across ranks
-    m = _make(am, ["fad", "kd", "prdc"], device_indices=[device], process_group=dist.group.WORLD)
-    m.add_reference(ref[rank::world])
-    res = m.evaluate(cand[rank::world])
-    out_q.put((rank, res))
+    if "apa" not in metrics:
+        ref, cand = [x[:, 1] for x in ref], [x[:, 1] for x in cand]      # stems only: no shuffled pairing across ranks
+    random.seed(11 + rank)
+    # device_indices=None under a process group = this rank's device only
+    m = _make(am, list(metrics), device_indices=None if backend == "gloo" else [device], process_group=dist.group.WORLD,
+              n_pca=n_pca)
+    assert m._devices == [torch.device("cuda", device)]
+
+    def shard(items):
+        if contiguous:                                   # rank order = row order of the one-process run (KD draws by row index)
+            return items[len(items) * rank // world:len(items) * (rank + 1) // world]
+        return items[rank::world]
+
+    m.add_reference(shard(ref))
+    res = m.evaluate(shard(cand))
+    again = m.evaluate(shard(cand))                      # cached projected reference sets, radii, d_x_xp
+    out_q.put((rank, res, again))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run_ranks(backend):
-    import audio_metrics_amd as am
+def _launch(backend, **kw):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, backend, q), kwargs=kw) for r in range(world)]
     for p in procs:
         p.start()
-    results = {}
+    results, seconds = {}, {}
     for _ in range(world):
-        rank, res = q.get(timeout=300)
-        results[rank] = res
+        rank, res, again = q.get(timeout=300)
+        results[rank], seconds[rank] = res, again
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert results[0] == results[1]                       # every rank reports the same values
+    assert seconds[0] == seconds[1]
+    return results[0], seconds[0]
+
+
+def _run_ranks(backend):
+    import audio_metrics_amd as am
+    got, _ = _launch(backend)
     ref, cand = _audio()
     ref, cand = [x[:, 1] for x in ref], [x[:, 1] for x in cand]
     m = _make(am, ["fad", "kd", "prdc"])
     m.add_reference(ref)
     single = m.evaluate(cand)
-    assert results[0].keys() == single.keys()
+    assert got.keys() == single.keys()
     for key in ("precision", "recall", "density", "coverage"):
-        assert results[0][key] == single[key], key         # integer counts do not depend on who holds which rows
-    assert abs(results[0]["fad"] - single["fad"]) <= 1e-5 * abs(single["fad"])
+        assert got[key] == single[key], key         # integer counts do not depend on who holds which rows
+    assert abs(got["fad"] - single["fad"]) <= 1e-5 * abs(single["fad"])
 
 
 def test_process_group_audio_metrics_two_ranks_gloo():
@@ -134,3 +152,65 @@ def test_process_group_audio_metrics_two_ranks_gloo():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
 def test_process_group_audio_metrics_two_ranks_rccl():
     _run_ranks("nccl")
+
+
+def _check_pca_against_golden(golden, got, keys):
+    g = golden("e2e")
+    for key in keys:
+        want = float(g[f"pca/{key}"])
+        slack = max(1e-4 * abs(want), 1.0 / 150) if key != "fad" else 1e-4 * abs(want)
+        assert abs(got[key] - want) <= slack, (key, got[key], want)
+
+
+def _pca_two_ranks(backend, golden):
+    """n_pca under a process group (reference audio_metrics.py:163-209, projection.py:6-46): the fit sees the union of the
+    ranks' rows through two all-reduces and runs replicated.  Order-free values (FAD, PRDC) must equal the reference's own
+    `pca` golden - produced by ONE process - and everything must equal this build's one-process run on the same rows."""
+    import audio_metrics_amd as am
+    got, again = _launch(backend, metrics=("fad", "kd", "prdc"), n_pca=8, contiguous=True)
+    _check_pca_against_golden(golden, got, ("fad", "precision", "recall", "density", "coverage"))
+    ref, cand = _audio()
+    m = _make(am, ["fad", "kd", "prdc"], n_pca=8)
+    m.add_reference([x[:, 1] for x in ref])
+    single = m.evaluate([x[:, 1] for x in cand])
+    assert list(got) == list(single)
+    for key, want in single.items():
+        slack = 1.0 / 150 if key in ("precision", "recall", "density", "coverage") else max(1e-5 * abs(want), 5e-7)
+        assert abs(got[key] - want) <= slack, (key, got[key], want)
+        assert abs(again[key] - got[key]) <= 1e-9 * max(1.0, abs(got[key])), key
+    # with APA: both projections fitted across ranks; the misaligned pairs are drawn per rank, so APA itself is only sane
+    got, again = _launch(backend, metrics=("fad", "apa"), n_pca=8, contiguous=True)
+    _check_pca_against_golden(golden, got, ("fad",))
+    assert 0.0 <= got["apa"] <= 1.0 and abs(again["apa"] - got["apa"]) <= 1e-9
+
+
+def test_process_group_with_pca_two_ranks_gloo(golden):
+    _pca_two_ranks("gloo", golden)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
+def test_process_group_with_pca_two_ranks_rccl(golden):
+    _pca_two_ranks("nccl", golden)
+
+
+def test_device_indices_none_means_every_visible_gpu():
+    """The reference's default (util/gpu_parallel.py:24-25, audio_metrics.py:276-279): None = all GPUs, an empty list = no
+    replica handler (the embedder runs where it lives)."""
+    import audio_metrics_amd as am
+    from audio_metrics_amd.audio_metrics import _visible_devices
+    count = torch.cuda.device_count()
+    current = torch.cuda.current_device()
+    devices = _visible_devices(None)
+    assert len(devices) == count and devices[0] == torch.device("cuda", current)
+    assert sorted(d.index for d in devices) == list(range(count))
+    assert _visible_devices([]) == [torch.device("cuda", current)]
+    assert _visible_devices(None, one_process_per_gpu=True) == [torch.device("cuda", current)]
+    ref, cand = _audio()
+    results = []
+    for indices in (None, [current]) if count == 1 else (None, list(range(count))):
+        random.seed(5)
+        m = _make(am, ["fad", "kd", "prdc", "apa"], device_indices=indices)
+        assert len(m._pool.devices) == count
+        m.add_reference(ref)
+        results.append(m.evaluate(cand))
+    assert results[0] == results[1]

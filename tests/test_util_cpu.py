@@ -51,3 +51,56 @@ def test_audio_slicer_windows(golden):
         assert np.array_equal(got, g[f"slicer/{name}/windows"]), name
     both = list(multi_audio_slicer([np.arange(10), np.arange(7)], 0.5, 8))
     assert [len(w) for w in both] == [4, 4, 4] and both[2][0] == 0
+
+
+def _pairs(n, length, dtype):
+    rng = np.random.default_rng(3)
+    if np.issubdtype(dtype, np.integer):
+        return [rng.integers(-2000, 2000, size=(length, 2)).astype(dtype) for _ in range(n)]
+    return [rng.standard_normal((length, 2)).astype(dtype) for _ in range(n)]
+
+
+def _collect(batches):
+    tags, rows = [], []
+    for batch in batches:
+        tags += batch["category"].tolist()
+        rows += [row.copy() for row in batch["audio"]]
+    return tags, rows
+
+
+def test_rendered_batches_take_the_dtype_of_the_mixed_window():
+    """A mix function may return another dtype than its input (pyloudnorm-style mixers return float64 for float32 windows,
+    the peak mixers return float for integer PCM): the worker-filled batch ring must carry what the mixer returned, exactly
+    like batches_of + np.stack (and the reference's np.stack, embed.py:218-225) does."""
+    from audio_metrics_amd.embed import WindowSource, batches_of, rendered_batches
+    from audio_metrics_amd.mix_functions import MIX_FUNCTIONS
+
+    def to_f64(audio, sr=None):
+        return audio.astype(np.float64).sum(axis=1) * 0.5
+
+    for mix, dtype, want in ((to_f64, np.float32, np.float64), (MIX_FUNCTIONS["P0"], np.int16, None)):
+        songs = _pairs(7, 40, dtype)                               # 7 songs of 40 samples, windows of 8: 35 windows
+        make = lambda workers: WindowSource(songs, 16, 0.5, mix, apa_mode="candidate", stems_mode=False,  # noqa: E731
+                                            mix_workers=workers)
+        plain_tags, plain_rows = _collect(batches_of(make(1), batch_size=4))
+        for workers in (1, 3):
+            tags, rows = _collect(rendered_batches(make(workers), batch_size=4, ring=6))
+            assert tags == plain_tags and len(rows) == len(plain_rows) == 35
+            for a, b in zip(rows, plain_rows):
+                assert a.dtype == b.dtype and np.array_equal(a, b)
+            if want is not None:
+                assert rows[0].dtype == want
+
+
+def test_rendered_batches_name_the_shapes_when_a_window_differs():
+    import pytest
+    from audio_metrics_amd.embed import WindowSource, rendered_batches
+    calls = []
+
+    def ragged(audio, sr=None):
+        calls.append(1)
+        return audio[:, 0] if len(calls) < 3 else audio[:-1, 0]
+
+    source = WindowSource(_pairs(2, 40, np.float32), 16, 0.5, ragged, apa_mode="candidate", mix_workers=1)
+    with pytest.raises(ValueError, match=r"\(8,\).*\(7,\)"):
+        list(rendered_batches(source, batch_size=4, ring=6))

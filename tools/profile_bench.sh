@@ -17,4 +17,5 @@ for pass in trace pmc_sq pmc_fetch pmc_write; do
     db=$(find "$OUT/$pass" -name "*.db" | head -1)
     [ -n "$db" ] && python3 tools/rocpd_summary.py "$db" > "$OUT/$pass.summary.txt" 2>&1
 done
+cp audio-metrics_amd/lib/libaudio_metrics_hip.so.stamp.json "$OUT/library.stamp.json"   # what tools/update_traffic.py ties the counters to
 ls -la "$OUT"
