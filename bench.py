@@ -536,8 +536,8 @@ def main():
             "variants": variants,
         }
         if world == 1:
-            out["first_call"] = first_call(step, fence)
             out["warm"] = warm_evaluate(am, ref, cand, k, max(1, min(args.steps, 3)))
+            out["first_call"] = first_call(step, fence)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ref, cand, k)
         print(json.dumps(out), flush=True)
