@@ -189,8 +189,11 @@ template <int KCAP, int V, bool KTAIL>
 __global__ void __launch_bounds__(ENGINE_THREADS, 2)
 knn_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ldx, const float* __restrict__ xnorm,
                    const float* __restrict__ Y, int64_t M, int64_t ldy, const float* __restrict__ ynorm,
-                   int D, int nchunks, int qstride, float* __restrict__ partial, const unsigned* __restrict__ half_scale) {
+                   int D, int nchunks, int qstride, float* __restrict__ partial, const unsigned* __restrict__ half_scale,
+                   const int* __restrict__ run_flag) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // (launched behind the f16 filter path as its data-dependent fallback: returns at once unless that path gave up)
+    if (run_flag != nullptr && *run_flag == 0) return;
     const LaneInfo L;
     // qstride > 1: only every qstride-th column tile is visited (cheap upper bounds for the symmetric kernel)
     const int64_t q_tiles = ((M + TB - 1) / TB + qstride - 1) / qstride;
@@ -249,9 +252,9 @@ knn_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ldx, const fl
 // radius[i] = sqrt_rn( (k+1)-th smallest d2 over all chunks )
 template <int KCAP>
 __global__ void knn_merge_kernel(const float* __restrict__ partial, int64_t N, int nchunks, int k1, int squared,
-                                 float* __restrict__ radii) {
+                                 float* __restrict__ radii, const int* __restrict__ run_flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    if (i >= N || (run_flag != nullptr && *run_flag == 0)) return;
     float m[KCAP];
 #pragma unroll
     for (int s = 0; s < KCAP; ++s) m[s] = partial[i * KCAP + s];
@@ -811,35 +814,45 @@ static int launch_norms(const float* X, int64_t N, int64_t ld, int D, float* out
 template <int KCAP, int V, bool KTAIL>
 static int launch_knn_vt(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
                          const float* yn, int D, int nchunks, int qstride, float* partial, hipStream_t st,
-                         const unsigned* half_scale = nullptr) {
+                         const unsigned* half_scale = nullptr, const int* run_flag = nullptr) {
     {
         AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_partial_kernel<KCAP, V, KTAIL>), (int)PAIRWISE_LDS_BYTES));
     }
     const int64_t blocks = ceil_div(N, TB) * nchunks;
-    if (qstride == 1) clock_begin(AM_KERNEL_KNN, st);         // main pass only; qstride > 1 is the sampled pre-pass
+    const bool clocked = qstride == 1 && run_flag == nullptr;   // main pass only; qstride > 1 is the sampled pre-pass
+    if (clocked) clock_begin(AM_KERNEL_KNN, st);
     hipLaunchKernelGGL((knn_partial_kernel<KCAP, V, KTAIL>), dim3((unsigned)blocks), dim3(ENGINE_THREADS),
-                       PAIRWISE_LDS_BYTES, st, X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, half_scale);
-    if (qstride == 1) clock_end(AM_KERNEL_KNN, st);
+                       PAIRWISE_LDS_BYTES, st, X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, half_scale, run_flag);
+    if (clocked) clock_end(AM_KERNEL_KNN, st);
     AM_LAUNCH_CHECK();
     return AM_OK;
 }
 
 template <int KCAP, int V>
 static int launch_knn_v(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
-                        const float* yn, int D, int nchunks, int qstride, float* partial, hipStream_t st) {
+                        const float* yn, int D, int nchunks, int qstride, float* partial, hipStream_t st,
+                        const int* run_flag = nullptr) {
     // the inner-dimension tail (D % 32 != 0) is a separate instantiation so the common kernel carries no tail code
     if constexpr ((V & EV_EARLY) != 0) {
         if ((D % BK) != 0)
-            return launch_knn_vt<KCAP, V, true>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st);
+            return launch_knn_vt<KCAP, V, true>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st, nullptr, run_flag);
     }
-    return launch_knn_vt<KCAP, V, false>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st);
+    return launch_knn_vt<KCAP, V, false>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st, nullptr, run_flag);
 }
 
 template <int KCAP>
 static int launch_knn(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
                       const float* yn, int D, int k1, int nchunks, int qstride, bool squared, float* partial,
-                      float* out_r, hipStream_t st) {
+                      float* out_r, hipStream_t st, const int* run_flag = nullptr) {
     int rc;
+    if (run_flag != nullptr) {                       // the gated fallback of the filter path: production schedule only
+        rc = launch_knn_v<KCAP, EV_DEFAULT>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st, run_flag);
+        if (rc != AM_OK) return rc;
+        hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st,
+                           partial, N, nchunks, k1, squared ? 1 : 0, out_r, run_flag);
+        AM_LAUNCH_CHECK();
+        return AM_OK;
+    }
 #ifdef AM_DEV_KNOBS
     if constexpr (KCAP == 6) {                       // older schedules stay selectable for A/B runs (k <= 5 kernel only)
         switch (qstride == 1 ? engine_variant() : EV_DEFAULT) {
@@ -854,7 +867,7 @@ static int launch_knn(const float* X, int64_t N, int64_t ldx, const float* xn, c
     }
     if (rc != AM_OK) return rc;
     hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st,
-                       partial, N, nchunks, k1, squared ? 1 : 0, out_r);
+                       partial, N, nchunks, k1, squared ? 1 : 0, out_r, static_cast<const int*>(nullptr));
     AM_LAUNCH_CHECK();
     return AM_OK;
 }
@@ -1362,7 +1375,7 @@ static int knn_bounds_impl(const float* X, int64_t N, int64_t ld, int D, int k, 
             }
             if (r2 != AM_OK) return r2;
             hipLaunchKernelGGL(knn_merge_kernel<KC>, dim3((unsigned)ceil_div(nrows, 256)), dim3(256), 0, st, partial, nrows,
-                               chunks, k + 1, 1, out_bound_sq);
+                               chunks, k + 1, 1, out_bound_sq, static_cast<const int*>(nullptr));
             hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(nrows, 256)), dim3(256), 0, st, out_bound_sq,
                                out_bound_sq, xn + row0, nrows, maxn, fast_c(D));
             AM_LAUNCH_CHECK();

@@ -310,6 +310,6 @@ int launch_knn_wide_sample(int kcap, const float* Xb, int64_t N, int64_t ldh, co
 int launch_knn_wide(int kcap, unsigned nwg, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, float* thr, int Dh,
                     int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
                     uint2* wgq, float* wgv, int qcap, int* wgq_count, int part, int nparts, float fc, uint2* ovq, float* ovv,
-                    unsigned long long* ovn, int ovcap, hipStream_t st);
+                    unsigned long long* ovn, int ovcap, const int* skip, hipStream_t st);
 
 }  // namespace am

@@ -728,9 +728,15 @@ static CrossFastBuffers carve_cross_fast(Carver& c, int64_t Nr, int64_t Nc, int 
 
 static bool cross_fast_enabled(int64_t Nr, int64_t Nc, int D) {
     static const int on = env_int("AM_PRDC_FAST", 1);
-    static const int64_t min_pairs = (int64_t)env_int("AM_FAST_MIN_PAIRS_LOG2", 24);
+    // Where the membership filter starts to pay (round 4: tools/threshold_sweep.py on randn, unit-norm and clustered sets,
+    // profiles/r4/threshold_sweep.txt): 2^24 pairs for D >= 256; for narrower rows the exact kernel's MFMA work shrinks with D
+    // while the filter's fixed passes do not - 2^26 pairs (8192^2) for 128 <= D < 256, 1e8 (10 000^2) below.  (Round 3 used
+    // 2^24 for every width: 0.05 - 0.08 ms too slow at 6 000 - 8 000 rows x 64 / 128.)
+    static const int min_pairs_env = env_int("AM_FAST_MIN_PAIRS_LOG2", 0);
+    const int64_t min_pairs_n = min_pairs_env > 0 ? ((int64_t)1 << min_pairs_env)
+                                                  : (D >= 256 ? (int64_t)1 << 24 : D >= 128 ? (int64_t)1 << 26 : (int64_t)100000000);
     const size_t verify_lds = (size_t)(4 * ((D + 7) / 8 * 8) + 2048) * sizeof(float);
-    return on != 0 && D >= 32 && D <= FAST_MAX_DIM && verify_lds <= 60 * 1024 && Nr * Nc >= ((int64_t)1 << min_pairs) &&
+    return on != 0 && D >= 32 && D <= FAST_MAX_DIM && verify_lds <= 60 * 1024 && Nr * Nc >= min_pairs_n &&
            Nr < ((int64_t)1 << 31) && Nc < ((int64_t)1 << 31);
 }
 
@@ -867,13 +873,13 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
                 int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
                 int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
                 int* __restrict__ wgq_count, int part, int nparts, float fc, uint2* __restrict__ ovq, float* __restrict__ ovv,
-                unsigned long long* __restrict__ ovn, int ovcap) {
+                unsigned long long* __restrict__ ovn, int ovcap, const int* __restrict__ skip) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
     const int64_t T = (N + TB - 1) / TB;
     const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
     constexpr int NW = KnnFastEpilogue<KCAP>::NWAVES;
-    if (sw.ntiles == 0) {
+    if (sw.ntiles == 0 || (skip != nullptr && *skip != 0)) {      // (skip: the data-dependent fallback took over, see knn_fast_predict_kernel)
         if (L.tid <= NW) wgq_count[(int64_t)blockIdx.x * (NW + 1) + L.tid] = 0;
         return;
     }
@@ -992,7 +998,9 @@ __device__ __forceinline__ void knn_file_approx(float* __restrict__ fval, unsign
 __global__ void __launch_bounds__(256) knn_fast_scatter_kernel(const uint2* __restrict__ wgq, const float* __restrict__ wgv,
                                                                int qcap, int wcap, int nsub, const int* __restrict__ wgq_count,
                                                                float* __restrict__ fval, unsigned* __restrict__ fidx,
-                                                               int* __restrict__ cnt, int cap, const float* __restrict__ thr) {
+                                                               int* __restrict__ cnt, int cap, const float* __restrict__ thr,
+                                                               const int* __restrict__ skip) {
+    if (skip != nullptr && *skip != 0) return;
     // thr[i] (the bound the sweep left behind: (k+1)-th smallest approximate value seen + 2E) admits every pair that can
     // be among row i's k+1 smallest; most entries were queued under the much looser bounds of the first windows and are
     // dropped here instead of being filed and pruned later
@@ -1012,7 +1020,9 @@ __global__ void __launch_bounds__(256) knn_fast_scatter_kernel(const uint2* __re
 __global__ void __launch_bounds__(256) knn_fast_scatter_spill_kernel(const uint2* __restrict__ ovq, const float* __restrict__ ovv,
                                                                      const unsigned long long* __restrict__ ovn, int ovcap,
                                                                      float* __restrict__ fval, unsigned* __restrict__ fidx,
-                                                                     int* __restrict__ cnt, int cap, const float* __restrict__ thr) {
+                                                                     int* __restrict__ cnt, int cap, const float* __restrict__ thr,
+                                                                     const int* __restrict__ skip) {
+    if (skip != nullptr && *skip != 0) return;
     const int n = (int)min(*ovn, (unsigned long long)ovcap);
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         const uint2 p = ovq[e];
@@ -1029,13 +1039,19 @@ __global__ void __launch_bounds__(256) knn_fast_prune_kernel(const float* __rest
                                                              const int* __restrict__ cnt, int cap, int64_t N, int k1,
                                                              const float* __restrict__ xnorm, const unsigned* __restrict__ maxn,
                                                              uint2* __restrict__ pairs, int pair_cap, int* __restrict__ pair_count,
-                                                             int* __restrict__ cnt2, int partitioned, float fc) {
+                                                             int* __restrict__ cnt2, int partitioned, float fc,
+                                                             int* __restrict__ gate) {
+    if (gate != nullptr && gate[0] != 0) return;          // (gate: data-dependent fallback, see knn_fast_predict_kernel)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int c = i < N ? cnt[i] : 0;
     // overflow on the way here; c < k1 cannot happen on one GPU (the true top k+1 are always queued) - in the
     // partitioned form a rank may hold fewer than k+1 entries of a row, which then all survive (kq = +inf)
     const bool bad = i < N && (c > cap || (c < k1 && !partitioned));
+    if (gate != nullptr) {
+        const unsigned long long nb = __ballot(bad);
+        if (lane == 0 && nb != 0ull) atomicAdd(gate + 3, __popcll(nb));
+    }
     const float* fv = fval + i * (int64_t)cap;
     int ns = 0;
     float thr = -INFINITY;
@@ -1089,8 +1105,9 @@ __global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __res
                                                               const float* __restrict__ xnorm, int D,
                                                               const uint2* __restrict__ pairs, const int* __restrict__ pair_count,
                                                               int pair_cap, float* __restrict__ cand, int* __restrict__ cnt2,
-                                                              int cap) {
+                                                              int cap, const int* __restrict__ skip) {
     extern __shared__ __attribute__((aligned(16))) float vlds[];
+    if (skip != nullptr && *skip != 0) return;
     const int n = min(*pair_count, pair_cap);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* tile = vlds + wave * 128 * VERIFY_LD;                     // rows 0..63: first rows of the pairs, 64..127: second rows
@@ -1110,9 +1127,9 @@ __global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __res
 template <int KCAP>
 __global__ void knn_fast_select_kernel(const float* __restrict__ cand, const int* __restrict__ cnt, int cap, int64_t N, int k1,
                                        const unsigned* __restrict__ maxn, float* __restrict__ radii, int* __restrict__ ov_list,
-                                       int* __restrict__ ov_count, float* __restrict__ out_lists) {
+                                       int* __restrict__ ov_count, float* __restrict__ out_lists, const int* __restrict__ skip) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    if (i >= N || (skip != nullptr && *skip != 0)) return;
     const int c = cnt[i];
     if (c > cap || (out_lists == nullptr && c < k1) || !half_scale_ok(maxn[2])) {
         if (out_lists != nullptr) out_lists[i * KCAP] = NAN;
@@ -1139,6 +1156,60 @@ __global__ void knn_fast_select_kernel(const float* __restrict__ cand, const int
     radii[i] = sqrt_rn(r2);
 }
 
+// ---- data-dependent fallback of the k-NN filter path (round 4) -----------------------------------------------------
+// The filter pays when the f16 values SEPARATE a row's nearest neighbours from the rest.  On tightly clustered data they
+// do not: every member of a row's cluster lies inside the error band of its (k+1)-th neighbour, the queues keep them all,
+// the prune step cannot drop them, and the exact verification touches hundreds of pairs per row (tools/threshold_sweep.py:
+// 50 clusters of width 1e-3, 20 000 x 512, k = 5: 283 ms against 7.5 ms for the exact kernels - 34 000 rows overflowed their
+// candidate buffers and went through the row-at-a-time fix-up).  Two device-side checks, no host round trip:
+//   A  after the sample pass: a row whose k+1 smallest SAMPLED values span less than the error band 2 E_i cannot be
+//      separated; if more than one row in eight is like that the sweep, scatter and prune kernels return at once;
+//   B  after the prune step: more surviving pairs than 8 (k+1) + 16 per row, or more than N / 64 rows sent to the fix-up.
+// In either case verification, selection and fix-up return at once and the exact general kernel - always launched behind
+// them, like the exact membership kernel behind its filter - really runs.  Same outputs bit for bit either way (both are
+// the exact kernels' values); the checks only choose the cheaper route.  Single-GPU form only: the partitioned entry points
+// exchange bounds and lists between ranks and have no common place for the decision.
+template <int KCAP>
+__global__ void __launch_bounds__(256) knn_fast_predict_kernel(const float* __restrict__ partial, int64_t N, int nchunks, int k1,
+                                                               const float* __restrict__ xnorm, const unsigned* __restrict__ maxn,
+                                                               float fc, int* __restrict__ gate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool flat = false;
+    if (i < N) {
+        float m[KCAP];
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) m[s] = partial[i * KCAP + s];
+        for (int c = 1; c < nchunks; ++c) {
+            const float* src = partial + ((int64_t)c * N + i) * KCAP;
+            for (int s = 0; s < KCAP; ++s) list_insert<KCAP>(m, src[s]);
+        }
+        float kth = m[0];
+#pragma unroll
+        for (int s = 1; s < KCAP; ++s)
+            if (s == k1 - 1) kth = m[s];
+        // (m[0] is the row's own column when the sample holds it - a zero; from m[1] on the values are neighbours either way:
+        // a span below the band means the band holds at least k - 1 sampled neighbours, 16 times as many in the whole row)
+        flat = kth < INFINITY && kth - m[k1 >= 3 ? 1 : 0] <= 2.f * fc * (xnorm[i] + __uint_as_float(maxn[0]));
+    }
+    const unsigned long long b = __ballot(flat);
+    if ((threadIdx.x & 63) == 0 && b != 0ull) atomicAdd(gate + 2, __popcll(b));
+}
+
+__global__ void knn_fast_decide_kernel(int* __restrict__ gate, int64_t N, int k1, int stage, const int* __restrict__ pair_count,
+                                       const unsigned* __restrict__ maxn, int* __restrict__ ov_count) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (stage == 0) {
+        gate[0] = (int64_t)gate[2] * 8 > N ? 1 : 0;
+    } else if (stage == 1) {
+        const bool volume = (int64_t)*pair_count > N * (int64_t)(8 * k1 + 16);
+        const bool fixups = (int64_t)gate[3] * 64 > N;
+        // (a scale outside the f16 range sends every row to the fix-up as well: the exact kernel is the better fix-up)
+        gate[1] = (gate[0] != 0 || volume || fixups || !half_scale_ok(maxn[2])) ? 1 : 0;
+    } else if (gate[1] != 0) {
+        *ov_count = (int)(N < 0x7fffffff ? N : 0x7fffffff);     // statistics: every row took the exact kernel
+    }
+}
+
 static bool knn_fast_enabled(int64_t N, int D) {
     static const int on = env_int("AM_KNN_FAST", 1);
     // Below: the exact kernels are faster.  Measured in round 3 (tools/size_sweep.py, k = 5, cold PRDC of two sets): the f16
@@ -1149,7 +1220,7 @@ static bool knn_fast_enabled(int64_t N, int D) {
     // Narrow rows (32 <= D < 128: what n_pca leaves) were excluded altogether ("the saved MFMA work scales with D"): from
     // 16 384 rows the sweep wins there too - 8.3 -> 2.9 ms at 50 000 x 64, 29.2 -> 7.8 ms at 100 000 x 64, break-even at 16 000.
     static const int min_rows_env = env_int("AM_KNN_FAST_MIN_ROWS", 0);
-    const int64_t min_rows = min_rows_env > 0 ? min_rows_env : (D >= 256 ? 6144 : D >= 128 ? 8192 : 16384);
+    const int64_t min_rows = min_rows_env > 0 ? min_rows_env : (D >= 256 ? 6144 : D >= 128 ? 8192 : 12000);   // (D < 128: 16384 until round 4)
     return on != 0 && N >= min_rows && D >= 32 && D <= FAST_MAX_DIM && N < ((int64_t)1 << 31);
 }
 
@@ -1162,6 +1233,9 @@ struct KnnFastBuffers {           // on top of the symmetric path's KnnBuffers
     uint2* ovq;                   // spill queue (entries past a region's capacity)
     float* ovv;
     unsigned long long* ovn;      // entries offered to it (64-bit: adversarial inputs offer billions)
+    int* gate;                    // [4] data-dependent fallback: [0] skip the sweep, [1] skip verification / run the exact
+                                  //     kernel, [2] rows the sample cannot separate, [3] rows the prune step sent to fix-up
+    float* xpartial;              // partial lists of the gated exact kernel (choose_chunks(N, N) x N x kcap)
 };
 constexpr int KNN_FAST_OVCAP = 1 << 22;
 
@@ -1176,6 +1250,8 @@ static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan&
     f.ovn = c.take<unsigned long long>(1);
     f.ovq = c.take<uint2>(KNN_FAST_OVCAP);
     f.ovv = c.take<float>(KNN_FAST_OVCAP);
+    f.gate = c.take<int>(4);
+    f.xpartial = c.take<float>((size_t)choose_chunks(N, N) * N * p.kcap);
     return f;
 }
 
@@ -1208,6 +1284,12 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     const float* Xb = reinterpret_cast<const float*>(prep != nullptr ? prep->half : f.xb);
     unsigned* maxn = f.maxn;
     float* thr = b.thr;
+    // data-dependent fallback to the exact general kernel (knn_fast_predict_kernel): the single-GPU form only
+    static const int gate_on = env_int("AM_KNN_FAST_GATE", 1);
+    int* gate = (gate_on != 0 && bounds_in == nullptr && out_lists == nullptr) ? f.gate : nullptr;
+    const int* skip_sweep = gate;
+    const int* skip_verify = gate != nullptr ? gate + 1 : nullptr;
+    if (gate != nullptr) AM_HIP_TRY(hipMemsetAsync(gate, 0, 4 * sizeof(int), st));
     AM_HIP_TRY(hipMemsetAsync(maxn, 0, 4 * sizeof(unsigned), st));
     if (prep != nullptr) {
         hipLaunchKernelGGL(prepared_stats_kernel, dim3(1), dim3(64), 0, st, prep->stats, maxn, 0, 2, 3);
@@ -1232,7 +1314,12 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
             return rc;
         }
         hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.partial, N, sample_chunks,
-                           k1, 1, thr);
+                           k1, 1, thr, static_cast<const int*>(nullptr));
+        if (gate != nullptr) {                           // check A: can the f16 values separate the rows' neighbours at all?
+            hipLaunchKernelGGL(knn_fast_predict_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.partial, N,
+                               sample_chunks, k1, b.xn, maxn, fast_c(D), gate);
+            hipLaunchKernelGGL(knn_fast_decide_kernel, dim3(1), dim3(64), 0, st, gate, N, k1, 0, f.pair_count, maxn, b.ov_count);
+        }
         hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, thr, thr, b.xn, N, maxn, 2.f * fast_c(D));
         AM_LAUNCH_CHECK();
     }
@@ -1257,41 +1344,51 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     if (p.tile_rows == WIDE_TILE_ROWS) {
         if ((rc = launch_knn_wide(KCAP, nwg, Xb, N, ldh, b.xn, thr, Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt,
                                   p.cap, b.wgq, f.wgv, qcap, b.wgq_count, part, nparts, fast_c(D), f.ovq, f.ovv, f.ovn, ovcap,
-                                  st)) != AM_OK)
+                                  skip_sweep, st)) != AM_OK)
             return rc;
     } else {
         hipLaunchKernelGGL(knn_fast_kernel<KCAP>, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st, Xb, N, ldh, b.xn,
                            thr, Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, f.wgv, qcap,
-                           b.wgq_count, part, nparts, fast_c(D), f.ovq, f.ovv, f.ovn, ovcap);
+                           b.wgq_count, part, nparts, fast_c(D), f.ovq, f.ovv, f.ovn, ovcap, skip_sweep);
     }
     clock_end(AM_KERNEL_KNN, st);
     AM_LAUNCH_CHECK();
     // 3) approximate values filed by row, 4) pruned against the row's own (k+1)-th smallest, 5) exact values of the
     //    survivors, 6) selection, 7) exact fix-up of overflowed rows
     hipLaunchKernelGGL(knn_fast_scatter_kernel, dim3(nreg), dim3(256), 0, st, b.wgq, f.wgv, qcap, wcap, nsub, b.wgq_count, b.cand,
-                       f.fidx, b.cnt, p.cap, thr);
+                       f.fidx, b.cnt, p.cap, thr, skip_sweep);
     hipLaunchKernelGGL(knn_fast_scatter_spill_kernel, dim3(256), dim3(256), 0, st, f.ovq, f.ovv, f.ovn, ovcap, b.cand, f.fidx,
-                       b.cnt, p.cap, thr);
+                       b.cnt, p.cap, thr, skip_sweep);
     AM_LAUNCH_CHECK();
     const int64_t pair_cap64 = std::min<int64_t>((int64_t)nwg * qcap, (int64_t)1 << 30);
     const int pair_cap = (int)pair_cap64;
     hipLaunchKernelGGL(knn_fast_prune_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.cand, f.fidx, b.cnt, p.cap,
-                       N, k1, b.xn, maxn, b.wgq, pair_cap, f.pair_count, f.cnt2, out_lists != nullptr ? 1 : 0, fast_c(D));
+                       N, k1, b.xn, maxn, b.wgq, pair_cap, f.pair_count, f.cnt2, out_lists != nullptr ? 1 : 0, fast_c(D), gate);
+    if (gate != nullptr)                                 // check B: did the prune step leave a verifiable amount of work?
+        hipLaunchKernelGGL(knn_fast_decide_kernel, dim3(1), dim3(64), 0, st, gate, N, k1, 1, f.pair_count, maxn, b.ov_count);
     AM_LAUNCH_CHECK();
     clock_begin(AM_KERNEL_KNN_VERIFY, st);
     {
         AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_fast_verify_kernel), (int)VERIFY_LDS_BYTES));
     }
     hipLaunchKernelGGL(knn_fast_verify_kernel, dim3(2048), dim3(256), VERIFY_LDS_BYTES, st, X, ld, b.xn, D, b.wgq, f.pair_count,
-                       pair_cap, b.cand, f.cnt2, p.cap);
+                       pair_cap, b.cand, f.cnt2, p.cap, skip_verify);
     clock_end(AM_KERNEL_KNN_VERIFY, st);
     AM_LAUNCH_CHECK();
     hipLaunchKernelGGL(knn_fast_select_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.cand, f.cnt2, p.cap, N, k1,
-                       maxn, out_r, b.ov_list, b.ov_count, out_lists);
+                       maxn, out_r, b.ov_list, b.ov_count, out_lists, skip_verify);
     AM_LAUNCH_CHECK();
     if (out_lists == nullptr) {
         hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
                            b.xn, D, k1, b.ov_list, b.ov_count, out_r);
+        AM_LAUNCH_CHECK();
+    }
+    if (gate != nullptr) {
+        // the exact general kernel behind the filter path: its workgroups return at once unless check A or B gave up
+        if ((rc = launch_knn<KCAP>(X, N, ld, b.xn, X, N, ld, b.xn, D, k1, choose_chunks(N, N), 1, false, f.xpartial, out_r, st,
+                                   gate + 1)) != AM_OK)
+            return rc;
+        hipLaunchKernelGGL(knn_fast_decide_kernel, dim3(1), dim3(64), 0, st, gate, N, k1, 2, f.pair_count, maxn, b.ov_count);
         AM_LAUNCH_CHECK();
     }
     if (long long* stats = filter_stats_for_current_device()) {

@@ -464,13 +464,13 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
                 int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
                 int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
                 int* __restrict__ wgq_count, int part, int nparts, float fc, uint2* __restrict__ ovq, float* __restrict__ ovv,
-                unsigned long long* __restrict__ ovn, int ovcap) {
+                unsigned long long* __restrict__ ovn, int ovcap, const int* __restrict__ skip) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const WLane L;
     const int64_t T = (N + WTB - 1) / WTB;
     const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
     constexpr int NW = KnnWideEpilogue<KCAP>::NWAVES;
-    if (sw.ntiles == 0) {
+    if (sw.ntiles == 0 || (skip != nullptr && *skip != 0)) {      // (skip: the data-dependent fallback took over, pairwise_fast.h)
         if (L.tid <= NW) wgq_count[(int64_t)blockIdx.x * (NW + 1) + L.tid] = 0;
         return;
     }
@@ -679,13 +679,13 @@ template <int KCAP>
 static int launch_knn_wide_t(unsigned nwg, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, float* thr, int Dh,
                              int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
                              uint2* wgq, float* wgv, int qcap, int* wgq_count, int part, int nparts, float fc, uint2* ovq,
-                             float* ovv, unsigned long long* ovn, int ovcap, hipStream_t st) {
+                             float* ovv, unsigned long long* ovn, int ovcap, const int* skip, hipStream_t st) {
     AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_wide_kernel<KCAP>), (int)KNN_WIDE_LDS_BYTES));
 #ifdef AM_DEV_KNOBS
     AM_HIP_TRY(set_wide_dev_symbols(st));
 #endif
     hipLaunchKernelGGL(knn_wide_kernel<KCAP>, dim3(nwg), dim3(WTHREADS), KNN_WIDE_LDS_BYTES, st, Xb, N, ldh, xnorm, thr, Dh, win_tiles,
-                       nwin, per_win, k1, maxn, partial, cnt, cap, wgq, wgv, qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap);
+                       nwin, per_win, k1, maxn, partial, cnt, cap, wgq, wgv, qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap, skip);
     AM_LAUNCH_CHECK();
     return AM_OK;
 }
@@ -693,13 +693,13 @@ static int launch_knn_wide_t(unsigned nwg, const float* Xb, int64_t N, int64_t l
 int launch_knn_wide(int kcap, unsigned nwg, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, float* thr, int Dh,
                     int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
                     uint2* wgq, float* wgv, int qcap, int* wgq_count, int part, int nparts, float fc, uint2* ovq, float* ovv,
-                    unsigned long long* ovn, int ovcap, hipStream_t st) {
+                    unsigned long long* ovn, int ovcap, const int* skip, hipStream_t st) {
     if (kcap == 6)
         return launch_knn_wide_t<6>(nwg, Xb, N, ldh, xnorm, thr, Dh, win_tiles, nwin, per_win, k1, maxn, partial, cnt, cap, wgq, wgv,
-                                    qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap, st);
+                                    qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap, skip, st);
     AM_REQUIRE(kcap == 11, AM_ERR_UNSUPPORTED_K, "the wide k-NN sweep holds lists of 6 or 11 entries (got %d)", kcap);
     return launch_knn_wide_t<11>(nwg, Xb, N, ldh, xnorm, thr, Dh, win_tiles, nwin, per_win, k1, maxn, partial, cnt, cap, wgq, wgv,
-                                 qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap, st);
+                                 qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap, skip, st);
 }
 
 }  // namespace am

@@ -124,14 +124,16 @@ def test_knn_long_lists_on_mid_sized_sets_bit_exact(am, k):
     assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, k).view(np.uint32))
 
 
-@pytest.mark.parametrize("n,d,k", [(17000, 64, 5), (16400, 40, 10), (6200, 256, 5), (8300, 130, 3)])
-def test_knn_filter_sweep_at_its_lower_thresholds_bit_exact(am, n, d, k):
-    """The f16 filter sweep + exact verification just above the row counts where it takes over (round 3: 6144 rows for
-    D >= 256, 8192 for 128 <= D < 256, 16 384 for the narrow rows n_pca leaves) - radii bit-identical to the C model of the exact
-    arithmetic, no row falls back."""
+@pytest.mark.parametrize("n,d,k,kind", [(17000, 64, 5, "randn"), (12100, 40, 10, "randn"), (6200, 256, 5, "randn"),
+                                        (8300, 130, 3, "randn"), (12100, 64, 5, "unit"), (6200, 512, 10, "unit"),
+                                        (8300, 128, 5, "unit")])
+def test_knn_filter_sweep_at_its_lower_thresholds_bit_exact(am, n, d, k, kind):
+    """The f16 filter sweep + exact verification just above the row counts where it takes over (6144 rows for D >= 256,
+    8192 for 128 <= D < 256, 12 000 for the narrow rows n_pca leaves: round 4, tools/threshold_sweep.py on randn AND
+    unit-norm (CLAP-shaped) sets) - radii bit-identical to the C model of the exact arithmetic, no row falls back."""
     from oracle import exact
     ops = am.hip_ops
-    x = gi.randn(66, n, d)
+    x = gi.randn(66, n, d) if kind == "randn" else gi.unit_norm(66, n, d)
     assert ops.knn_path(n, n, d, k) == 3
     ops.filter_stats_enable("cuda:0", True)
     r = am.nearest_neighbour_distances(dev(x), k).cpu().numpy()
@@ -139,6 +141,33 @@ def test_knn_filter_sweep_at_its_lower_thresholds_bit_exact(am, n, d, k):
     ops.filter_stats_enable("cuda:0", False)
     assert stats["knn_calls"] == 1 and stats["knn_fallback_rows"] == 0, stats
     assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, k).view(np.uint32))
+
+
+@pytest.mark.parametrize("n,d,k", [(20000, 128, 5), (9000, 512, 5), (16500, 64, 10)])
+def test_knn_filter_gives_way_on_data_it_cannot_separate(am, n, d, k):
+    """Tightly clustered rows (50 centres, spread 1e-3): every member of a row's cluster lies inside the f16 error band of its
+    (k+1)-th neighbour - hundreds of undecidable pairs per row (measured before the guard: 283 ms against 7.5 ms for the exact
+    kernels at 20 000 x 512, k = 5).  The device-side checks of the filter path (knn_fast_predict_kernel) must hand the whole
+    set to the exact general kernel: every row is reported as a fallback row, and the radii are the C model's bits."""
+    from oracle import exact
+    ops = am.hip_ops
+    rng = np.random.default_rng(5)
+    centres = rng.standard_normal((50, d)).astype(np.float32)
+    x = (centres[rng.integers(0, 50, n)] + 1e-3 * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+    assert ops.knn_path(n, n, d, k) == 3                     # the shapes alone still choose the filter path
+    ops.filter_stats_enable("cuda:0", True)
+    r = am.nearest_neighbour_distances(dev(x), k).cpu().numpy()
+    stats = ops.filter_stats_read("cuda:0")
+    ops.filter_stats_enable("cuda:0", False)
+    assert stats["knn_calls"] == 1 and stats["knn_fallback_rows"] == n, stats
+    assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, k).view(np.uint32))
+    # well-separated data of the same shape keeps the filter path (no fallback row)
+    y = gi.randn(67, n, d)
+    ops.filter_stats_enable("cuda:0", True)
+    am.nearest_neighbour_distances(dev(y), k)
+    stats = ops.filter_stats_read("cuda:0")
+    ops.filter_stats_enable("cuda:0", False)
+    assert stats["knn_fallback_rows"] == 0, stats
 
 
 def test_knn_rows_vs_other_columns(am):
@@ -547,7 +576,7 @@ def test_membership_filter_survives_undecidable_inputs():
     assert outs[0] == outs[1], outs
 
 
-@pytest.mark.parametrize("n_ref,n_cand", [(70000, 300), (300, 70000), (33000, 1500)])
+@pytest.mark.parametrize("n_ref,n_cand", [(70000, 1500), (1500, 70000), (33000, 3100)])    # (>= 1e8 pairs: the filter's threshold at D = 64)
 def test_membership_filter_unequal_sets_bit_exact(am, n_ref, n_cand):
     """Very unequal set sizes through the 256-row filter engine (one column chunk / two row blocks / ragged edges):
     counts, flags and row minima equal the C model bit for bit (radii chosen so that a few percent of the pairs count)."""
