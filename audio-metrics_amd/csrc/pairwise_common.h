@@ -59,7 +59,7 @@ struct SymWork {
 };
 
 // tiles of window W that belong to row block pb (cyclic half-range pairing; see sym_work)
-__device__ __forceinline__ SymWork sym_item(int64_t T, int win_tiles, int W, int64_t pb, int part, int nparts) {
+__host__ __device__ __forceinline__ SymWork sym_item(int64_t T, int win_tiles, int W, int64_t pb, int part, int nparts) {
     const int64_t q0 = (int64_t)W * win_tiles;
     const int64_t q1 = (q0 + win_tiles < T) ? q0 + win_tiles : T;
     // offsets 0 .. T/2; for even T the antipodal offset belongs to the lower-numbered block only
@@ -83,6 +83,31 @@ __device__ __forceinline__ SymWork sym_item(int64_t T, int win_tiles, int W, int
     return w;
 }
 
+// (window, slot e of the window) -> row block: within a window the row blocks that own ALL of its tiles come first (equal
+// work items that walk the window's Q tiles in lockstep), the partial ones last
+__host__ __device__ __forceinline__ int64_t sym_block_of(int64_t T, int win_tiles, int W, int e) {
+    const int64_t q0 = (int64_t)W * win_tiles;
+    const int64_t q1 = (q0 + win_tiles < T) ? q0 + win_tiles : T;
+    const int wlen = (int)(q1 - q0);
+    const int full_lo = wlen - 1, full_hi = (int)(T / 2);          // r in [full_lo, full_hi]: pb <= q0, pb+noff >= q1
+    const int nfull = full_hi >= full_lo ? full_hi - full_lo + 1 : 0;
+    int r;
+    if (e < nfull) r = full_lo + e;
+    else if (e - nfull < full_lo) r = e - nfull;
+    else r = full_hi + 1 + (e - nfull - full_lo);
+    int64_t pb = (q1 - 1 - r) % T;
+    if (pb < 0) pb += T;
+    return pb;
+}
+
+// workgroups of the sweep that have tiles to multiply for rank `part` (host side: sizes the queue regions of a partitioned run)
+static inline int64_t sym_active_items(int64_t T, int win_tiles, int nwin, int per_win, int part, int nparts) {
+    int64_t n = 0;
+    for (int W = 0; W < nwin; ++W)
+        for (int e = 0; e < per_win; ++e) n += sym_item(T, win_tiles, W, sym_block_of(T, win_tiles, W, e), part, nparts).ntiles > 0;
+    return n;
+}
+
 __device__ __forceinline__ SymWork sym_work(int64_t T, int win_tiles, int nwin, int per_win, int part, int nparts) {
     // Work item = (column-tile WINDOW, row block) over the CYCLIC HALF-RANGE pairing: block pb owns the tile
     // pairs (pb, q) with (q - pb) mod T in 0 .. T/2.  All workgroups in flight stream the same window of Q
@@ -92,24 +117,7 @@ __device__ __forceinline__ SymWork sym_work(int64_t T, int win_tiles, int nwin, 
     // in which other blocks generate the mirrored candidates for pb's rows - pb has already published a
     // bound over most of its half-range.
     const int W = nwin - 1 - (int)(blockIdx.x / per_win);
-    const int64_t q0 = (int64_t)W * win_tiles;
-    const int64_t q1 = (q0 + win_tiles < T) ? q0 + win_tiles : T;
-    // Within a window, the row blocks that own ALL of its tiles (equal-sized work items, which therefore walk
-    // the window's Q tiles in lockstep and share them through L2) are issued first, the partial ones (blocks
-    // inside the window and blocks whose half-range ends inside it) last.
-    int r;
-    {
-        const int e = (int)(blockIdx.x % per_win);
-        const int wlen = (int)(q1 - q0);
-        const int full_lo = wlen - 1, full_hi = (int)(T / 2);          // r in [full_lo, full_hi]: pb <= q0, pb+noff >= q1
-        const int nfull = full_hi >= full_lo ? full_hi - full_lo + 1 : 0;
-        if (e < nfull) r = full_lo + e;
-        else if (e - nfull < full_lo) r = e - nfull;
-        else r = e + 1 - full_lo + full_lo;                            // = e + 1 ... beyond the full range
-        if (e >= nfull + full_lo) r = full_hi + 1 + (e - nfull - full_lo);
-    }
-    int64_t pb = (q1 - 1 - r) % T;
-    if (pb < 0) pb += T;
+    const int64_t pb = sym_block_of(T, win_tiles, W, (int)(blockIdx.x % per_win));
     return sym_item(T, win_tiles, W, pb, part, nparts);
 }
 
@@ -310,6 +318,6 @@ int launch_knn_wide_sample(int kcap, const float* Xb, int64_t N, int64_t ldh, co
 int launch_knn_wide(int kcap, unsigned nwg, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, float* thr, int Dh,
                     int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
                     uint2* wgq, float* wgv, int qcap, int* wgq_count, int part, int nparts, float fc, uint2* ovq, float* ovv,
-                    unsigned long long* ovn, int ovcap, const int* skip, hipStream_t st);
+                    unsigned long long* ovn, int ovcap, const int* skip, int* region_counter, hipStream_t st);
 
 }  // namespace am

@@ -873,15 +873,27 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
                 int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
                 int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
                 int* __restrict__ wgq_count, int part, int nparts, float fc, uint2* __restrict__ ovq, float* __restrict__ ovv,
-                unsigned long long* __restrict__ ovn, int ovcap, const int* __restrict__ skip) {
+                unsigned long long* __restrict__ ovn, int ovcap, const int* __restrict__ skip, int* __restrict__ region_counter) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LaneInfo L;
     const int64_t T = (N + TB - 1) / TB;
     const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
     constexpr int NW = KnnFastEpilogue<KCAP>::NWAVES;
     if (sw.ntiles == 0 || (skip != nullptr && *skip != 0)) {      // (skip: the data-dependent fallback took over, see knn_fast_predict_kernel)
-        if (L.tid <= NW) wgq_count[(int64_t)blockIdx.x * (NW + 1) + L.tid] = 0;
+        if (region_counter == nullptr && L.tid <= NW) wgq_count[(int64_t)blockIdx.x * (NW + 1) + L.tid] = 0;
         return;
+    }
+    // Queue region of this workgroup: its own index - or, in a PARTITIONED run (region_counter given), the next free one:
+    // only the workgroups of this rank's row blocks queue anything, so the memory of all regions is cut into as many (larger)
+    // regions as there are active workgroups and handed out in arrival order (the counts were zeroed by the host).  With
+    // regions indexed by workgroup a rank used 1 / nparts of them, and at 1M rows the busiest ones overflowed: 14 000 rows
+    // went through the row-at-a-time fix-up (6 - 11 s per set on 8 ranks, tools/scale_model.py).
+    int64_t region = blockIdx.x;
+    if (region_counter != nullptr) {
+        int* slot = reinterpret_cast<int*>(lds + ENGINE_LDS_FLOATS + 4 * TB) + 1;
+        if (L.tid == 0) *slot = atomicAdd(region_counter, 1);
+        __syncthreads();
+        region = __builtin_amdgcn_readfirstlane(*slot);
     }
     const float nmax = __uint_as_float(maxn[0]);
     KnnFastEpilogue<KCAP> epi(L);
@@ -892,12 +904,12 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     epi.aux = lds + ENGINE_LDS_FLOATS;
     const int wave = __builtin_amdgcn_readfirstlane(L.tid >> 6);
     epi.wcap = qcap / (2 * NW);                       // private sub-regions: half of the workgroup's region in all
-    epi.wgq = wgq + (int64_t)blockIdx.x * qcap + wave * epi.wcap;
-    epi.wgv = wgv + (int64_t)blockIdx.x * qcap + wave * epi.wcap;
+    epi.wgq = wgq + region * qcap + wave * epi.wcap;
+    epi.wgv = wgv + region * qcap + wave * epi.wcap;
     epi.wq = 0;
     epi.shcap = qcap - NW * epi.wcap;                 // the shared part behind them
-    epi.shq = wgq + (int64_t)blockIdx.x * qcap + NW * epi.wcap;
-    epi.shv = wgv + (int64_t)blockIdx.x * qcap + NW * epi.wcap;
+    epi.shq = wgq + region * qcap + NW * epi.wcap;
+    epi.shv = wgv + region * qcap + NW * epi.wcap;
     epi.qn = reinterpret_cast<int*>(lds + ENGINE_LDS_FLOATS + 4 * TB);
     if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
     epi.ovq = ovq;
@@ -927,8 +939,8 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
         for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
     }
     __syncthreads();
-    if (L.lane == 0) wgq_count[(int64_t)blockIdx.x * (NW + 1) + wave] = min(epi.wq, epi.wcap);
-    if (L.tid == 0) wgq_count[(int64_t)blockIdx.x * (NW + 1) + NW] = min(*epi.qn, epi.shcap);
+    if (L.lane == 0) wgq_count[region * (NW + 1) + wave] = min(epi.wq, epi.wcap);
+    if (L.tid == 0) wgq_count[region * (NW + 1) + NW] = min(*epi.qn, epi.shcap);
     if (L.tid < TB) {
         const int64_t i = sw.pb * TB + L.tid;
         if (i < N) {
@@ -1233,8 +1245,9 @@ struct KnnFastBuffers {           // on top of the symmetric path's KnnBuffers
     uint2* ovq;                   // spill queue (entries past a region's capacity)
     float* ovv;
     unsigned long long* ovn;      // entries offered to it (64-bit: adversarial inputs offer billions)
-    int* gate;                    // [4] data-dependent fallback: [0] skip the sweep, [1] skip verification / run the exact
-                                  //     kernel, [2] rows the sample cannot separate, [3] rows the prune step sent to fix-up
+    int* gate;                    // [8] data-dependent fallback: [0] skip the sweep, [1] skip verification / run the exact
+                                  //     kernel, [2] rows the sample cannot separate, [3] rows the prune step sent to fix-up;
+                                  //     [4] next free queue region of a partitioned run
     float* xpartial;              // partial lists of the gated exact kernel (choose_chunks(N, N) x N x kcap)
 };
 constexpr int KNN_FAST_OVCAP = 1 << 22;
@@ -1250,7 +1263,7 @@ static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan&
     f.ovn = c.take<unsigned long long>(1);
     f.ovq = c.take<uint2>(KNN_FAST_OVCAP);
     f.ovv = c.take<float>(KNN_FAST_OVCAP);
-    f.gate = c.take<int>(4);
+    f.gate = c.take<int>(8);
     f.xpartial = c.take<float>((size_t)choose_chunks(N, N) * N * p.kcap);
     return f;
 }
@@ -1335,21 +1348,34 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     {
         AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_fast_kernel<KCAP>), (int)PAIRWISE_LDS_BYTES + 16));
     }
-    const int qcap = p.qcap;                                               // per workgroup: nsub private sub-regions + a shared part
+    int qcap = p.qcap;                                                     // per workgroup: nsub private sub-regions + a shared part
     const int nsub = p.tile_rows == WIDE_TILE_ROWS ? 8 : 4;                  // KnnFastEpilogue::NWAVES of the engine that runs
+    unsigned nregions = nwg;
+    int* region_counter = nullptr;
+    if (nparts > 1) {
+        // a rank's workgroups share ALL the region memory: as many regions as it has active workgroups, handed out in
+        // arrival order (see the kernels); every region nparts-ish times the one-GPU size
+        const int64_t active = std::max<int64_t>(1, sym_active_items(ceil_div(N, p.tile_rows), p.win_tiles, p.nwin, p.per_win, part, nparts));
+        const int64_t grown = std::min<int64_t>((int64_t)nwg * qcap / active, 1 << 18) / 16 * 16;
+        qcap = (int)std::max<int64_t>(grown, qcap);
+        nregions = (unsigned)std::min<int64_t>(active, (int64_t)nwg * p.qcap / qcap);
+        region_counter = f.gate + 4;
+        AM_HIP_TRY(hipMemsetAsync(region_counter, 0, sizeof(int), st));
+        AM_HIP_TRY(hipMemsetAsync(b.wgq_count, 0, (size_t)nregions * (nsub + 1) * sizeof(int), st));
+    }
     const int wcap = qcap / (2 * nsub);
-    const unsigned nreg = nwg * (unsigned)(nsub + 1);                       // queue parts in all
+    const unsigned nreg = nregions * (unsigned)(nsub + 1);                  // queue parts in all
     static const int ovcap = std::max(0, std::min(env_int("AM_KNN_FAST_OVCAP", KNN_FAST_OVCAP), KNN_FAST_OVCAP));   // (tests shrink it)
     clock_begin(AM_KERNEL_KNN, st);
     if (p.tile_rows == WIDE_TILE_ROWS) {
         if ((rc = launch_knn_wide(KCAP, nwg, Xb, N, ldh, b.xn, thr, Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt,
                                   p.cap, b.wgq, f.wgv, qcap, b.wgq_count, part, nparts, fast_c(D), f.ovq, f.ovv, f.ovn, ovcap,
-                                  skip_sweep, st)) != AM_OK)
+                                  skip_sweep, region_counter, st)) != AM_OK)
             return rc;
     } else {
         hipLaunchKernelGGL(knn_fast_kernel<KCAP>, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st, Xb, N, ldh, b.xn,
                            thr, Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, f.wgv, qcap,
-                           b.wgq_count, part, nparts, fast_c(D), f.ovq, f.ovv, f.ovn, ovcap, skip_sweep);
+                           b.wgq_count, part, nparts, fast_c(D), f.ovq, f.ovv, f.ovn, ovcap, skip_sweep, region_counter);
     }
     clock_end(AM_KERNEL_KNN, st);
     AM_LAUNCH_CHECK();
@@ -1360,7 +1386,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     hipLaunchKernelGGL(knn_fast_scatter_spill_kernel, dim3(256), dim3(256), 0, st, f.ovq, f.ovv, f.ovn, ovcap, b.cand, f.fidx,
                        b.cnt, p.cap, thr, skip_sweep);
     AM_LAUNCH_CHECK();
-    const int64_t pair_cap64 = std::min<int64_t>((int64_t)nwg * qcap, (int64_t)1 << 30);
+    const int64_t pair_cap64 = std::min<int64_t>((int64_t)nwg * p.qcap, (int64_t)1 << 30);   // (the pair list reuses the region memory)
     const int pair_cap = (int)pair_cap64;
     hipLaunchKernelGGL(knn_fast_prune_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.cand, f.fidx, b.cnt, p.cap,
                        N, k1, b.xn, maxn, b.wgq, pair_cap, f.pair_count, f.cnt2, out_lists != nullptr ? 1 : 0, fast_c(D), gate);

@@ -464,15 +464,27 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
                 int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
                 int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
                 int* __restrict__ wgq_count, int part, int nparts, float fc, uint2* __restrict__ ovq, float* __restrict__ ovv,
-                unsigned long long* __restrict__ ovn, int ovcap, const int* __restrict__ skip) {
+                unsigned long long* __restrict__ ovn, int ovcap, const int* __restrict__ skip, int* __restrict__ region_counter) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const WLane L;
     const int64_t T = (N + WTB - 1) / WTB;
     const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
     constexpr int NW = KnnWideEpilogue<KCAP>::NWAVES;
     if (sw.ntiles == 0 || (skip != nullptr && *skip != 0)) {      // (skip: the data-dependent fallback took over, pairwise_fast.h)
-        if (L.tid <= NW) wgq_count[(int64_t)blockIdx.x * (NW + 1) + L.tid] = 0;
+        if (region_counter == nullptr && L.tid <= NW) wgq_count[(int64_t)blockIdx.x * (NW + 1) + L.tid] = 0;
         return;
+    }
+    // Queue region of this workgroup: its own index - or, in a PARTITIONED run (region_counter given), the next free one:
+    // only the workgroups of this rank's row blocks queue anything, so the memory of all regions is cut into as many (larger)
+    // regions as there are active workgroups and handed out in arrival order (the counts were zeroed by the host).  With
+    // regions indexed by workgroup a rank used 1 / nparts of them, and at 1M rows the busiest ones overflowed: 14 000 rows
+    // went through the row-at-a-time fix-up (6 - 11 s per set on 8 ranks, tools/scale_model.py).
+    int64_t region = blockIdx.x;
+    if (region_counter != nullptr) {
+        int* slot = reinterpret_cast<int*>(lds + WENGINE_LDS_WORDS + 8 * WTB) + 1;
+        if (L.tid == 0) *slot = atomicAdd(region_counter, 1);
+        __syncthreads();
+        region = __builtin_amdgcn_readfirstlane(*slot);
     }
     const float nmax = __uint_as_float(maxn[0]);
     KnnWideEpilogue<KCAP> epi(L);
@@ -483,12 +495,12 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
     epi.aux = lds + WENGINE_LDS_WORDS;
     const int wave = __builtin_amdgcn_readfirstlane(L.wave);
     epi.wcap = qcap / (2 * NW);                       // private sub-regions: half of the workgroup's region in all
-    epi.wgq = wgq + (int64_t)blockIdx.x * qcap + wave * epi.wcap;
-    epi.wgv = wgv + (int64_t)blockIdx.x * qcap + wave * epi.wcap;
+    epi.wgq = wgq + region * qcap + wave * epi.wcap;
+    epi.wgv = wgv + region * qcap + wave * epi.wcap;
     epi.wq = 0;
     epi.shcap = qcap - NW * epi.wcap;                 // the shared part behind them
-    epi.shq = wgq + (int64_t)blockIdx.x * qcap + NW * epi.wcap;
-    epi.shv = wgv + (int64_t)blockIdx.x * qcap + NW * epi.wcap;
+    epi.shq = wgq + region * qcap + NW * epi.wcap;
+    epi.shv = wgv + region * qcap + NW * epi.wcap;
     epi.qn = reinterpret_cast<int*>(lds + WENGINE_LDS_WORDS + 8 * WTB);
     if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
     epi.ovq = ovq;
@@ -518,8 +530,8 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
         for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
     }
     __syncthreads();
-    if (L.lane == 0) wgq_count[(int64_t)blockIdx.x * (NW + 1) + wave] = min(epi.wq, epi.wcap);
-    if (L.tid == 0) wgq_count[(int64_t)blockIdx.x * (NW + 1) + NW] = min(*epi.qn, epi.shcap);
+    if (L.lane == 0) wgq_count[region * (NW + 1) + wave] = min(epi.wq, epi.wcap);
+    if (L.tid == 0) wgq_count[region * (NW + 1) + NW] = min(*epi.qn, epi.shcap);
     if (L.tid < WTB) {
         const int64_t i = sw.pb * WTB + L.tid;
         if (i < N) {
@@ -679,13 +691,13 @@ template <int KCAP>
 static int launch_knn_wide_t(unsigned nwg, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, float* thr, int Dh,
                              int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
                              uint2* wgq, float* wgv, int qcap, int* wgq_count, int part, int nparts, float fc, uint2* ovq,
-                             float* ovv, unsigned long long* ovn, int ovcap, const int* skip, hipStream_t st) {
+                             float* ovv, unsigned long long* ovn, int ovcap, const int* skip, int* region_counter, hipStream_t st) {
     AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_wide_kernel<KCAP>), (int)KNN_WIDE_LDS_BYTES));
 #ifdef AM_DEV_KNOBS
     AM_HIP_TRY(set_wide_dev_symbols(st));
 #endif
     hipLaunchKernelGGL(knn_wide_kernel<KCAP>, dim3(nwg), dim3(WTHREADS), KNN_WIDE_LDS_BYTES, st, Xb, N, ldh, xnorm, thr, Dh, win_tiles,
-                       nwin, per_win, k1, maxn, partial, cnt, cap, wgq, wgv, qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap, skip);
+                       nwin, per_win, k1, maxn, partial, cnt, cap, wgq, wgv, qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap, skip, region_counter);
     AM_LAUNCH_CHECK();
     return AM_OK;
 }
@@ -693,13 +705,13 @@ static int launch_knn_wide_t(unsigned nwg, const float* Xb, int64_t N, int64_t l
 int launch_knn_wide(int kcap, unsigned nwg, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, float* thr, int Dh,
                     int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
                     uint2* wgq, float* wgv, int qcap, int* wgq_count, int part, int nparts, float fc, uint2* ovq, float* ovv,
-                    unsigned long long* ovn, int ovcap, const int* skip, hipStream_t st) {
+                    unsigned long long* ovn, int ovcap, const int* skip, int* region_counter, hipStream_t st) {
     if (kcap == 6)
         return launch_knn_wide_t<6>(nwg, Xb, N, ldh, xnorm, thr, Dh, win_tiles, nwin, per_win, k1, maxn, partial, cnt, cap, wgq, wgv,
-                                    qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap, skip, st);
+                                    qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap, skip, region_counter, st);
     AM_REQUIRE(kcap == 11, AM_ERR_UNSUPPORTED_K, "the wide k-NN sweep holds lists of 6 or 11 entries (got %d)", kcap);
     return launch_knn_wide_t<11>(nwg, Xb, N, ldh, xnorm, thr, Dh, win_tiles, nwin, per_win, k1, maxn, partial, cnt, cap, wgq, wgv,
-                                 qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap, skip, st);
+                                 qcap, wgq_count, part, nparts, fc, ovq, ovv, ovn, ovcap, skip, region_counter, st);
 }
 
 }  // namespace am
