@@ -8,9 +8,10 @@ is a reduction over rows plus at most one exchange step:
                 local centred scatters of both sets -> one all-reduce -> covariances;
                 the 2 MB Newton-Schulz problem is then solved redundantly on every rank,
                 on a side stream under the PRDC kernels.
-  KD            all-gather of the embeddings (needed by PRDC anyway), started before the
-                statistics kernels and awaited after them; subsets are dealt round-robin
-                to ranks; the S partial results are summed.
+  KD            all-gather of the embeddings (needed by PRDC anyway): the reference rows before the
+                statistics kernels, the candidate rows behind the reference set's bounds exchange
+                (one communicator: they travel under the reference set's sweep); subsets are dealt
+                round-robin to ranks; the S partial results are summed.
   PRDC          each rank owns a row block of both sets against the gathered columns:
                 radii stay local -> all-gather; column counts and the two local row totals
                 travel in one int32 buffer -> one all-reduce.

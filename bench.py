@@ -259,6 +259,9 @@ def main():
                     help="row gathers on a second RCCL communicator (distributed.enable_bulk_communicator; default: one)")
     args = ap.parse_args()
 
+    # dmabuf IPC is the only form the host driver supports (see the environment notes): must be in the environment BEFORE the
+    # first HIP call of the process initialises the runtime; harmless when already set
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))                # plain `python bench.py --gpus N`: the ranks run in a child
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -273,8 +276,6 @@ def main():
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     if world > 1:
-        # dmabuf IPC is the only form the host driver supports (see the environment notes); harmless when already set
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
