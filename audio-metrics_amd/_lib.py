@@ -20,6 +20,8 @@ SIGNATURES = {
     "am_stats_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "am_colsum_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_size_t, _P]),
     "am_scatter_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
+    "am_stats_f64_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "am_stats_f64": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "am_stats_merge_f64": (c_int, [c_int64, _P, _P, c_int64, _P, _P, c_int, _P, _P, _P]),
     "am_stats_push_max_rows": (c_int, []),
     "am_stats_push_f32": (c_int, [_P, c_int64, c_int, c_int64, c_int64, _P, _P, _P, _P, c_int64, _P]),

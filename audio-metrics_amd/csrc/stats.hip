@@ -413,6 +413,97 @@ static int check_x(const float* X, int64_t N, int D, int64_t ld) {
     return AM_OK;
 }
 
+// ---- float64 rows (data.py:37-58 computes in the dtype it is given: the reference's own test embedder and the output of its
+//      PCA projection are f64).  Column sums per row block + the same fixed-order reduction as above; the centred scatter
+//      on v_mfma_f64_16x16x4_f64: a workgroup owns a 32 x 32 block of the upper triangle of the D x D matrix (wave w the
+//      16 x 16 tile (w >> 1, w & 1)) over one slab of rows, lane (l15, l4) feeding row n0 + l4, column c0 + l15 - no LDS, the
+//      operands come straight from the cache (a rare path: ~2 ms for 100 000 x 512).  Per-slab partial blocks, reduced in a
+//      fixed order and mirrored (deterministic).
+constexpr int S64_TILE = 32;
+__global__ void __launch_bounds__(256) colsum64_partial_kernel(const double* __restrict__ X, int64_t N, int64_t ld, int D,
+                                                               int64_t rows_per_block, double* __restrict__ partial) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        double s = 0.0;
+        for (int64_t row = r0; row < r1; ++row) s += X[row * ld + d];
+        partial[(int64_t)blockIdx.x * D + d] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) scatter64_partial_kernel(const double* __restrict__ X, int64_t N, int64_t ld, int D,
+                                                                const double* __restrict__ mean, int64_t slab_rows, int ntri,
+                                                                double* __restrict__ partial) {
+    const int T = (D + S64_TILE - 1) / S64_TILE;
+    int tp, tq;
+    tri_decode((int)(blockIdx.x % ntri), T, tp, tq);
+    const int64_t slab = blockIdx.x / ntri;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ca = tp * S64_TILE + (wave >> 1) * 16 + l15, cb = tq * S64_TILE + (wave & 1) * 16 + l15;
+    const double ma = ca < D ? mean[ca] : 0.0, mb = cb < D ? mean[cb] : 0.0;
+    const int64_t r0 = slab * slab_rows;
+    const int64_t r1 = (r0 + slab_rows < N) ? r0 + slab_rows : N;
+    typedef double f64x4s __attribute__((ext_vector_type(4)));
+    f64x4s acc = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t n0 = r0; n0 < r1; n0 += 16) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                             // four independent row groups in flight
+            const int64_t n = n0 + u * 4 + l4;
+            const bool in = n < r1;
+            a[u] = (in && ca < D) ? X[n * ld + ca] - ma : 0.0;
+            b[u] = (in && cb < D) ? X[n * ld + cb] - mb : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+    // C layout: row (first factor's column) = (lane >> 4) + 4 reg, column (second factor's column) = lane & 15
+    double* out = partial + ((int64_t)slab * ntri + (blockIdx.x % ntri)) * (S64_TILE * S64_TILE);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[((wave >> 1) * 16 + l4 + 4 * r) * S64_TILE + (wave & 1) * 16 + l15] = acc[r];
+}
+
+__global__ void __launch_bounds__(256) scatter64_reduce_kernel(const double* __restrict__ partial, int nslabs, int ntri, int D,
+                                                               double scale, double* __restrict__ out) {
+    const int T = (D + S64_TILE - 1) / S64_TILE;
+    int tp, tq;
+    tri_decode((int)blockIdx.y, T, tp, tq);
+    const int e = blockIdx.x * 256 + threadIdx.x;                 // element of the 32 x 32 block
+    const int i = tp * S64_TILE + e / S64_TILE, j = tq * S64_TILE + e % S64_TILE;
+    if (i >= D || j >= D) return;
+    double s = 0.0;
+    for (int sl = 0; sl < nslabs; ++sl) s += partial[((int64_t)sl * ntri + blockIdx.y) * (S64_TILE * S64_TILE) + e];
+    s *= scale;
+    if (tp != tq || j >= i) out[(int64_t)i * D + j] = s;           // diagonal blocks: the upper triangle decides (exactly symmetric)
+    if (tp != tq || j > i) out[(int64_t)j * D + i] = s;
+}
+
+struct Stats64Plan {
+    int cs_blocks, ntri, nslabs;
+    int64_t cs_rows, slab_rows;
+};
+static Stats64Plan plan_stats64(int64_t N, int D) {
+    Stats64Plan p;
+    int64_t b = std::min<int64_t>(std::max<int64_t>(ceil_div(N, 256), 1), 512);
+    p.cs_rows = ceil_div(N, b);
+    p.cs_blocks = (int)ceil_div(N, p.cs_rows);
+    const int T = (int)ceil_div(D, S64_TILE);
+    p.ntri = T * (T + 1) / 2;
+    int64_t s = std::max<int64_t>(2048 / p.ntri, 1);                 // ~8 workgroups per CU in all
+    s = std::min<int64_t>(s, std::max<int64_t>(ceil_div(N, 256), 1));   // at least 256 rows per slab
+    s = std::min<int64_t>(s, 64);
+    p.slab_rows = ceil_div(ceil_div(N, s), 16) * 16;
+    p.nslabs = (int)ceil_div(N, p.slab_rows);
+    return p;
+}
+static size_t stats64_ws(int D, const Stats64Plan& p) {
+    Carver c(nullptr, 0);
+    c.take<double>((size_t)p.cs_blocks * D);
+    c.take<double>((size_t)p.nslabs * p.ntri * S64_TILE * S64_TILE);
+    return c.off;
+}
+
 static int run_colsum(const float* X, int64_t N, int D, int64_t ld, double scale, double* out, double* partial,
                       const StatsPlan& p, hipStream_t st) {
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.cs_blocks), dim3(256), 0, st, X, N, ld, D, p.cs_rows, partial);
@@ -491,6 +582,41 @@ extern "C" int am_stats_f32(const float* X, int64_t N, int D, int64_t ld, double
         return AM_OK;
     }
     return run_scatter(X, N, D, ld, mean, 1.0 / (double)(N - 1), cov, sc_part, p, st);
+}
+
+extern "C" size_t am_stats_f64_workspace_bytes(int64_t N, int D) {
+    if (N < 1 || D < 1) return 0;
+    return stats64_ws(D, plan_stats64(N, D));
+}
+
+extern "C" int am_stats_f64(const double* X, int64_t N, int D, int64_t ld, double* mean, double* cov, void* ws, size_t ws_bytes,
+                            am_stream_t stream) {
+    AM_REQUIRE(X && mean && cov, AM_ERR_BAD_ARG, "null pointer");
+    AM_REQUIRE(N >= 1 && D >= 1, AM_ERR_BAD_SHAPE, "X has shape %lld x %d", (long long)N, D);
+    AM_REQUIRE(ld >= D, AM_ERR_BAD_ARG, "ld=%lld < D=%d", (long long)ld, D);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Stats64Plan p = plan_stats64(N, D);
+    Carver c(ws, ws_bytes);
+    double* cs_part = c.take<double>((size_t)p.cs_blocks * D);
+    double* sc_part = c.take<double>((size_t)p.nslabs * p.ntri * S64_TILE * S64_TILE);
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    hipLaunchKernelGGL(colsum64_partial_kernel, dim3(p.cs_blocks), dim3(256), 0, st, X, N, ld, D, p.cs_rows, cs_part);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)ceil_div(D, CSR_COLS)), dim3(256), 0, st, cs_part, p.cs_blocks, D,
+                       1.0 / (double)N, mean);
+    AM_LAUNCH_CHECK();
+    if (N == 1) {                                          // data.py:40-42
+        hipLaunchKernelGGL(zero_f64_kernel, dim3((unsigned)ceil_div((int64_t)D * D, 256)), dim3(256), 0, st, cov, (int64_t)D * D);
+        AM_LAUNCH_CHECK();
+        return AM_OK;
+    }
+    hipLaunchKernelGGL(scatter64_partial_kernel, dim3((unsigned)(p.ntri * p.nslabs)), dim3(256), 0, st, X, N, ld, D, mean, p.slab_rows,
+                       p.ntri, sc_part);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scatter64_reduce_kernel, dim3(S64_TILE * S64_TILE / 256, (unsigned)p.ntri), dim3(256), 0, st, sc_part,
+                       p.nslabs, p.ntri, D, 1.0 / (double)(N - 1), cov);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
 }
 
 extern "C" int am_stats_merge_f64(int64_t n1, const double* mean1, const double* cov1, int64_t n2, const double* mean2,

@@ -55,6 +55,7 @@ class AudioMetricsData:
         self._content_version = 0         # bumped whenever the stored rows change: validity of the cached PreparedSet
         self._prepared = None
         self._prepared_version = -1
+        self._fed_f64 = False             # float64 rows went through add(): the statistics come from the f64 values
 
     @property
     def embeddings(self):
@@ -122,6 +123,7 @@ class AudioMetricsData:
         if self.embeddings is not None:
             other._append(ops.as_matrix(self.embeddings.to(device)))
         other.radii = {key: r.to(device) for key, r in self.radii.items()}
+        other._fed_f64 = self._fed_f64
         return other
 
     def add(self, embeddings):
@@ -129,6 +131,8 @@ class AudioMetricsData:
         the embedding pipeline feeds (embed.py:231-236) - take ONE kernel launch (am_stats_push_f32) instead of the
         statistics / merge / copy chain."""
         e = embeddings
+        if torch.is_tensor(e) and e.dtype == torch.float64 or (isinstance(e, np.ndarray) and e.dtype == np.float64):
+            return self._add_f64(e)
         if not (torch.is_tensor(e) and e.is_cuda and e.dtype == torch.float32 and e.dim() == 2 and e.stride(1) == 1):
             e = self._to_device_matrix(embeddings)
         elif self._device is None:
@@ -143,6 +147,25 @@ class AudioMetricsData:
         self._update_stats(mean, cov, n)
         if self.store_embeddings:
             self._update_embeddings(e)
+
+    def _add_f64(self, embeddings):
+        """add() of float64 rows: statistics in f64 from the f64 values, as the reference computes them (data.py:39-44);
+        stored rows are kept as f32 for the kernel-distance / PRDC kernels (one RuntimeWarning per process)."""
+        e = ensure_tensor(embeddings)
+        if e.dim() != 2:
+            raise ValueError(f"embeddings must have shape [n, d], got {tuple(e.shape)}")
+        if not e.is_cuda:
+            e = e.to(self.device, non_blocking=True)
+        elif self._device is None:
+            self._device = e.device
+        n = e.shape[0]
+        if n == 0:
+            raise ValueError("cannot add an empty batch of embeddings")
+        mean, cov = ops.stats_f64(e)
+        self._update_stats(mean, cov, n)
+        self._fed_f64 = True
+        if self.store_embeddings:
+            self._update_embeddings(e)                      # narrowed (as_matrix warns once)
 
     def _push(self, e):
         """The one-launch form of add().  False (nothing done) when the running state is not in the plain (D,), (D, D) f64
@@ -181,6 +204,10 @@ class AudioMetricsData:
         if rows is None:
             return
         self.n = int(rows.shape[0])
+        if getattr(self, "_fed_f64", False) and self.mean is not None and self.n >= 2:
+            # the stored rows are an f32 copy of float64 inputs; the accumulated statistics - Chan-merged in f64 from the
+            # f64 values - describe the same rows and are the closer ones to what the reference recomputes from its f64 matrix
+            return
         self.mean, self.cov = ops.stats(rows)
         if self.n < 2:
             # reference quirk kept on purpose: a (1, 1) zero matrix, not (D, D) (data.py:56)
@@ -264,6 +291,7 @@ class AudioMetricsData:
             elif self.store_embeddings != other.store_embeddings:
                 raise AssertionError("cannot merge a set that stores its embeddings with one that does not")
             self._update_stats(other.mean.clone(), other.cov.clone(), other.n)
+            self._fed_f64 = self._fed_f64 or getattr(other, "_fed_f64", False)
             if self.store_embeddings:
                 self._update_embeddings(other.embeddings)
         return self

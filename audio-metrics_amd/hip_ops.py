@@ -164,15 +164,18 @@ _NARROWING_WARNED = False
 
 
 def _warn_narrowing():
-    """Once per process: the reference computes an add()'s statistics in the dtype of the embeddings it is given
-    (data.py:39-44; its own test embedder yields float64), this path computes on float32 rows - real embedders (CLAP,
-    VGGish) produce float32, so only synthetic float64 inputs see a difference (~1e-7 relative in the statistics)."""
+    """Once per process: the reference keeps float64 embeddings as they are (data.py:39-44, 68-72; its own test embedder and
+    the output of its PCA projection are float64).  Here an add() computes the STATISTICS of float64 rows in f64 too
+    (am_stats_f64), but rows that are stored - for the kernel distance and PRDC, whose kernels are f32 - are kept as
+    float32: real embedders (CLAP, VGGish) produce float32, so only synthetic float64 inputs and PCA-projected sets see
+    the narrowing (~6e-8 relative per element)."""
     global _NARROWING_WARNED
     if not _NARROWING_WARNED:
         _NARROWING_WARNED = True
         import warnings
-        warnings.warn("audio_metrics_amd: float64 embeddings are narrowed to float32 for the device path (the reference "
-                      "computes in the input dtype; differences are at the 1e-7 level)", RuntimeWarning, stacklevel=3)
+        warnings.warn("audio_metrics_amd: float64 embeddings are stored as float32 for the kernel-distance / PRDC kernels "
+                      "(statistics, FAD and APA are computed from the float64 values; the reference keeps float64 throughout)",
+                      RuntimeWarning, stacklevel=3)
 
 
 def as_matrix(e, name="embeddings"):
@@ -220,6 +223,24 @@ def stats(e):
     nb = lib.am_stats_workspace_bytes(n, d)
     ws = _workspace(nb, e.device)
     _call(lib, "am_stats_f32", e.device, _ptr(e), n, d, _ld(e), _ptr(mean), _ptr(cov), _ptr(ws), nb)
+    return mean, cov
+
+
+def stats_f64(e):
+    """mean f64[D], unbiased covariance f64[D, D] of the rows of a FLOAT64 device matrix, every step in f64 (am_stats_f64):
+    the reference computes in the dtype it is given (data.py:39-44)."""
+    lib = _lib.load()
+    _require_cuda(e, "embeddings")
+    if e.dim() != 2 or e.dtype != torch.float64:
+        raise ValueError(f"stats_f64 takes a 2-D float64 matrix, got {tuple(e.shape)} {e.dtype}")
+    if e.stride(1) != 1 or (e.shape[0] > 1 and e.stride(0) < e.shape[1]):
+        e = e.contiguous()
+    n, d = e.shape
+    mean = torch.empty(d, dtype=torch.float64, device=e.device)
+    cov = torch.empty((d, d), dtype=torch.float64, device=e.device)
+    nb = lib.am_stats_f64_workspace_bytes(n, d)
+    ws = _workspace(nb, e.device)
+    _call(lib, "am_stats_f64", e.device, _ptr(e), n, d, e.stride(0) if n > 1 else d, _ptr(mean), _ptr(cov), _ptr(ws), nb)
     return mean, cov
 
 

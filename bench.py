@@ -273,13 +273,20 @@ def main():
     # rank to one device, AM_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on the same GPU.
     device_index = int(os.environ.get("AM_BENCH_DEVICE", local_rank))
     backend = os.environ.get("AM_BENCH_BACKEND", "nccl")
+    if torch.cuda.device_count() <= device_index:
+        sys.exit(f"rank {rank}: cuda:{device_index} does not exist ({torch.cuda.device_count()} GPUs visible) - "
+                 f"--gpus {args.gpus} needs one GPU per rank")
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     if world > 1:
+        # a collective that does not complete (a rank died, a fabric problem) becomes an error after ten minutes instead of a
+        # hang that only the caller's own time limit ends
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("AM_BENCH_COLLECTIVE_TIMEOUT_S", "600")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     import audio_metrics_amd as am
     from audio_metrics_amd import hip_ops as ops

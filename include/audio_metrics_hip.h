@@ -68,6 +68,13 @@ int am_colsum_f32(const float* X, int64_t N, int D, int64_t ld,
                   double* colsum, void* ws, size_t ws_bytes, am_stream_t stream);
 int am_scatter_f32(const float* X, int64_t N, int D, int64_t ld, const double* mean,
                    double* scatter, void* ws, size_t ws_bytes, am_stream_t stream);
+/* float64 rows: the reference computes an add()'s statistics in the dtype of the embeddings it is given (data.py:39-44; its
+ * own test embedder and the output of its PCA projection are float64).  Same outputs, every step in f64 (column sums per row
+ * block, centred scatter on the f64 matrix cores, fixed-order reductions).  ld in elements, no alignment requirement. */
+size_t am_stats_f64_workspace_bytes(int64_t N, int D);
+int am_stats_f64(const double* X, int64_t N, int D, int64_t ld,
+                 double* mean, double* cov,
+                 void* ws, size_t ws_bytes, am_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * A3  Chan / pairwise merge of two (n, mean, cov) triples in f64

@@ -237,6 +237,36 @@ def test_incremental_equals_oneshot(am):
     assert c.embeddings.shape == (1101, 8)
 
 
+@pytest.mark.parametrize("n,d", [(1, 8), (2, 5), (33, 8), (1000, 24), (5000, 130), (20000, 512), (777, 33)])
+def test_float64_rows_keep_float64_statistics(am, n, d):
+    """The reference computes an add()'s statistics in the dtype of the embeddings it is given (data.py:39-44): float64 rows
+    (its own test embedder, the output of its PCA projection) must not pass through float32 on the way to mean / covariance.
+    am_stats_f64 against torch's f64 mean / cov on the device and against the CPU oracle fed the same f64 rows."""
+    import oracle
+    rng = np.random.default_rng(40 + n)
+    x = rng.standard_normal((n, d)) * 1.3 + 0.2 + 1e-9 * rng.standard_normal((n, d))      # (not representable in f32)
+    xd = torch.as_tensor(x).to("cuda:0")
+    mean, cov = am.hip_ops.stats_f64(xd)
+    want_mean = xd.mean(0)
+    want_cov = torch.cov(xd.T) if n > 1 else torch.zeros((d, d), dtype=torch.float64, device=xd.device)
+    scale = float(want_cov.abs().max()) if n > 1 else 1.0
+    assert float((mean - want_mean).abs().max()) <= 1e-13 * max(1.0, float(want_mean.abs().max()))
+    assert float((cov - want_cov.reshape(d, d)).abs().max()) <= 1e-12 * max(scale, 1e-30)
+    assert torch.equal(cov, cov.T)                                                      # exactly symmetric
+    # through the container, in 32-row adds like the pipeline's, against the oracle's dtype ladder on the same rows
+    a, o = am.AudioMetricsData(store_embeddings=False), oracle.OracleData(False)
+    for lo in range(0, n, 32):
+        a.add(xd[lo:lo + 32])
+        o.add(torch.as_tensor(x[lo:lo + 32]))
+    np.testing.assert_allclose(a.mean.cpu().numpy(), o.mean.numpy(), rtol=1e-12, atol=1e-13)
+    if n > 1:
+        np.testing.assert_allclose(a.cov.cpu().numpy(), o.cov.numpy(), rtol=1e-10, atol=1e-12 * scale)
+    # the f32 route on the same values is visibly coarser: the f64 route is not a relabelled narrowing
+    if n >= 1000:
+        m32, _ = am.hip_ops.stats(xd.to(torch.float32))
+        assert float((m32 - want_mean).abs().max()) > 50 * float((mean - want_mean).abs().max())
+
+
 @pytest.mark.parametrize("d,splits", [(512, [32] * 40), (21, [1, 7, 1, 32, 128, 3]), (128, [128, 5, 64]), (40, [1, 1, 1, 16])])
 def test_one_launch_add_matches_the_chain(am, d, splits):
     """am_stats_push_f32 (one launch per small add: batch statistics + Chan merge + row append, data.py:37-47, 68-94)
