@@ -344,7 +344,9 @@ int am_evaluate_f32(const float* ref, int64_t n_ref, int64_t ld_ref, const float
  * milliseconds, and resets that kernel's record.  Disabled by default; no cost when disabled.
  * am_knn_path / am_prdc_path tell which form the library picks for a shape (0 = exact general kernel,
  * 1 = exact symmetric kernel (k-NN only), 2 = f16 filter + exact verification on the 128 x 128 engine,
- * 3 = the same on the 256 x 256 f16 engine). */
+ * 3 = the same on the 256 x 256 f16 engine, 4 = row-at-a-time kernel for k > AM_MAX_K).  The choice is a pure function of
+ * the shapes; inside forms 2 / 3 the DATA can still hand a call to the exact kernels on the device (rows the f16 values
+ * cannot separate, queue overflow, operands that cannot be scaled into f16) - am_filter_stats_enable counts those. */
 enum am_clocked_kernel { AM_KERNEL_KNN = 0, AM_KERNEL_PRDC_CROSS = 1, AM_KERNEL_KNN_VERIFY = 2, AM_KERNEL_PRDC_VERIFY = 3 };
 int am_kernel_clock_enable(int on);
 int am_kernel_clock_read(int kernel, int64_t* launches, double* total_ms);

@@ -104,3 +104,29 @@ def test_rendered_batches_name_the_shapes_when_a_window_differs():
     source = WindowSource(_pairs(2, 40, np.float32), 16, 0.5, ragged, apa_mode="candidate", mix_workers=1)
     with pytest.raises(ValueError, match=r"\(8,\).*\(7,\)"):
         list(rendered_batches(source, batch_size=4, ring=6))
+
+
+def test_device_indices_follow_the_reference_rule(monkeypatch):
+    """util/gpu_parallel.py:24-28 + audio_metrics.py:276-279: None = every visible GPU, a non-empty list = exactly those, an
+    empty one = no replica handler (the embedder runs where it lives); no GPU at all = RuntimeError.  (Host logic: the
+    CUDA queries are replaced, nothing touches a device.)"""
+    import pytest
+    import torch
+    from audio_metrics_amd.audio_metrics import _visible_devices
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 2)
+    cuda = lambda i: torch.device("cuda", i)                                     # noqa: E731
+    assert _visible_devices(None) == [cuda(2), cuda(0), cuda(1), cuda(3)]         # the current device is the home of the statistics
+    assert _visible_devices([1, 3]) == [cuda(1), cuda(3)]
+    assert _visible_devices(()) == [cuda(2)]
+
+    class OnGpu3:
+        def get_device(self):
+            return torch.device("cuda", 3)
+    assert _visible_devices([], embedder=OnGpu3()) == [cuda(3)]
+    # one process per GPU: the launcher gave this rank its device
+    assert _visible_devices(None, one_process_per_gpu=True) == [cuda(2)]
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    with pytest.raises(RuntimeError, match="No GPUs found"):
+        _visible_devices(None)

@@ -41,6 +41,9 @@ def measure(n, d, k, world, dev):
     gen = torch.Generator(device="cuda").manual_seed(0)
     ref = torch.randn(n, d, generator=gen, device="cuda")
     cand = torch.randn(n, d, generator=gen, device="cuda") * 1.05 + 0.05
+    if os.environ.get("AB_DATA", "randn") == "clap":              # CLAP-shaped: unit-norm rows with offsets 0.5 / 0.55
+        ref, cand = ref + 0.5, (cand - 0.05) / 1.05 + 0.55
+        ref, cand = ref / ref.norm(dim=1, keepdim=True), cand / cand.norm(dim=1, keepdim=True)
     rows = n // world
     pre = {}
     for name, x in (("ref", ref), ("cand", cand)):
@@ -179,9 +182,9 @@ def simulate(seg, n, d, k, world, order, fabric):
 
 
 def main():
-    n, d, k = int(os.environ.get("AB_ROWS", "100000")), 512, 5
+    n, d, k = int(os.environ.get("AB_ROWS", "100000")), 512, int(os.environ.get("AB_K", "5"))
     dev = torch.device("cuda:0")
-    out = {"workload": f"bench.py: FAD+KD+PRDC(k={k}) cold evaluate of 2 x {n} x {d}", "measured_on": "ONE MI355X (rank 0 emulated)",
+    out = {"workload": f"bench.py: FAD+KD+PRDC(k={k}) cold evaluate of 2 x {n} x {d} ({os.environ.get('AB_DATA', 'randn')})", "measured_on": "ONE MI355X (rank 0 emulated)",
            "assumptions": {"xgmi_link_GBps_per_direction": LINK / 1e9, "links_per_gpu": 7, "collective_latency_us": LAT * 1e6,
                            "mesh": "all links at once at 70 % of the link rate", "ring": "one link per direction at 80 %"},
            "worlds": {}}
