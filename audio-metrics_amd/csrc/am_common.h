@@ -48,6 +48,13 @@ hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
 void clock_begin(int kernel, hipStream_t st);
 void clock_end(int kernel, hipStream_t st);
 
+// max(v, 0) of an EXACT squared distance, with a NaN turned into +inf.  In the reference a NaN distance - a row with a
+// non-finite element - stays NaN through torch.cdist's clamp_min(0) (prdc.py:12,34) and then never counts: torch.kthvalue sorts
+// NaN last, and NaN < radius is false.  +inf behaves the same way in every comparison of these kernels and, unlike NaN, is
+// safe in the min / max networks of the sorted lists (list_insert: fminf / fmaxf return their non-NaN operand, a NaN would
+// duplicate the list's smallest entry).  Plain fmaxf(v, 0) would put the pair at distance 0 from everybody.
+__device__ __forceinline__ float clamp0(float v) { return v != v ? __builtin_inff() : fmaxf(v, 0.f); }
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

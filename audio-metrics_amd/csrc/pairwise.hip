@@ -175,7 +175,7 @@ struct KnnEpilogue {
                 if (__any(tmin < best[nt][KCAP - 1])) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const float d2 = fmaxf(fmaf(dscale, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
+                        const float d2 = clamp0(fmaf(dscale, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]));
                         if (__any(d2 < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], d2);
                     }
                 }
@@ -356,7 +356,7 @@ struct KnnSymEpilogue {
                 if (!(ablate & 2) && __any(tmin < best[nt][KCAP - 1] && tmin <= flt[nt])) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const float d2 = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
+                        const float d2 = clamp0(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]));
                         const float v = d2 <= flt[nt] ? d2 : INFINITY;
                         if (__any(v < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], v);
                     }
@@ -365,7 +365,7 @@ struct KnnSymEpilogue {
                 if (mirror && __any(rowok[nt] && marg <= 0.f)) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const float d2 = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
+                        const float d2 = clamp0(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]));
                         if (rowok[nt] && d2 <= tq[reg >> 2][reg & 3])
                             push(jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3), d2);
                     }
@@ -576,10 +576,10 @@ __global__ void __launch_bounds__(256) knn_fixup_kernel(const float* __restrict_
             const int64_t j2 = j + 256;
             float da, db;
             dot(X + j * ld, j2 < N ? X + j2 * ld : nullptr, da, db);
-            const float d2a = fmaxf(fmaf(-2.f, da, xi + xnorm[j]), 0.f);
+            const float d2a = clamp0(fmaf(-2.f, da, xi + xnorm[j]));
             if (d2a < m[KCAP - 1]) list_insert<KCAP>(m, d2a);
             if (j2 < N) {
-                const float d2b = fmaxf(fmaf(-2.f, db, xi + xnorm[j2]), 0.f);
+                const float d2b = clamp0(fmaf(-2.f, db, xi + xnorm[j2]));
                 if (d2b < m[KCAP - 1]) list_insert<KCAP>(m, d2b);
             }
         }
@@ -647,7 +647,7 @@ struct CrossEpilogue {
                 float tmin = INFINITY;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const float d2 = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
+                    const float d2 = clamp0(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]));
                     tmin = fminf(tmin, d2);
                     // d2 - T < 0  <=>  d2 < T (IEEE subtraction never rounds across zero); NaN (inf - inf) is dropped
                     margin[nt] = fminf(margin[nt], d2 - tc[reg >> 2][reg & 3]);
@@ -657,7 +657,7 @@ struct CrossEpilogue {
                 if (__any(tmin < tr[nt])) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const float d2 = fmaxf(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]), 0.f);
+                        const float d2 = clamp0(fmaf(-2.f, acc[mt][nt][reg], xn[nt] + yn[reg >> 2][reg & 3]));
                         const unsigned long long mask = __ballot(d2 < tr[nt]);
                         if (mask != 0ull && L.lane == 0) {
                             const int64_t j = jbase + mt * 32 + (reg >> 2) * 8 + (reg & 3);
@@ -1162,7 +1162,7 @@ __global__ void __launch_bounds__(256) knn_rows_kernel(const float* __restrict__
                     a = fmaf(a1[s2], x1[s2], a);
                 }
             }
-            line[j] = fmaxf(fmaf(-2.f, a, xi + ynorm[j]), 0.f);
+            line[j] = clamp0(fmaf(-2.f, a, xi + ynorm[j]));
         }
         if (threadIdx.x == 0) { sel_prefix = 0u; sel_rank = (unsigned)(k1 - 1); }      // 0-based rank of the wanted value
         for (int shift = 24; shift >= 0; shift -= 8) {

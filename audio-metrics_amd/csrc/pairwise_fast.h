@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(256) cross_verify_regions_kernel(const float* 
         const unsigned i = v.x, j = v.y & ~FAST_COUNTED;
         const float acc = wave_pair_dot(R, ldr, C, ldc, i, j, D, tile, lane);
         if (valid) {
-            const float t = fmaxf(fmaf(-2.f, acc, rnorm[i] + cnorm[j]), 0.f);
+            const float t = clamp0(fmaf(-2.f, acc, rnorm[i] + cnorm[j]));
             float mn = INFINITY;
             bool any = false, cov = false;
             cross_apply(t, j, v.y, rthr[i], cthr, col_count, mn, any, cov);
@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(256) cross_verify_kernel(const float* __restri
             if (e < cnt) {
                 const unsigned jf = sorted[start[lr] + e];
                 const int64_t j = jf & ~FAST_COUNTED;
-                const float t = fmaxf(fmaf(-2.f, exact_pair_dot(xs, C + j * ldc, D), xi + cnorm[j]), 0.f);
+                const float t = clamp0(fmaf(-2.f, exact_pair_dot(xs, C + j * ldc, D), xi + cnorm[j]));
                 cross_apply(t, j, jf, ti, cthr, col_count, mn, any, cov);
             }
         }
@@ -639,7 +639,7 @@ __global__ void __launch_bounds__(256) cross_verify_overflow_kernel(const float*
                 acc = fmaf(y1[s], x1[s], acc);
             }
         }
-        const float t = fmaxf(fmaf(-2.f, acc, rnorm[i] + cnorm[j]), 0.f);
+        const float t = clamp0(fmaf(-2.f, acc, rnorm[i] + cnorm[j]));
         float mn = INFINITY;
         bool any = false, cov = false;
         cross_apply(t, j, v.y, rthr[i], cthr, col_count, mn, any, cov);
@@ -1129,7 +1129,7 @@ __global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __res
         const bool hole = p.x == FAST_HOLE;
         if (hole) p = make_uint2(0u, 0u);
         const float acc = wave_pair_dot(X, ld, X, ld, p.x, p.y, D, tile, lane);
-        if (!hole) knn_file(cand, cnt2, cap, p.x, fmaxf(fmaf(-2.f, acc, xnorm[p.x] + xnorm[p.y]), 0.f));
+        if (!hole) knn_file(cand, cnt2, cap, p.x, clamp0(fmaf(-2.f, acc, xnorm[p.x] + xnorm[p.y])));
     }
 }
 

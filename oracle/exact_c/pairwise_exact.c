@@ -12,7 +12,7 @@
  *   - <x,y>   : one fmaf chain in the index order 8c+0, 8c+4, 8c+1, 8c+5, 8c+2,
  *               8c+6, 8c+3, 8c+7 (c = 0,1,...)  (v_mfma_f32_32x32x2_f32 feeds,
  *               tile_engine.h);
- *   - d2      : max(fmaf(-2, <x,y>, |x|^2 + |y|^2), 0);
+ *   - d2      : max(fmaf(-2, <x,y>, |x|^2 + |y|^2), 0), a NaN becoming +inf;
  *   - radius  : sqrtf of the (k+1)-th smallest d2 of the row;
  *   - "d < R" : d2 < T(R), T(R) = smallest float t with sqrtf(t) >= R.
  * Build: gcc -O3 -mavx2 -mfma -ffp-contract=off -fopenmp -shared -fPIC (see Makefile).
@@ -81,7 +81,7 @@ static void d2_row(const float* x, float xn, int D, const float* Yt, const float
     }
     for (int64_t j = 0; j < M; ++j) {
         const float d2 = fmaf(-2.f, acc[j], xn + yn[j]);
-        acc[j] = d2 > 0.f ? d2 : 0.f;
+        acc[j] = d2 != d2 ? INFINITY : (d2 < 0.f ? 0.f : d2);   /* NaN (a non-finite row) -> +inf: like torch's NaN it never counts */
     }
 }
 

@@ -170,6 +170,37 @@ def test_knn_filter_gives_way_on_data_it_cannot_separate(am, n, d, k):
     assert stats["knn_fallback_rows"] == 0, stats
 
 
+def test_non_finite_rows_do_not_poison_the_finite_ones(am):
+    """One NaN row and one row with an infinite element in a set large enough for the f16 filter path (the scale of the f16 copy
+    cannot be derived from a non-finite maximum: the device-side checks must route the call to the exact kernel).  Like
+    torch.kthvalue in the reference (prdc.py:13), a NaN distance never counts among a row's k + 1 smallest: every finite row
+    keeps the radius it has in torch's own computation; nothing hangs, nothing is NaN that should not be."""
+    n, d, k = 9000, 128, 5
+    x = gi.randn(71, n, d)
+    x[123] = np.nan
+    x[4567, 7] = np.inf
+    assert am.hip_ops.knn_path(n, n, d, k) == 3
+    r = am.nearest_neighbour_distances(dev(x), k).cpu()
+    xt = torch.as_tensor(x)
+    want = torch.kthvalue(torch.cdist(xt, xt), k + 1, dim=-1)[0]
+    finite = torch.ones(n, dtype=torch.bool)
+    finite[123] = finite[4567] = False
+    assert torch.isfinite(r[finite]).all()
+    assert float((r[finite] - want[finite]).abs().max()) <= 3e-5 * float(want[finite].max())
+    # ... and the four PRDC values of (this set, a clean candidate set) equal the reference formulation's on the same rows
+    import oracle
+    y = gi.randn(72, n, d) * 1.05 + 0.05
+    a, b = am.AudioMetricsData(True), am.AudioMetricsData(True)
+    a.add(dev(x))
+    b.add(dev(y))
+    assert am.hip_ops.prdc_path(n, n, d) == 3
+    got = am.prdc(a, b, k)
+    oa, ob = oracle.OracleData(True).add(torch.as_tensor(x)), oracle.OracleData(True).add(torch.as_tensor(y))
+    want_prdc = oracle.prdc(oa, ob, k)
+    for key, w in want_prdc.items():
+        assert abs(got[key] - w) <= max(1e-4 * abs(w), 2.0 / n), (key, got[key], w)
+
+
 def test_knn_rows_vs_other_columns(am):
     """row shard against a larger column set (the multi-GPU calling pattern)."""
     from oracle import exact
