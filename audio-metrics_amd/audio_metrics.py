@@ -228,9 +228,10 @@ class AudioMetrics:
                 "mix_projection", ["mix_reference", "mix_anti_reference"], cand, False)
         if self._group is not None:
             return self._evaluate_sharded(sets)
-        result = self._run_fused(sets) or {}
+        fused = self._run_fused(sets)                  # None: the one-call form does not apply - every metric runs on its own
+        result = dict(fused) if fused is not None else {}
         for key, run in METRIC_TABLE:
-            if key in self.metrics and not (result and key in FUSED_METRICS):
+            if key in self.metrics and not (fused is not None and key in FUSED_METRICS):
                 result.update(run(self, sets))
         return result
 

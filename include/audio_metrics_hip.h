@@ -183,10 +183,13 @@ int am_kd_rbf_f32(const float* X, int64_t N1, int64_t ldx,
  *   Distances follow torch.cdist's matmul form  sqrt(max(|x|^2+|y|^2-2x.y, 0))
  *   in f32; no N x M matrix is materialised.  1 <= k, k+1 <= M (k > AM_MAX_K: one row at a time on the vector ALUs,
  *   same values; a correctness path - the reference's evaluate() caps k at 10).
- *   Y == X with >= 6144 rows (D >= 256) / 8192 rows (128 <= D < 256) / 16384 rows (32 <= D < 128), D <= 4096, runs as a scaled-f16 MFMA FILTER sweep over half of the tile pairs
+ *   Y == X with >= 6144 rows (D >= 256) / 8192 rows (128 <= D < 256) / 12000 rows (32 <= D < 128), D <= 4096, runs as a scaled-f16 MFMA FILTER sweep over half of the tile pairs
  *   followed by an f32 evaluation - with the arithmetic of the exact kernel - of the pairs its error bound cannot
  *   rule out (csrc/pairwise_fast.h): the radii are bit-identical to the exact kernels', which remain the path for
- *   the other shapes and the automatic per-row fallback.
+ *   the other shapes and the automatic fallback - per row (a row whose buffers overflowed), or for the whole call when
+ *   device-side checks find that the f16 values cannot separate the rows' neighbours (tightly clustered data) or that the
+ *   operands cannot be scaled into f16 (non-finite values).  A row with a non-finite element is nobody's neighbour (its
+ *   distances count as +inf, where torch carries NaN); its own radius is +inf.
  * ------------------------------------------------------------------------- */
 size_t am_knn_workspace_bytes(int64_t N, int64_t M, int D, int k);
 int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx,
@@ -262,7 +265,8 @@ int am_prdc_counts_prepared_f32(const float* R, int64_t Nr, int64_t ldr, const a
  *   Outputs are OVERWRITTEN.  am_prdc_reduce turns the first three into the four integer totals
  *   { #cols with count>0, #rows with any, sum of counts, #rows covered } (device int64[4]); the caller
  *   divides in f64.
- *   Large problems run as a scaled-f16 MFMA FILTER pass that queues every pair whose membership its error bound
+ *   Large problems (Nr * Nc >= 2^24 pairs for D >= 256, 2^26 for 128 <= D < 256, 1e8 for 32 <= D < 128; D <= 4096) run as a
+ *   scaled-f16 MFMA FILTER pass that queues every pair whose membership its error bound
  *   cannot decide, followed by an f32 evaluation of exactly those pairs with the arithmetic of the exact
  *   kernel (csrc/pairwise_fast.h): the outputs are bit-identical to the exact kernel's, which remains the
  *   path for small problems and the automatic fallback.  Asking for out_row_min adds the candidates of the

@@ -152,3 +152,44 @@ def test_save_load_state_roundtrip(am, tmp_path):
     m2.reset_reference()
     with pytest.raises(ValueError):
         m2.evaluate(cand)
+
+
+def test_stale_radius_cache_after_a_second_add_reference_is_an_error_not_a_wild_read(am):
+    """The reference never invalidates the radii cache on append (data.py:60-66 vs 68-72): after add_reference(A); evaluate();
+    add_reference(B) the stem reference holds radii of len(A) rows beside len(A) + len(B) rows, and its prdc() fails on the
+    broadcast.  Here the fused one-call evaluate hands raw pointers to the library: it must NOT reuse such a cache (an
+    out-of-bounds device read) - the call falls back to the per-metric path, which raises the shape error."""
+    ref, cand = data(stems_only=True)
+    m = make(am, ["fad", "prdc"])
+    m.add_reference(ref)
+    first = m.evaluate(cand)
+    assert set(first) == {"fad", "precision", "recall", "density", "coverage"}
+    k = min(10, len(m.stem_reference))
+    assert m.stem_reference.radii["radii_%d" % k].numel() == m.stem_reference.embeddings.shape[0]
+    c = gi.E2E
+    m.add_reference([x[:, 1] for x in gi.e2e_pairs(c["seed"] + 2, 30, c["seconds"], c["sr"])])
+    assert m.stem_reference.embeddings.shape[0] > m.stem_reference.radii["radii_%d" % k].numel()
+    with pytest.raises(ValueError, match="radius / embedding shapes do not match"):
+        m.evaluate(cand)
+    # the library-level guard of the one-call form
+    from audio_metrics_amd import hip_ops as ops
+    rows = m.stem_reference.embeddings
+    with pytest.raises(ValueError, match="radius / embedding shapes do not match"):
+        ops.evaluate(rows, rows, ("fad", "prdc"), 5, given_ref={"radii": torch.zeros(7, dtype=torch.float32, device=rows.device)})
+    with pytest.raises(ValueError, match="has shape"):
+        ops.evaluate(rows, rows, ("fad", "prdc"), 5, given_ref={"mean": torch.zeros(3, dtype=torch.float64, device=rows.device)})
+
+
+def test_a_mixer_that_changes_the_dtype_runs_through_the_pipeline(am):
+    """A callable mix function returning float64 for float32 windows (what a pyloudnorm-style mixer does) used to abort
+    add_reference with an exception without a message; the batch ring now takes the dtype of the mixed window."""
+    ref, cand = data()
+    results = []
+    for mix in (gi.e2e_mix, lambda audio, sr=None: gi.e2e_mix(audio, sr).astype(np.float64)):
+        random.seed(9)
+        m = am.AudioMetrics(metrics=["fad", "apa"], embedder=gi.NumpyEmbedder(gi.E2E["dim"], gi.E2E["sr"]), mix_function=mix,
+                            win_dur=gi.E2E["win_dur"])
+        m.add_reference(ref)
+        results.append(m.evaluate(cand))
+    for key in results[0]:
+        assert abs(results[0][key] - results[1][key]) <= 1e-6 * max(1.0, abs(results[0][key])), key
