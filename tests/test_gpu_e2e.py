@@ -193,3 +193,22 @@ def test_a_mixer_that_changes_the_dtype_runs_through_the_pipeline(am):
         results.append(m.evaluate(cand))
     for key in results[0]:
         assert abs(results[0][key] - results[1][key]) <= 1e-6 * max(1.0, abs(results[0][key])), key
+
+
+@pytest.mark.parametrize("metrics", [["fad"], ["kd"], ["prdc"], ["fad", "kd"], ["kd", "prdc"], ["fad", "prdc"], ["prdc", "fad", "kd"]])
+def test_every_metric_subset_gives_the_golden_values(am, golden, metrics):
+    """Whatever subset of the stem metrics is asked for - and whichever of them the one-call form covers - each requested
+    key comes back, in the reference's key order (audio_metrics.py:254-274), with the value of the reference's own run on
+    the same stems (golden `stems`, produced with all three)."""
+    g = golden("e2e")
+    m = make(am, metrics)
+    ref, cand = data(stems_only=True)
+    m.add_reference(ref)
+    res = m.evaluate(cand)
+    order = [k for k in (str(k) for k in g["stems/keys"])
+             if (k == "fad" and "fad" in metrics) or (k.startswith("kernel") and "kd" in metrics)
+             or (k in ("precision", "recall", "density", "coverage") and "prdc" in metrics)]
+    assert list(res) == order
+    for key, v in res.items():
+        want = float(g[f"stems/{key}"])
+        assert abs(v - want) <= tol(key, want), (key, v, want)

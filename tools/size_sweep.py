@@ -24,16 +24,20 @@ for d in dims:
         for k in ks:
             evaluate_sharded(ref, cand, nearest_k=k)
             torch.cuda.synchronize()
-            reps = 3 if n >= 32000 else 10
+            reps = 2 if n >= 150000 else 3 if n >= 32000 else 10
             t0 = time.perf_counter()
             for _ in range(reps):
                 evaluate_sharded(ref, cand, nearest_k=k)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / reps * 1e3
+            ops.filter_stats_enable(dev, True)
             t0 = time.perf_counter()
             for _ in range(reps):
                 evaluate_sharded(ref, cand, metrics=("prdc",), nearest_k=k)
             torch.cuda.synchronize()
             ms_prdc = (time.perf_counter() - t0) / reps * 1e3
+            st = ops.filter_stats_read(dev)
+            ops.filter_stats_enable(dev, False)
             print(f"N={n:7d} D={d:4d} k={k:2d}: evaluate {ms:8.3f} ms  prdc only {ms_prdc:8.3f} ms  ({3 * 2.0 * n * n * d / ms_prdc * 1e-9:7.1f} TF algorithmic)  "
-                  f"knn_path {ops.knn_path(n, n, d, k)} prdc_path {ops.prdc_path(n, n, d)}", flush=True)
+                  f"knn_path {ops.knn_path(n, n, d, k)} prdc_path {ops.prdc_path(n, n, d)}  queued/row {st['knn_queued'] / max(2 * reps * n, 1):6.1f} "
+                  f"fallback rows {st['knn_fallback_rows'] / reps:.0f} membership fallbacks {st['prdc_fallback_calls'] / reps:.0f}", flush=True)
