@@ -256,6 +256,10 @@ for name, rows, dim, k in (("small", 2500, 96, 4), ("partitioned", 33000, 128, 5
     out[f"{name}_stats"] = {"n": int(merged.n), "mean_diff": float((merged.mean - data.mean).abs().max()),
                             "cov_diff": float((merged.cov - data.cov).abs().max())}
     assert D.global_count(rows, dev) == rows
+    # the statistics the row-sharded PCA fit consumes (n_pca under a process group): two all-reduces over RCCL
+    n_g, mean_g, cov_g = D.global_stats(ref)
+    out[f"{name}_global_stats"] = {"n": int(n_g), "mean_diff": float((mean_g - data.mean).abs().max()),
+                                   "cov_diff": float((cov_g - data.cov).abs().max() / data.cov.abs().max())}
     D.COLLECTIVES_AT_WORLD_ONE = False
 torch.cuda.synchronize()
 dist.barrier()
@@ -278,6 +282,9 @@ def test_collectives_over_rccl_in_a_group_of_one():
     line = [l for l in res.stdout.splitlines() if l.startswith("RCCL1 ")][0]
     out = json.loads(line[len("RCCL1 "):])
     for name, rec in out.items():
+        if name.endswith("_global_stats"):
+            assert rec["n"] in (2500, 33000) and rec["mean_diff"] <= 1e-12 and rec["cov_diff"] <= 1e-9, (name, rec)
+            continue
         if name.endswith("_stats"):
             assert rec["n"] in (2500, 33000) and rec["mean_diff"] == 0.0 and rec["cov_diff"] == 0.0, (name, rec)
             continue
