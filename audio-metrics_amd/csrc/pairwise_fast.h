@@ -32,6 +32,7 @@ namespace am {
 
 constexpr int EV_FAST = EV_DEFAULT | EV_F16 | EV_LDS;       // 128-row engine, f16 operands, LDS-direct fills (no ds_write: the store path bounds the staged form)
 constexpr int FAST_MAX_DIM = 4096;                                            // fast_c's derivation holds up to here
+constexpr int FAST_MIN_DIM = 1;                                               // (32 until round 4: see knn_fast_enabled)
 // Mantissa bits dropped from the f16 copies (round to nearest even on the bit pattern, after the f32 -> f16 rounding):
 // the matrix cores draw less power on operands with fewer significant bits and the chip, which runs these kernels at its
 // power limit (1.8-1.9 GHz), clocks higher.  An element then carries |d| <= u = 2^-(11-n) + 2^-11 instead of 2^-11, and the
@@ -730,13 +731,13 @@ static bool cross_fast_enabled(int64_t Nr, int64_t Nc, int D) {
     static const int on = env_int("AM_PRDC_FAST", 1);
     // Where the membership filter starts to pay (round 4: tools/threshold_sweep.py on randn, unit-norm and clustered sets,
     // profiles/r4/threshold_sweep.txt): 2^24 pairs for D >= 256; for narrower rows the exact kernel's MFMA work shrinks with D
-    // while the filter's fixed passes do not - 2^26 pairs (8192^2) for 128 <= D < 256, 1e8 (10 000^2) below.  (Round 3 used
+    // while the filter's fixed passes do not - 2^26 pairs (8192^2) for 128 <= D < 256, 1e8 (10 000^2) for 32 <= D < 128, 2^28 (16 384^2) below.  (Round 3 used
     // 2^24 for every width: 0.05 - 0.08 ms too slow at 6 000 - 8 000 rows x 64 / 128.)
     static const int min_pairs_env = env_int("AM_FAST_MIN_PAIRS_LOG2", 0);
     const int64_t min_pairs_n = min_pairs_env > 0 ? ((int64_t)1 << min_pairs_env)
-                                                  : (D >= 256 ? (int64_t)1 << 24 : D >= 128 ? (int64_t)1 << 26 : (int64_t)100000000);
+                                                  : (D >= 256 ? (int64_t)1 << 24 : D >= 128 ? (int64_t)1 << 26 : D >= 32 ? (int64_t)100000000 : (int64_t)1 << 28);
     const size_t verify_lds = (size_t)(4 * ((D + 7) / 8 * 8) + 2048) * sizeof(float);
-    return on != 0 && D >= 32 && D <= FAST_MAX_DIM && verify_lds <= 60 * 1024 && Nr * Nc >= min_pairs_n &&
+    return on != 0 && D >= FAST_MIN_DIM && D <= FAST_MAX_DIM && verify_lds <= 60 * 1024 && Nr * Nc >= min_pairs_n &&
            Nr < ((int64_t)1 << 31) && Nc < ((int64_t)1 << 31);
 }
 
@@ -1174,8 +1175,8 @@ __global__ void knn_fast_select_kernel(const float* __restrict__ cand, const int
 // the prune step cannot drop them, and the exact verification touches hundreds of pairs per row (tools/threshold_sweep.py:
 // 50 clusters of width 1e-3, 20 000 x 512, k = 5: 283 ms against 7.5 ms for the exact kernels - 34 000 rows overflowed their
 // candidate buffers and went through the row-at-a-time fix-up).  Two device-side checks, no host round trip:
-//   A  after the sample pass: a row whose k+1 smallest SAMPLED values span less than the error band 2 E_i cannot be
-//      separated; if more than one row in eight is like that the sweep, scatter and prune kernels return at once;
+//   A  after the sample pass: a row whose smallest SAMPLED values (the whole list: 6 or 11) span less than the error band
+//      2 E_i cannot be separated; if more than one row in eight is like that the sweep, scatter and prune kernels return at once;
 //   B  after the prune step: more surviving pairs than 8 (k+1) + 16 per row, or more than N / 64 rows sent to the fix-up.
 // In either case verification, selection and fix-up return at once and the exact general kernel - always launched behind
 // them, like the exact membership kernel behind its filter - really runs.  Same outputs bit for bit either way (both are
@@ -1195,13 +1196,12 @@ __global__ void __launch_bounds__(256) knn_fast_predict_kernel(const float* __re
             const float* src = partial + ((int64_t)c * N + i) * KCAP;
             for (int s = 0; s < KCAP; ++s) list_insert<KCAP>(m, src[s]);
         }
-        float kth = m[0];
-#pragma unroll
-        for (int s = 1; s < KCAP; ++s)
-            if (s == k1 - 1) kth = m[s];
-        // (m[0] is the row's own column when the sample holds it - a zero; from m[1] on the values are neighbours either way:
-        // a span below the band means the band holds at least k - 1 sampled neighbours, 16 times as many in the whole row)
-        flat = kth < INFINITY && kth - m[k1 >= 3 ? 1 : 0] <= 2.f * fc * (xnorm[i] + __uint_as_float(maxn[0]));
+        // The WHOLE list, whatever k: m[0] is the row's own column when the sample holds it - a zero; from m[1] on the values
+        // are neighbours either way.  KCAP - 1 sampled neighbours inside one band means 16 times as many in the whole row.
+        // (The span up to the (k+1)-th value only - a single spacing of the order statistics for k = 2 - misfired on
+        // well-separated low-dimensional sets.)
+        (void)k1;
+        flat = m[KCAP - 1] < INFINITY && m[KCAP - 1] - m[1] <= 2.f * fc * (xnorm[i] + __uint_as_float(maxn[0]));
     }
     const unsigned long long b = __ballot(flat);
     if ((threadIdx.x & 63) == 0 && b != 0ull) atomicAdd(gate + 2, __popcll(b));
@@ -1232,8 +1232,12 @@ static bool knn_fast_enabled(int64_t N, int D) {
     // Narrow rows (32 <= D < 128: what n_pca leaves) were excluded altogether ("the saved MFMA work scales with D"): from
     // 16 384 rows the sweep wins there too - 8.3 -> 2.9 ms at 50 000 x 64, 29.2 -> 7.8 ms at 100 000 x 64, break-even at 16 000.
     static const int min_rows_env = env_int("AM_KNN_FAST_MIN_ROWS", 0);
-    const int64_t min_rows = min_rows_env > 0 ? min_rows_env : (D >= 256 ? 6144 : D >= 128 ? 8192 : 12000);   // (D < 128: 16384 until round 4)
-    return on != 0 && N >= min_rows && D >= 32 && D <= FAST_MAX_DIM && N < ((int64_t)1 << 31);
+    // D < 32 (round 4; what n_pca = 8 ... 24 leaves: the reference's own tests project to 8 - 10 components): excluded until
+    // then for no better reason than the 32-wide k-slab of the 128-row engine - the f16 copy pads a row to 64 elements anyway
+    // and the bound holds for any D.  25.7 -> 8.2 ms at 100 000 x 8, 7.2 -> 3.1 ms at 50 000 x 16, break-even at ~14 000 rows
+    // (profiles/r4/threshold_sweep_narrow.txt; bit-identical to the exact kernels on randn and unit-norm sets).
+    const int64_t min_rows = min_rows_env > 0 ? min_rows_env : (D >= 256 ? 6144 : D >= 128 ? 8192 : D >= 32 ? 12000 : 16384);
+    return on != 0 && N >= min_rows && D >= FAST_MIN_DIM && D <= FAST_MAX_DIM && N < ((int64_t)1 << 31);
 }
 
 struct KnnFastBuffers {           // on top of the symmetric path's KnnBuffers

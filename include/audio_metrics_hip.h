@@ -183,7 +183,7 @@ int am_kd_rbf_f32(const float* X, int64_t N1, int64_t ldx,
  *   Distances follow torch.cdist's matmul form  sqrt(max(|x|^2+|y|^2-2x.y, 0))
  *   in f32; no N x M matrix is materialised.  1 <= k, k+1 <= M (k > AM_MAX_K: one row at a time on the vector ALUs,
  *   same values; a correctness path - the reference's evaluate() caps k at 10).
- *   Y == X with >= 6144 rows (D >= 256) / 8192 rows (128 <= D < 256) / 12000 rows (32 <= D < 128), D <= 4096, runs as a scaled-f16 MFMA FILTER sweep over half of the tile pairs
+ *   Y == X with >= 6144 rows (D >= 256) / 8192 rows (128 <= D < 256) / 12000 rows (32 <= D < 128) / 16384 rows (D < 32), D <= 4096, runs as a scaled-f16 MFMA FILTER sweep over half of the tile pairs
  *   followed by an f32 evaluation - with the arithmetic of the exact kernel - of the pairs its error bound cannot
  *   rule out (csrc/pairwise_fast.h): the radii are bit-identical to the exact kernels', which remain the path for
  *   the other shapes and the automatic fallback - per row (a row whose buffers overflowed), or for the whole call when
@@ -265,7 +265,7 @@ int am_prdc_counts_prepared_f32(const float* R, int64_t Nr, int64_t ldr, const a
  *   Outputs are OVERWRITTEN.  am_prdc_reduce turns the first three into the four integer totals
  *   { #cols with count>0, #rows with any, sum of counts, #rows covered } (device int64[4]); the caller
  *   divides in f64.
- *   Large problems (Nr * Nc >= 2^24 pairs for D >= 256, 2^26 for 128 <= D < 256, 1e8 for 32 <= D < 128; D <= 4096) run as a
+ *   Large problems (Nr * Nc >= 2^24 pairs for D >= 256, 2^26 for 128 <= D < 256, 1e8 for 32 <= D < 128, 2^28 below; D <= 4096) run as a
  *   scaled-f16 MFMA FILTER pass that queues every pair whose membership its error bound
  *   cannot decide, followed by an f32 evaluation of exactly those pairs with the arithmetic of the exact
  *   kernel (csrc/pairwise_fast.h): the outputs are bit-identical to the exact kernel's, which remains the

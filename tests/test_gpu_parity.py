@@ -126,11 +126,12 @@ def test_knn_long_lists_on_mid_sized_sets_bit_exact(am, k):
 
 @pytest.mark.parametrize("n,d,k,kind", [(17000, 64, 5, "randn"), (12100, 40, 10, "randn"), (6200, 256, 5, "randn"),
                                         (8300, 130, 3, "randn"), (12100, 64, 5, "unit"), (6200, 512, 10, "unit"),
-                                        (8300, 128, 5, "unit")])
+                                        (8300, 128, 5, "unit"), (17000, 8, 5, "randn"), (16500, 24, 10, "unit"),
+                                        (16400, 12, 2, "randn")])
 def test_knn_filter_sweep_at_its_lower_thresholds_bit_exact(am, n, d, k, kind):
     """The f16 filter sweep + exact verification just above the row counts where it takes over (6144 rows for D >= 256,
-    8192 for 128 <= D < 256, 12 000 for the narrow rows n_pca leaves: round 4, tools/threshold_sweep.py on randn AND
-    unit-norm (CLAP-shaped) sets) - radii bit-identical to the C model of the exact arithmetic, no row falls back."""
+    8192 for 128 <= D < 256, 12 000 for 32 <= D < 128 and 16 384 below - the narrow rows n_pca leaves: round 4,
+    tools/threshold_sweep.py on randn AND unit-norm (CLAP-shaped) sets) - radii bit-identical to the C model of the exact arithmetic, no row falls back."""
     from oracle import exact
     ops = am.hip_ops
     x = gi.randn(66, n, d) if kind == "randn" else gi.unit_norm(66, n, d)
@@ -168,6 +169,23 @@ def test_knn_filter_gives_way_on_data_it_cannot_separate(am, n, d, k):
     stats = ops.filter_stats_read("cuda:0")
     ops.filter_stats_enable("cuda:0", False)
     assert stats["knn_fallback_rows"] == 0, stats
+
+
+def test_dense_low_dimensional_sets_take_the_exact_kernel_on_their_own(am):
+    """16 400 random points in THREE dimensions: neighbours are closer than the f16 error band (which scales with the squared
+    norms, not with the neighbour distances), so the filter cannot separate them - the shapes choose the filter path, the
+    device-side check hands the call to the exact kernel, the radii are the C model's bits."""
+    from oracle import exact
+    ops = am.hip_ops
+    n, d, k = 16400, 3, 2
+    x = gi.randn(66, n, d)
+    assert ops.knn_path(n, n, d, k) == 3
+    ops.filter_stats_enable("cuda:0", True)
+    r = am.nearest_neighbour_distances(dev(x), k).cpu().numpy()
+    stats = ops.filter_stats_read("cuda:0")
+    ops.filter_stats_enable("cuda:0", False)
+    assert stats["knn_fallback_rows"] == n, stats
+    assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, k).view(np.uint32))
 
 
 def test_non_finite_rows_do_not_poison_the_finite_ones(am):
