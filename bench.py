@@ -310,7 +310,7 @@ def main():
         torch.cuda.synchronize()
 
     if args.config == "e2e":
-        run_e2e(args, am, dev, world, rank, fence)
+        run_e2e(args, am, dev, world, rank, fence, n_ranks_seen)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -558,7 +558,7 @@ def per_step(stats, steps):
     return {key: value / steps for key, value in stats.items()}
 
 
-def run_e2e(args, am, dev, world, rank, fence):
+def run_e2e(args, am, dev, world, rank, fence, n_ranks_seen=1):
     """BASELINE configs[4] shape: (context, stem) audio pairs -> embedder forward on this rank's GPU -> device-side
     aggregation -> APA + FAD, one process per GPU with the statistics merged across ranks (distributed.merged_stats).
     The embedder is `SyntheticEmbedder` (LAION-CLAP and its checkpoint cannot be installed here) - a torch module with
@@ -643,7 +643,7 @@ def run_e2e(args, am, dev, world, rank, fence):
         windows = 2 * pairs                       # reference + candidate pairs, one 5 s window each
         print(json.dumps({
             "metric": "APA+FAD end-to-end pairs/sec (audio -> embedder -> device aggregation -> metrics)",
-            "value": windows / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": 1, "warmup": 0,
+            "value": windows / elapsed, "unit": "pairs/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": 1, "warmup": 0,
             "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"APA+FAD end-to-end, {pairs} reference + {pairs} candidate pairs of ({sr * seconds}, 2) f32 "
