@@ -507,8 +507,10 @@ __global__ void __launch_bounds__(256) cross_verify_regions_kernel(const float* 
                                                                    const int* __restrict__ wgq_count, const uint2* __restrict__ items,
                                                                    const int* __restrict__ item_count, int32_t* __restrict__ col_count,
                                                                    unsigned* __restrict__ row_min_bits,
-                                                                   unsigned* __restrict__ row_any, unsigned* __restrict__ row_cover) {
+                                                                   unsigned* __restrict__ row_any, unsigned* __restrict__ row_cover,
+                                                                   const int* __restrict__ fail) {
     extern __shared__ __attribute__((aligned(16))) float vlds[];
+    if (*fail) return;                                    // (the exact kernel takes the whole call: cross_fast_decide_kernel)
     const int nitems = *item_count;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* tile = vlds + wave * 128 * VERIFY_LD;
@@ -648,6 +650,22 @@ __global__ void __launch_bounds__(256) cross_verify_overflow_kernel(const float*
         if (any) atomicOr(row_any + i, 1u);
         if (cov) atomicOr(row_cover + i, 1u);
     }
+}
+
+// Data-dependent fallback of the membership filter (round 4), the counterpart of check B of the k-NN filter: when the filter
+// pass has queued more pairs than an exact verification is worth - both sets drawn around the SAME tight clusters: every
+// candidate of a reference row's cluster lies inside the error band of that row's radius, 400 undecidable pairs per row at
+// 20 000 rows, most of them through the one-pair-per-thread overflow path: 96 ms against 7.6 ms for the exact kernel at
+// 20 000 x 512, 90 against 2 ms at 20 000 x 64 (tools/threshold_sweep.py, data family `shared`) - the fail flag is raised, the
+// verification kernels return at once and the exact kernel, always launched behind, really runs.  An exactly verified pair
+// costs about as much as 80 pairs of the exact kernel and the filter pass itself an eighth of it: the limit is 1 / 128 of all
+// pairs, or more entries in the overflow queue than its slow path should see.
+__global__ void cross_fast_decide_kernel(const int* __restrict__ ov_count, int ovcap, int* __restrict__ fail, long long limit_total,
+                                         int limit_overflow) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int spilled = ov_count[0] < ovcap ? ov_count[0] : ovcap;
+    const long long total = (long long)ov_count[2] * 64 + spilled;           // (regions are listed in batches of 64 entries)
+    if (total > limit_total || ov_count[0] > limit_overflow) *fail = 1;
 }
 
 // Both queues overflowed (pathological inputs: e.g. one huge cluster of duplicates): wipe the accumulators so the
@@ -801,16 +819,23 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
     AM_LAUNCH_CHECK();
     unsigned* rmin_or_null = want_min ? rmin : nullptr;
     if (p.wide) {
+        // budgets of the data-dependent fallback (cross_fast_decide_kernel).  The overflow queue's budget is enforced INSIDE
+        // the filter pass: entries past it raise the fail flag at once and the workgroups not yet started return at their
+        // first instruction - on inputs the bound cannot decide most of the pass's time went into those entries
+        const long long pairs = (long long)Nr * (long long)Nc;
+        const long long limit_total = std::max<long long>(pairs / 128, 65536);
+        const int limit_overflow = (int)std::min<long long>(std::max<long long>(pairs >> 14, 65536), p.ovcap);
         clock_begin(AM_KERNEL_PRDC_CROSS, st);
         if ((rc = launch_cross_wide(want_min, (unsigned)p.blocks, Rb, Nr, ldb / 2, rn, rt, Cb, Nc, ldb / 2, cn, ct, Dh, p.nchunks,
                                     p.grp_rows, b.maxn, b.rmin_approx, rany, rcov, col_count, b.wgq, p.qcap, b.wgq_count, b.items,
-                                    b.ovq, b.ov_count, p.ovcap, fail, fast_c(D), st)) != AM_OK)
+                                    b.ovq, b.ov_count, limit_overflow, fail, fast_c(D), st)) != AM_OK)
             return rc;
         clock_end(AM_KERNEL_PRDC_CROSS, st);
+        hipLaunchKernelGGL(cross_fast_decide_kernel, dim3(1), dim3(64), 0, st, b.ov_count, p.ovcap, fail, limit_total, limit_overflow);
         clock_begin(AM_KERNEL_PRDC_VERIFY, st);
         AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&cross_verify_regions_kernel), (int)VERIFY_LDS_BYTES));
         hipLaunchKernelGGL(cross_verify_regions_kernel, dim3(CROSS_VERIFY_GRID), dim3(256), VERIFY_LDS_BYTES, st, R, ldr, rn, rt, C, ldc,
-                           cn, ct, D, b.wgq, p.qcap, b.wgq_count, b.items, b.ov_count + 2, col_count, rmin_or_null, rany, rcov);
+                           cn, ct, D, b.wgq, p.qcap, b.wgq_count, b.items, b.ov_count + 2, col_count, rmin_or_null, rany, rcov, fail);
         clock_end(AM_KERNEL_PRDC_VERIFY, st);
     } else {
         clock_begin(AM_KERNEL_PRDC_CROSS, st);

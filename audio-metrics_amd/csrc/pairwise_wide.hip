@@ -243,7 +243,9 @@ cross_wide_kernel(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const f
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const WLane L;
     const WideWork w = wide_work((Nc + WTB - 1) / WTB, nchunks, (Nr + WTB - 1) / WTB, grp_rows);
-    if (w.ntiles == 0) {
+    // (fail already raised - by an earlier workgroup whose entries no longer fit the overflow queue's budget, see
+    // cross_fast_decide_kernel: the exact kernel will redo the whole call, the rest of this grid has nothing to add)
+    if (w.ntiles == 0 || *reinterpret_cast<volatile int*>(fail) != 0) {
         if (L.tid == 0) wgq_count[blockIdx.x] = 0;
         return;
     }
