@@ -32,11 +32,12 @@ def child(kind, dim):
     from audio_metrics_amd import hip_ops as ops
     ops.filter_stats_enable("cuda:0", True)
     for n in ROWS:
-        if kind == "shared":                                  # both sets around the SAME 50 tight clusters
+        if kind.startswith("shared"):                         # both sets around the SAME 50 clusters; "shared:0.03" sets their spread
+            spread = float(kind.split(":")[1]) if ":" in kind else 1e-3
             gen = torch.Generator(device="cuda").manual_seed(5)
             centres = torch.randn(50, dim, generator=gen, device="cuda")
-            ref = centres[torch.randint(0, 50, (n,), generator=gen, device="cuda")] + 1e-3 * torch.randn(n, dim, generator=gen, device="cuda")
-            cand = centres[torch.randint(0, 50, (n,), generator=gen, device="cuda")] + 1e-3 * torch.randn(n, dim, generator=gen, device="cuda")
+            ref = centres[torch.randint(0, 50, (n,), generator=gen, device="cuda")] + spread * torch.randn(n, dim, generator=gen, device="cuda")
+            cand = centres[torch.randint(0, 50, (n,), generator=gen, device="cuda")] + spread * torch.randn(n, dim, generator=gen, device="cuda")
         else:
             ref, cand = make(kind, n, dim, 11), make(kind, n, dim, 12)
         if kind == "randn":
