@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(ENGINE_THREADS, 2)
 knn_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ldx, const float* __restrict__ xnorm,
                    const float* __restrict__ Y, int64_t M, int64_t ldy, const float* __restrict__ ynorm,
                    int D, int nchunks, int qstride, float* __restrict__ partial, const unsigned* __restrict__ half_scale,
-                   const int* __restrict__ run_flag) {
+                   const int* __restrict__ run_flag, const int* __restrict__ active_rows, int min_active) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (launched behind the f16 filter path as its data-dependent fallback: returns at once unless that path gave up)
     if (run_flag != nullptr && *run_flag == 0) return;
@@ -198,6 +198,9 @@ knn_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ldx, const fl
     // qstride > 1: only every qstride-th column tile is visited (cheap upper bounds for the symmetric kernel)
     const int64_t q_tiles = ((M + TB - 1) / TB + qstride - 1) / qstride;
     const WorkItem w = work_item(q_tiles, nchunks);
+    // (batched fix-up of the filter path: X holds *active_rows gathered rows - a device-side count -, the grid was sized for the
+    // buffer's capacity; nothing to do for fewer than min_active rows, which take the row-at-a-time kernel)
+    if (active_rows != nullptr && (*active_rows < min_active || w.prow0 >= *active_rows)) return;
 
     KnnEpilogue<KCAP> epi(L);
     epi.qnorm = ynorm;
@@ -252,9 +255,11 @@ knn_partial_kernel(const float* __restrict__ X, int64_t N, int64_t ldx, const fl
 // radius[i] = sqrt_rn( (k+1)-th smallest d2 over all chunks )
 template <int KCAP>
 __global__ void knn_merge_kernel(const float* __restrict__ partial, int64_t N, int nchunks, int k1, int squared,
-                                 float* __restrict__ radii, const int* __restrict__ run_flag) {
+                                 float* __restrict__ radii, const int* __restrict__ run_flag,
+                                 const int* __restrict__ active_rows = nullptr, int min_active = 0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N || (run_flag != nullptr && *run_flag == 0)) return;
+    if (active_rows != nullptr && (*active_rows < min_active || i >= *active_rows)) return;
     float m[KCAP];
 #pragma unroll
     for (int s = 0; s < KCAP; ++s) m[s] = partial[i * KCAP + s];
@@ -542,10 +547,13 @@ template <int KCAP>
 __global__ void __launch_bounds__(256) knn_fixup_kernel(const float* __restrict__ X, int64_t N, int64_t ld,
                                                         const float* __restrict__ xnorm, int D, int k1,
                                                         const int* __restrict__ ov_list, const int* __restrict__ ov_count,
-                                                        float* __restrict__ radii) {
+                                                        float* __restrict__ radii, int batched_from, int batched_cap) {
     extern __shared__ __attribute__((aligned(16))) float xrow[];      // D padded to a multiple of 32
     __shared__ float lists[256 * KCAP];
     const int n_ov = *ov_count;
+    // batched_from > 0 (filter path): lists of batched_from rows or more are recomputed by the general MFMA kernel on a gathered
+    // copy (knn_gather_rows_kernel), up to batched_cap rows - this kernel keeps the short lists and whatever exceeds the copy
+    const int first_row = (batched_from > 0 && n_ov >= batched_from) ? (n_ov < batched_cap ? n_ov : batched_cap) : 0;
     const int dp = (D + 31) / 32 * 32;
     auto dot = [&](const float* __restrict__ ya, const float* __restrict__ yb, float& da, float& db) {
         float a = 0.f, b = 0.f;
@@ -564,7 +572,7 @@ __global__ void __launch_bounds__(256) knn_fixup_kernel(const float* __restrict_
         da = a;
         db = b;
     };
-    for (int ov = blockIdx.x; ov < n_ov; ov += gridDim.x) {
+    for (int ov = first_row + blockIdx.x; ov < n_ov; ov += gridDim.x) {
         const int64_t i = ov_list[ov];
         for (int k = threadIdx.x; k < dp; k += 256) xrow[k] = k < D ? X[i * ld + k] : 0.f;
         __syncthreads();
@@ -814,15 +822,17 @@ static int launch_norms(const float* X, int64_t N, int64_t ld, int D, float* out
 template <int KCAP, int V, bool KTAIL>
 static int launch_knn_vt(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
                          const float* yn, int D, int nchunks, int qstride, float* partial, hipStream_t st,
-                         const unsigned* half_scale = nullptr, const int* run_flag = nullptr) {
+                         const unsigned* half_scale = nullptr, const int* run_flag = nullptr, const int* active_rows = nullptr,
+                         int min_active = 0) {
     {
         AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_partial_kernel<KCAP, V, KTAIL>), (int)PAIRWISE_LDS_BYTES));
     }
     const int64_t blocks = ceil_div(N, TB) * nchunks;
-    const bool clocked = qstride == 1 && run_flag == nullptr;   // main pass only; qstride > 1 is the sampled pre-pass
+    const bool clocked = qstride == 1 && run_flag == nullptr && active_rows == nullptr;   // main pass only; qstride > 1 is the sampled pre-pass
     if (clocked) clock_begin(AM_KERNEL_KNN, st);
     hipLaunchKernelGGL((knn_partial_kernel<KCAP, V, KTAIL>), dim3((unsigned)blocks), dim3(ENGINE_THREADS),
-                       PAIRWISE_LDS_BYTES, st, X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, half_scale, run_flag);
+                       PAIRWISE_LDS_BYTES, st, X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, half_scale, run_flag,
+                       active_rows, min_active);
     if (clocked) clock_end(AM_KERNEL_KNN, st);
     AM_LAUNCH_CHECK();
     return AM_OK;
@@ -831,25 +841,29 @@ static int launch_knn_vt(const float* X, int64_t N, int64_t ldx, const float* xn
 template <int KCAP, int V>
 static int launch_knn_v(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
                         const float* yn, int D, int nchunks, int qstride, float* partial, hipStream_t st,
-                        const int* run_flag = nullptr) {
+                        const int* run_flag = nullptr, const int* active_rows = nullptr, int min_active = 0) {
     // the inner-dimension tail (D % 32 != 0) is a separate instantiation so the common kernel carries no tail code
     if constexpr ((V & EV_EARLY) != 0) {
         if ((D % BK) != 0)
-            return launch_knn_vt<KCAP, V, true>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st, nullptr, run_flag);
+            return launch_knn_vt<KCAP, V, true>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st, nullptr, run_flag,
+                                                active_rows, min_active);
     }
-    return launch_knn_vt<KCAP, V, false>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st, nullptr, run_flag);
+    return launch_knn_vt<KCAP, V, false>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st, nullptr, run_flag,
+                                         active_rows, min_active);
 }
 
 template <int KCAP>
 static int launch_knn(const float* X, int64_t N, int64_t ldx, const float* xn, const float* Y, int64_t M, int64_t ldy,
                       const float* yn, int D, int k1, int nchunks, int qstride, bool squared, float* partial,
-                      float* out_r, hipStream_t st, const int* run_flag = nullptr) {
+                      float* out_r, hipStream_t st, const int* run_flag = nullptr, const int* active_rows = nullptr,
+                      int min_active = 0) {
     int rc;
-    if (run_flag != nullptr) {                       // the gated fallback of the filter path: production schedule only
-        rc = launch_knn_v<KCAP, EV_DEFAULT>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st, run_flag);
+    if (run_flag != nullptr || active_rows != nullptr) {   // gated forms behind the filter path: production schedule only
+        rc = launch_knn_v<KCAP, EV_DEFAULT>(X, N, ldx, xn, Y, M, ldy, yn, D, nchunks, qstride, partial, st, run_flag, active_rows,
+                                            min_active);
         if (rc != AM_OK) return rc;
         hipLaunchKernelGGL(knn_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st,
-                           partial, N, nchunks, k1, squared ? 1 : 0, out_r, run_flag);
+                           partial, N, nchunks, k1, squared ? 1 : 0, out_r, run_flag, active_rows, min_active);
         AM_LAUNCH_CHECK();
         return AM_OK;
     }
@@ -903,7 +917,7 @@ static int launch_knn_sym(const float* X, int64_t N, int64_t ld, const float* xn
     AM_LAUNCH_CHECK();
     if (out_lists != nullptr) return AM_OK;            // partitioned form: fix-up happens after the lists are merged
     hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
-                       xn, D, k1, ov_list, ov_count, out_r);
+                       xn, D, k1, ov_list, ov_count, out_r, 0, 0);
     AM_LAUNCH_CHECK();
     return AM_OK;
 }
@@ -1472,7 +1486,7 @@ static int run_lists_finish(const float* lists, int nparts, const float* X, int6
                        out_r, ov_list, ov_count);
     AM_LAUNCH_CHECK();
     hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
-                       xn, D, k1, ov_list, ov_count, out_r);
+                       xn, D, k1, ov_list, ov_count, out_r, 0, 0);
     AM_LAUNCH_CHECK();
     return AM_OK;
 }

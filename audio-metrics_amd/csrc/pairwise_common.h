@@ -137,6 +137,11 @@ static __constant__ unsigned long long* g_wide_trace;
 static __constant__ int g_wide_trace_b0;                      // AM_WIDE_TRACE_B0: first traced workgroup
 #endif
 
+// false for a row that knn_fast_mask_flat_kernel took out of the sweep (bound -inf, set before the sweep starts)
+__device__ __forceinline__ bool epi_row_in_sweep(const float* thr, int64_t i) {
+    return __hip_atomic_load(thr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > -INFINITY;
+}
+
 constexpr unsigned FAST_COUNTED = 0x80000000u;                               // membership queue entry: the pair was already counted as certain
 constexpr unsigned FAST_BOTH = 0x80000000u;
 constexpr int FAST_ROW_OVERFLOW = 0x40000000;                                 // OR-ed into a row's entry count: > any cap, and the

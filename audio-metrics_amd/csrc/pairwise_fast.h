@@ -720,6 +720,11 @@ static CrossFastPlan plan_cross_fast(int64_t Nr, int64_t Nc) {
     static const int qcap = std::min(env_int("AM_FAST_QCAP", 2048), 2048);       // cross_verify_kernel: <= 256 * 8
     static const int ovcap = env_int("AM_FAST_OVCAP", 1 << 22);
     p.qcap = qcap;
+    // The 256-row engine's regions are verified in batches of 64 (no limit from a sort in LDS): twice the size, so that a
+    // few candidate columns that EVERY reference row has to look at exactly - a block of identical low-norm rows, silence in
+    // a stem dataset, is everybody's nearest neighbour at one and the same distance - stay in the regions (coalesced
+    // verification) instead of spilling into the one-pair-per-thread overflow path (tools/dups_probe.py)
+    if (p.wide && env_int("AM_FAST_QCAP", 0) == 0) p.qcap = 4096;
     p.ovcap = ovcap;
     return p;
 }
@@ -822,9 +827,11 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
         // budgets of the data-dependent fallback (cross_fast_decide_kernel).  The overflow queue's budget is enforced INSIDE
         // the filter pass: entries past it raise the fail flag at once and the workgroups not yet started return at their
         // first instruction - on inputs the bound cannot decide most of the pass's time went into those entries
+        // (an overflow-queue entry costs ~20 ns in its one-pair-per-thread kernel, a pair of the exact kernel 2 D / 140 TF:
+        // the budget is what costs a quarter of the exact kernel's time)
         const long long pairs = (long long)Nr * (long long)Nc;
         const long long limit_total = std::max<long long>(pairs / 128, 65536);
-        const int limit_overflow = (int)std::min<long long>(std::max<long long>(pairs >> 14, 65536), p.ovcap);
+        const int limit_overflow = (int)std::min<long long>(std::max<long long>((pairs >> 22) * D, 65536), p.ovcap);
         clock_begin(AM_KERNEL_PRDC_CROSS, st);
         if ((rc = launch_cross_wide(want_min, (unsigned)p.blocks, Rb, Nr, ldb / 2, rn, rt, Cb, Nc, ldb / 2, cn, ct, Dh, p.nchunks,
                                     p.grp_rows, b.maxn, b.rmin_approx, rany, rcov, col_count, b.wgq, p.qcap, b.wgq_count, b.items,
@@ -1001,7 +1008,8 @@ knn_fast_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
             for (int s = 0; s < KCAP; ++s) __hip_atomic_store(out + s, m[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float kthv = m[KCAP - 1];
             const float bound = kthv + 2.f * fc * (xnorm[i] + nmax);     // >= 0, so its bit pattern orders like the value
-            atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
+            // (a row taken out of the sweep keeps its -inf: knn_fast_mask_flat_kernel; nobody else writes thr[i])
+            if (epi_row_in_sweep(thr, i)) atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
         }
     }
 }
@@ -1194,6 +1202,36 @@ __global__ void knn_fast_select_kernel(const float* __restrict__ cand, const int
     radii[i] = sqrt_rn(r2);
 }
 
+// ---- batched fix-up (round 4) -----------------------------------------------------------------------------------------
+// Rows whose candidate buffers overflowed - a block of identical rows larger than the buffer: every one of them has all the
+// others at distance zero; silent windows of a stem dataset embed to the same vector - were recomputed one row at a time on
+// the vector ALUs (knn_fixup_kernel: 42 us per row at 100 000 x 512; 500 duplicates = 21 ms, 1000 = 42 ms, beside a 7 ms
+// call).  From KNN_FIX_BATCH_FROM rows on they are gathered into a contiguous copy and go through the exact GENERAL kernel
+// on the matrix cores (rows of the copy against all columns: 0.75 us per row), the radii are scattered back; same values bit
+// for bit (the general kernel is the exact arithmetic).  The list is a device-side count: the grids are sized for the
+// copy's capacity (N / 8 rows; more overflowed rows than that send the whole call to the exact kernel, check B) and the
+// workgroups past the count return at once.
+__global__ void __launch_bounds__(256) knn_gather_rows_kernel(const float* __restrict__ X, int64_t ld, int D, const float* __restrict__ xnorm,
+                                                              const int* __restrict__ ov_list, const int* __restrict__ ov_count,
+                                                              int batched_from, int capacity, float* __restrict__ rows, int64_t ldr,
+                                                              float* __restrict__ norms) {
+    const int n = *ov_count < capacity ? *ov_count : capacity;
+    if (*ov_count < batched_from) return;
+    for (int r = blockIdx.x; r < n; r += gridDim.x) {
+        const int64_t src = ov_list[r];
+        for (int c = threadIdx.x; c < (int)ldr; c += 256) rows[(int64_t)r * ldr + c] = c < D ? X[src * ld + c] : 0.f;
+        if (threadIdx.x == 0) norms[r] = xnorm[src];
+    }
+}
+
+__global__ void __launch_bounds__(256) knn_scatter_radii_kernel(const float* __restrict__ radii_of_copy, const int* __restrict__ ov_list,
+                                                                const int* __restrict__ ov_count, int batched_from, int capacity,
+                                                                float* __restrict__ radii) {
+    const int n = *ov_count < capacity ? *ov_count : capacity;
+    if (*ov_count < batched_from) return;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) radii[ov_list[r]] = radii_of_copy[r];
+}
+
 // ---- data-dependent fallback of the k-NN filter path (round 4) -----------------------------------------------------
 // The filter pays when the f16 values SEPARATE a row's nearest neighbours from the rest.  On tightly clustered data they
 // do not: every member of a row's cluster lies inside the error band of its (k+1)-th neighbour, the queues keep them all,
@@ -1202,7 +1240,8 @@ __global__ void knn_fast_select_kernel(const float* __restrict__ cand, const int
 // candidate buffers and went through the row-at-a-time fix-up).  Two device-side checks, no host round trip:
 //   A  after the sample pass: a row whose smallest SAMPLED values (the whole list: 6 or 11) span less than the error band
 //      2 E_i cannot be separated; if more than one row in eight is like that the sweep, scatter and prune kernels return at once;
-//   B  after the prune step: more surviving pairs than 8 (k+1) + 16 per row, or more than N / 64 rows sent to the fix-up.
+//   B  after the prune step: more surviving pairs than max(8 (k+1) + 16, N / 160) per row, or more than N / 8 rows sent to
+//      the fix-up.
 // In either case verification, selection and fix-up return at once and the exact general kernel - always launched behind
 // them, like the exact membership kernel behind its filter - really runs.  Same outputs bit for bit either way (both are
 // the exact kernels' values); the checks only choose the cheaper route.  Single-GPU form only: the partitioned entry points
@@ -1210,7 +1249,7 @@ __global__ void knn_fast_select_kernel(const float* __restrict__ cand, const int
 template <int KCAP>
 __global__ void __launch_bounds__(256) knn_fast_predict_kernel(const float* __restrict__ partial, int64_t N, int nchunks, int k1,
                                                                const float* __restrict__ xnorm, const unsigned* __restrict__ maxn,
-                                                               float fc, int* __restrict__ gate) {
+                                                               float fc, int* __restrict__ gate, unsigned char* __restrict__ flat_rows) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool flat = false;
     if (i < N) {
@@ -1226,10 +1265,31 @@ __global__ void __launch_bounds__(256) knn_fast_predict_kernel(const float* __re
         // (The span up to the (k+1)-th value only - a single spacing of the order statistics for k = 2 - misfired on
         // well-separated low-dimensional sets.)
         (void)k1;
-        flat = m[KCAP - 1] < INFINITY && m[KCAP - 1] - m[1] <= 2.f * fc * (xnorm[i] + __uint_as_float(maxn[0]));
+        const float band = 2.f * fc * (xnorm[i] + __uint_as_float(maxn[0]));
+        flat = m[KCAP - 1] < INFINITY && m[KCAP - 1] - m[1] <= band;
+        // The per-row verdict (knn_fast_mask_flat_kernel) asks for much more: a span of a sixteenth of the band - identical rows
+        // give identical approximate values, span zero - because a chance coincidence of five or ten order statistics within
+        // the whole band happens to one row in a few hundred of ordinary data (0.3 - 0.7 % of randn / unit-norm rows: measured),
+        // and every masked row costs a row of the exact kernel.
+        if (i < N) flat_rows[i] = (flat && m[KCAP - 1] - m[1] <= 0.0625f * band) ? 1 : 0;
     }
     const unsigned long long b = __ballot(flat);
     if ((threadIdx.x & 63) == 0 && b != 0ull) atomicAdd(gate + 2, __popcll(b));
+}
+
+// Rows the sample cannot separate (fewer than one in eight, or check A would have taken the whole call): taken out of the
+// sweep - bound -inf: nothing is queued FOR them, while they stay everybody else's candidates - and marked as overflowed, so
+// that selection hands them to the batched fix-up.  A block of identical rows (silence in a stem dataset) larger than a
+// row's candidate buffer used to flood the queues: 10 000 duplicates among 100 000 rows took 90 ms (whole-call fallback),
+// now the sweep plus 10 000 rows of the exact general kernel.
+__global__ void __launch_bounds__(256) knn_fast_mask_flat_kernel(const unsigned char* __restrict__ flat_rows, const int* __restrict__ gate,
+                                                                 float* __restrict__ thr, int* __restrict__ cnt, int64_t N) {
+    if (gate[0] != 0) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N && flat_rows[i]) {
+        thr[i] = -INFINITY;
+        cnt[i] = FAST_ROW_OVERFLOW;
+    }
 }
 
 __global__ void knn_fast_decide_kernel(int* __restrict__ gate, int64_t N, int k1, int stage, const int* __restrict__ pair_count,
@@ -1238,8 +1298,13 @@ __global__ void knn_fast_decide_kernel(int* __restrict__ gate, int64_t N, int k1
     if (stage == 0) {
         gate[0] = (int64_t)gate[2] * 8 > N ? 1 : 0;
     } else if (stage == 1) {
-        const bool volume = (int64_t)*pair_count > N * (int64_t)(8 * k1 + 16);
-        const bool fixups = (int64_t)gate[3] * 64 > N;
+        // an exactly verified pair costs about as much as 80 pairs of the exact kernel, which looks at N pairs per row: the
+        // verification is worth it up to N / 160 survivors per row (half the exact kernel's time) - 625 at 100 000 rows, where a
+        // block of 100 identical low-norm rows makes every row verify 100 tied neighbours (tools/dups_probe.py) - and never
+        // fewer than 8 (k+1) + 16
+        const int64_t per_row = N / 160 > (int64_t)(8 * k1 + 16) ? N / 160 : (int64_t)(8 * k1 + 16);
+        const bool volume = (int64_t)*pair_count > N * per_row;
+        const bool fixups = (int64_t)gate[3] * 8 > N;          // (more than the batched fix-up's copy holds)
         // (a scale outside the f16 range sends every row to the fix-up as well: the exact kernel is the better fix-up)
         gate[1] = (gate[0] != 0 || volume || fixups || !half_scale_ok(maxn[2])) ? 1 : 0;
     } else if (gate[1] != 0) {
@@ -1278,7 +1343,12 @@ struct KnnFastBuffers {           // on top of the symmetric path's KnnBuffers
                                   //     kernel, [2] rows the sample cannot separate, [3] rows the prune step sent to fix-up;
                                   //     [4] next free queue region of a partitioned run
     float* xpartial;              // partial lists of the gated exact kernel (choose_chunks(N, N) x N x kcap)
+    unsigned char* flat_rows;     // [N] rows the sample cannot separate (check A's per-row verdict)
+    float *fix_rows, *fix_norms, *fix_partial, *fix_radii;   // batched fix-up: gathered copy of the overflowed rows, their norms,
+                                                             // the general kernel's partial lists and radii
 };
+constexpr int KNN_FIX_BATCH_FROM = 32;                        // shorter lists of overflowed rows: one row at a time (knn_fixup_kernel)
+static inline int64_t knn_fix_capacity(int64_t N) { return ceil_div(std::max<int64_t>(N / 8, 1024), TB) * TB; }
 constexpr int KNN_FAST_OVCAP = 1 << 22;
 
 static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan& p) {
@@ -1294,6 +1364,12 @@ static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan&
     f.ovv = c.take<float>(KNN_FAST_OVCAP);
     f.gate = c.take<int>(8);
     f.xpartial = c.take<float>((size_t)choose_chunks(N, N) * N * p.kcap);
+    f.flat_rows = c.take<unsigned char>((size_t)N);
+    const int64_t fcap = knn_fix_capacity(N);
+    f.fix_rows = c.take<float>((size_t)fcap * ((D + 3) / 4 * 4));
+    f.fix_norms = c.take<float>((size_t)fcap);
+    f.fix_partial = c.take<float>((size_t)choose_chunks(fcap, N) * fcap * p.kcap);
+    f.fix_radii = c.take<float>((size_t)fcap);
     return f;
 }
 
@@ -1359,7 +1435,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
                            k1, 1, thr, static_cast<const int*>(nullptr));
         if (gate != nullptr) {                           // check A: can the f16 values separate the rows' neighbours at all?
             hipLaunchKernelGGL(knn_fast_predict_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.partial, N,
-                               sample_chunks, k1, b.xn, maxn, fast_c(D), gate);
+                               sample_chunks, k1, b.xn, maxn, fast_c(D), gate, f.flat_rows);
             hipLaunchKernelGGL(knn_fast_decide_kernel, dim3(1), dim3(64), 0, st, gate, N, k1, 0, f.pair_count, maxn, b.ov_count);
         }
         hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, thr, thr, b.xn, N, maxn, 2.f * fast_c(D));
@@ -1367,6 +1443,10 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     }
     AM_HIP_TRY(hipMemsetAsync(b.cnt, 0, (size_t)(N + 1) * sizeof(int), st));
     AM_HIP_TRY(hipMemsetAsync(f.cnt2, 0, (size_t)(N + 2) * sizeof(int), st));
+    if (gate != nullptr) {
+        hipLaunchKernelGGL(knn_fast_mask_flat_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, f.flat_rows, gate, thr, b.cnt, N);
+        AM_LAUNCH_CHECK();
+    }
     AM_HIP_TRY(hipMemsetAsync(f.ovn, 0, sizeof(unsigned long long), st));
     // 2) symmetric filter sweep
     const unsigned nwg = (unsigned)p.nwg;
@@ -1434,8 +1514,19 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
                        maxn, out_r, b.ov_list, b.ov_count, out_lists, skip_verify);
     AM_LAUNCH_CHECK();
     if (out_lists == nullptr) {
+        // short lists of overflowed rows: one row at a time; from KNN_FIX_BATCH_FROM rows on: gathered copy + general kernel
+        const int fcap = (int)knn_fix_capacity(N);
+        const int64_t ldr = (D + 3) / 4 * 4;
         hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
-                           b.xn, D, k1, b.ov_list, b.ov_count, out_r);
+                           b.xn, D, k1, b.ov_list, b.ov_count, out_r, KNN_FIX_BATCH_FROM, fcap);
+        hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(1024), dim3(256), 0, st, X, ld, D, b.xn, b.ov_list, b.ov_count,
+                           KNN_FIX_BATCH_FROM, fcap, f.fix_rows, ldr, f.fix_norms);
+        AM_LAUNCH_CHECK();
+        if ((rc = launch_knn<KCAP>(f.fix_rows, fcap, ldr, f.fix_norms, X, N, ld, b.xn, D, k1, choose_chunks(fcap, N), 1, false,
+                                   f.fix_partial, f.fix_radii, st, nullptr, b.ov_count, KNN_FIX_BATCH_FROM)) != AM_OK)
+            return rc;
+        hipLaunchKernelGGL(knn_scatter_radii_kernel, dim3(64), dim3(256), 0, st, f.fix_radii, b.ov_list, b.ov_count,
+                           KNN_FIX_BATCH_FROM, fcap, out_r);
         AM_LAUNCH_CHECK();
     }
     if (gate != nullptr) {

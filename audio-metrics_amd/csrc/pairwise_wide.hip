@@ -568,7 +568,8 @@ knn_wide_kernel(const float* __restrict__ Xb, int64_t N, int64_t ldh, const floa
             for (int s = 0; s < KCAP; ++s) __hip_atomic_store(out + s, m[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float kthv = m[KCAP - 1];
             const float bound = kthv + 2.f * fc * (xnorm[i] + nmax);
-            atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
+            // (a row taken out of the sweep keeps its -inf: knn_fast_mask_flat_kernel; nobody else writes thr[i])
+            if (epi_row_in_sweep(thr, i)) atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
         }
     }
 }

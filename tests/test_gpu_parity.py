@@ -171,6 +171,33 @@ def test_knn_filter_gives_way_on_data_it_cannot_separate(am, n, d, k):
     assert stats["knn_fallback_rows"] == 0, stats
 
 
+@pytest.mark.parametrize("n,d,k,block", [(20000, 128, 5, 700), (20000, 128, 10, 1500), (12000, 512, 5, 40), (33000, 64, 3, 3000)])
+def test_a_block_of_identical_rows_goes_through_the_batched_fix_up(am, n, d, k, block):
+    """Silent windows of a stem dataset embed to one and the same vector: a block of identical rows.  Each of them has all the
+    others at distance zero - more than a row's candidate buffer holds once the block is larger than it (384 / 704 entries) -
+    and was recomputed one row at a time (42 us per row at 100 000 x 512).  Now the sample pass recognises such rows (identical
+    rows give identical approximate values), takes them out of the sweep and hands them to the batched fix-up: the exact
+    GENERAL kernel on a gathered copy.  Exactly the block's rows fall back (a block that fits the buffers: none), everybody
+    else stays on the filter path, and every radius is the C model's bits."""
+    from oracle import exact
+    ops = am.hip_ops
+    x = gi.unit_norm(81, n, d)
+    rng = np.random.default_rng(block)
+    rows = rng.choice(n, block, replace=False)
+    x[rows] = x[rows[0]]
+    assert ops.knn_path(n, n, d, k) == 3
+    ops.filter_stats_enable("cuda:0", True)
+    r = am.nearest_neighbour_distances(dev(x), k).cpu().numpy()
+    stats = ops.filter_stats_read("cuda:0")
+    ops.filter_stats_enable("cuda:0", False)
+    cap = max(256, 64 * (k + 1))
+    if block > cap:
+        assert block <= stats["knn_fallback_rows"] <= block + n // 200, stats           # the block, and hardly anybody else
+    else:
+        assert stats["knn_fallback_rows"] <= n // 200, stats
+    assert np.array_equal(r.view(np.uint32), exact.knn_radii(x, k).view(np.uint32))
+
+
 def test_membership_filter_gives_way_when_both_sets_share_tight_clusters(am):
     """Reference and candidate rows drawn around the SAME 50 tight clusters: every candidate of a reference row's cluster lies
     inside the f16 error band of that row's radius - hundreds of undecidable pairs per row (before the guard: 96 ms against
