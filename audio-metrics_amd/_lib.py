@@ -46,6 +46,7 @@ SIGNATURES = {
     "am_knn_part_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "am_knn_bounds_f32": (c_int, [_P, c_int64, c_int64, c_int, c_int, c_int64, c_int64, _P, _P, c_size_t, _P]),
     "am_knn_sym_part_f32": (c_int, [_P, c_int64, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "am_knn_lists_finish_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "am_knn_lists_finish_f32": (c_int, [_P, c_int, _P, c_int64, c_int64, c_int, c_int, _P, _P, c_size_t, _P]),
     "am_prdc_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "am_prdc_counts_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P,

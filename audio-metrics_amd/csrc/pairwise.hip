@@ -1479,16 +1479,53 @@ extern "C" int am_knn_sym_part_prepared_f32(const float* X, int64_t N, int64_t l
     return knn_sym_part_impl(X, N, ld, D, k, part, nparts, bounds_sq, out_lists, ws, ws_bytes, stream, &ps);
 }
 
+// more flagged rows than the batched fix-up's copy holds: all of them go through the exact general kernel (every row's
+// value there is the same bits as the lists'), the list is emptied
+__global__ void knn_finish_route_kernel(int* __restrict__ ov_count, int capacity, int* __restrict__ run_exact) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool all = *ov_count > capacity;
+    *run_exact = all ? 1 : 0;
+    if (all) *ov_count = 0;
+}
+
+struct ListsFinishBuffers {
+    float* xn;
+    int *ov_list, *ov_count, *run_exact;
+    KnnFixup fix;
+    float* xpartial;
+};
+
+static ListsFinishBuffers carve_lists_finish(Carver& c, int64_t N, int D, int kcap) {
+    ListsFinishBuffers b;
+    b.xn = c.take<float>(N);
+    b.ov_list = c.take<int>(N + 2);
+    b.ov_count = b.ov_list ? b.ov_list + N : nullptr;
+    b.run_exact = b.ov_list ? b.ov_list + N + 1 : nullptr;
+    b.fix = carve_knn_fixup(c, N, D, kcap);
+    b.xpartial = c.take<float>((size_t)choose_chunks(N, N) * N * kcap);
+    return b;
+}
+
+// Flagged rows (a rank's candidate buffer or queue overflowed for them: blocks of identical rows, ties around a hub): a few -
+// one row at a time; up to N / 8 - the batched fix-up on the matrix cores (run_knn_fixup); more - the exact general kernel
+// over all rows, behind a device-side flag.  (Round 3 took every flagged row one at a time: 42 us per row at 100 000 x 512.)
 template <int KCAP>
-static int run_lists_finish(const float* lists, int nparts, const float* X, int64_t N, int64_t ld, int D, int k1, float* xn,
-                            int* ov_list, int* ov_count, float* out_r, hipStream_t st) {
+static int run_lists_finish(const float* lists, int nparts, const float* X, int64_t N, int64_t ld, int D, int k1,
+                            const ListsFinishBuffers& b, float* out_r, hipStream_t st) {
+    int rc;
     hipLaunchKernelGGL(knn_lists_finish_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, lists, nparts, N, k1,
-                       out_r, ov_list, ov_count);
+                       out_r, b.ov_list, b.ov_count);
+    hipLaunchKernelGGL(knn_finish_route_kernel, dim3(1), dim3(64), 0, st, b.ov_count, (int)b.fix.capacity, b.run_exact);
     AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
-                       xn, D, k1, ov_list, ov_count, out_r, 0, 0);
-    AM_LAUNCH_CHECK();
-    return AM_OK;
+    if ((rc = run_knn_fixup<KCAP>(X, N, ld, b.xn, D, k1, b.ov_list, b.ov_count, b.fix, out_r, st)) != AM_OK) return rc;
+    return launch_knn<KCAP>(X, N, ld, b.xn, X, N, ld, b.xn, D, k1, choose_chunks(N, N), 1, false, b.xpartial, out_r, st, b.run_exact);
+}
+
+extern "C" size_t am_knn_lists_finish_workspace_bytes(int64_t N, int D, int k) {
+    if (N < 1 || D < 1 || k < 1 || k > AM_MAX_K) return 0;
+    Carver c(nullptr, 0);
+    carve_lists_finish(c, N, D, kcap_for(k + 1));
+    return c.off;
 }
 
 extern "C" int am_knn_lists_finish_f32(const float* lists, int nparts, const float* X, int64_t N, int64_t ld, int D, int k,
@@ -1499,16 +1536,15 @@ extern "C" int am_knn_lists_finish_f32(const float* lists, int nparts, const flo
     AM_REQUIRE(k >= 1 && k <= AM_MAX_K && nparts >= 1, AM_ERR_BAD_ARG, "k=%d nparts=%d", k, nparts);
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carver c(ws, ws_bytes);
-    float* xn = c.take<float>(N);
-    int* ov = c.take<int>(N + 1);
+    const ListsFinishBuffers b = carve_lists_finish(c, N, D, kcap_for(k + 1));
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
-    if ((rc = launch_norms(X, N, ld, D, xn, st)) != AM_OK) return rc;
-    AM_HIP_TRY(hipMemsetAsync(ov + N, 0, sizeof(int), st));
+    if ((rc = launch_norms(X, N, ld, D, b.xn, st)) != AM_OK) return rc;
+    AM_HIP_TRY(hipMemsetAsync(b.ov_count, 0, 2 * sizeof(int), st));
     switch (kcap_for(k + 1)) {
-        case 6:  return run_lists_finish<6>(lists, nparts, X, N, ld, D, k + 1, xn, ov, ov + N, out_r, st);
-        case 11: return run_lists_finish<11>(lists, nparts, X, N, ld, D, k + 1, xn, ov, ov + N, out_r, st);
-        case 16: return run_lists_finish<16>(lists, nparts, X, N, ld, D, k + 1, xn, ov, ov + N, out_r, st);
-        default: return run_lists_finish<32>(lists, nparts, X, N, ld, D, k + 1, xn, ov, ov + N, out_r, st);
+        case 6:  return run_lists_finish<6>(lists, nparts, X, N, ld, D, k + 1, b, out_r, st);
+        case 11: return run_lists_finish<11>(lists, nparts, X, N, ld, D, k + 1, b, out_r, st);
+        case 16: return run_lists_finish<16>(lists, nparts, X, N, ld, D, k + 1, b, out_r, st);
+        default: return run_lists_finish<32>(lists, nparts, X, N, ld, D, k + 1, b, out_r, st);
     }
 }
 

@@ -1232,6 +1232,45 @@ __global__ void __launch_bounds__(256) knn_scatter_radii_kernel(const float* __r
     for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) radii[ov_list[r]] = radii_of_copy[r];
 }
 
+constexpr int KNN_FIX_BATCH_FROM = 32;                        // shorter lists of overflowed rows: one row at a time (knn_fixup_kernel)
+static inline int64_t knn_fix_capacity(int64_t N) { return ceil_div(std::max<int64_t>(N / 8, 1024), TB) * TB; }
+
+struct KnnFixup {                 // batched fix-up: gathered copy of the overflowed rows, their norms, the general kernel's
+    float *rows, *norms, *partial, *radii;                                                    // partial lists and radii
+    int64_t capacity;
+};
+
+static KnnFixup carve_knn_fixup(Carver& c, int64_t N, int D, int kcap) {
+    KnnFixup x;
+    x.capacity = knn_fix_capacity(N);
+    x.rows = c.take<float>((size_t)x.capacity * ((D + 3) / 4 * 4));
+    x.norms = c.take<float>((size_t)x.capacity);
+    x.partial = c.take<float>((size_t)choose_chunks(x.capacity, N) * x.capacity * kcap);
+    x.radii = c.take<float>((size_t)x.capacity);
+    return x;
+}
+
+// radii of the rows in ov_list (a device-side count): one row at a time below KNN_FIX_BATCH_FROM rows, through the gathered
+// copy from there on (rows past the copy's capacity: one at a time again - the callers keep the list below it)
+template <int KCAP>
+static int run_knn_fixup(const float* X, int64_t N, int64_t ld, const float* xn, int D, int k1, const int* ov_list, const int* ov_count,
+                         const KnnFixup& x, float* out_r, hipStream_t st) {
+    int rc;
+    const int fcap = (int)x.capacity;
+    const int64_t ldr = (D + 3) / 4 * 4;
+    hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
+                       xn, D, k1, ov_list, ov_count, out_r, KNN_FIX_BATCH_FROM, fcap);
+    hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(1024), dim3(256), 0, st, X, ld, D, xn, ov_list, ov_count, KNN_FIX_BATCH_FROM, fcap,
+                       x.rows, ldr, x.norms);
+    AM_LAUNCH_CHECK();
+    if ((rc = launch_knn<KCAP>(x.rows, fcap, ldr, x.norms, X, N, ld, xn, D, k1, choose_chunks(fcap, N), 1, false, x.partial, x.radii,
+                               st, nullptr, ov_count, KNN_FIX_BATCH_FROM)) != AM_OK)
+        return rc;
+    hipLaunchKernelGGL(knn_scatter_radii_kernel, dim3(64), dim3(256), 0, st, x.radii, ov_list, ov_count, KNN_FIX_BATCH_FROM, fcap, out_r);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
 // ---- data-dependent fallback of the k-NN filter path (round 4) -----------------------------------------------------
 // The filter pays when the f16 values SEPARATE a row's nearest neighbours from the rest.  On tightly clustered data they
 // do not: every member of a row's cluster lies inside the error band of its (k+1)-th neighbour, the queues keep them all,
@@ -1344,11 +1383,8 @@ struct KnnFastBuffers {           // on top of the symmetric path's KnnBuffers
                                   //     [4] next free queue region of a partitioned run
     float* xpartial;              // partial lists of the gated exact kernel (choose_chunks(N, N) x N x kcap)
     unsigned char* flat_rows;     // [N] rows the sample cannot separate (check A's per-row verdict)
-    float *fix_rows, *fix_norms, *fix_partial, *fix_radii;   // batched fix-up: gathered copy of the overflowed rows, their norms,
-                                                             // the general kernel's partial lists and radii
+    KnnFixup fix;                 // batched fix-up of the overflowed rows
 };
-constexpr int KNN_FIX_BATCH_FROM = 32;                        // shorter lists of overflowed rows: one row at a time (knn_fixup_kernel)
-static inline int64_t knn_fix_capacity(int64_t N) { return ceil_div(std::max<int64_t>(N / 8, 1024), TB) * TB; }
 constexpr int KNN_FAST_OVCAP = 1 << 22;
 
 static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan& p) {
@@ -1365,11 +1401,7 @@ static KnnFastBuffers carve_knn_fast(Carver& c, int64_t N, int D, const KnnPlan&
     f.gate = c.take<int>(8);
     f.xpartial = c.take<float>((size_t)choose_chunks(N, N) * N * p.kcap);
     f.flat_rows = c.take<unsigned char>((size_t)N);
-    const int64_t fcap = knn_fix_capacity(N);
-    f.fix_rows = c.take<float>((size_t)fcap * ((D + 3) / 4 * 4));
-    f.fix_norms = c.take<float>((size_t)fcap);
-    f.fix_partial = c.take<float>((size_t)choose_chunks(fcap, N) * fcap * p.kcap);
-    f.fix_radii = c.take<float>((size_t)fcap);
+    f.fix = carve_knn_fixup(c, N, D, p.kcap);
     return f;
 }
 
@@ -1515,19 +1547,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     AM_LAUNCH_CHECK();
     if (out_lists == nullptr) {
         // short lists of overflowed rows: one row at a time; from KNN_FIX_BATCH_FROM rows on: gathered copy + general kernel
-        const int fcap = (int)knn_fix_capacity(N);
-        const int64_t ldr = (D + 3) / 4 * 4;
-        hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
-                           b.xn, D, k1, b.ov_list, b.ov_count, out_r, KNN_FIX_BATCH_FROM, fcap);
-        hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(1024), dim3(256), 0, st, X, ld, D, b.xn, b.ov_list, b.ov_count,
-                           KNN_FIX_BATCH_FROM, fcap, f.fix_rows, ldr, f.fix_norms);
-        AM_LAUNCH_CHECK();
-        if ((rc = launch_knn<KCAP>(f.fix_rows, fcap, ldr, f.fix_norms, X, N, ld, b.xn, D, k1, choose_chunks(fcap, N), 1, false,
-                                   f.fix_partial, f.fix_radii, st, nullptr, b.ov_count, KNN_FIX_BATCH_FROM)) != AM_OK)
-            return rc;
-        hipLaunchKernelGGL(knn_scatter_radii_kernel, dim3(64), dim3(256), 0, st, f.fix_radii, b.ov_list, b.ov_count,
-                           KNN_FIX_BATCH_FROM, fcap, out_r);
-        AM_LAUNCH_CHECK();
+        if ((rc = run_knn_fixup<KCAP>(X, N, ld, b.xn, D, k1, b.ov_list, b.ov_count, f.fix, out_r, st)) != AM_OK) return rc;
     }
     if (gate != nullptr) {
         // the exact general kernel behind the filter path: its workgroups return at once unless check A or B gave up

@@ -566,7 +566,7 @@ def knn_lists_finish(lists, x_full, k):
     lists = lists.to(torch.float32).contiguous()
     nparts = lists.shape[0]
     out = torch.empty(n, dtype=torch.float32, device=x.device)
-    nb = 2 * (4 * (n + 64) + 512)
+    nb = lib.am_knn_lists_finish_workspace_bytes(n, d, int(k))
     ws = _workspace(nb, x.device)
     _call(lib, "am_knn_lists_finish_f32", x.device, _ptr(lists), nparts, _ptr(x), n, _ld(x), d, int(k), _ptr(out), _ptr(ws), nb)
     return out

@@ -207,6 +207,7 @@ int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx,
  *                           (+inf padded; a NaN in slot 0 flags a row whose candidate buffer overflowed);
  *                           bounds_sq[N] is read (the exact form also tightens it in place)
  *   am_knn_lists_finish_f32 lists[nparts][N][width] (all-gathered) -> out_r[N]; flagged rows are recomputed exactly
+ *                           (workspace: am_knn_lists_finish_workspace_bytes)
  * Shapes that take the f16 filter + exact verification form in am_knn_radii_f32 take it here too (csrc/pairwise_fast.h):
  * the bounds come from an f16 sample pass, each rank sweeps its row blocks on the f16 copy and evaluates its surviving
  * pairs exactly; out_lists then holds the rank's smallest EXACT values per row.
@@ -219,6 +220,7 @@ int am_knn_bounds_f32(const float* X, int64_t N, int64_t ld, int D, int k, int64
                       float* out_bound_sq, void* ws, size_t ws_bytes, am_stream_t stream);
 int am_knn_sym_part_f32(const float* X, int64_t N, int64_t ld, int D, int k, int part, int nparts,
                         float* bounds_sq, float* out_lists, void* ws, size_t ws_bytes, am_stream_t stream);
+size_t am_knn_lists_finish_workspace_bytes(int64_t N, int D, int k);
 int am_knn_lists_finish_f32(const float* lists, int nparts, const float* X, int64_t N, int64_t ld, int D, int k,
                             float* out_r, void* ws, size_t ws_bytes, am_stream_t stream);
 

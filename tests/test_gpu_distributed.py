@@ -105,6 +105,41 @@ def test_partitioned_symmetric_knn_bit_identical(nparts, k, rows, path):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("kind,nparts", [("block", 3), ("hub", 4), ("flag_everything", 2)])
+def test_partitioned_knn_with_identical_rows(kind, nparts):
+    """Blocks of identical rows in the partitioned form: their rows overflow the ranks' candidate buffers and come back flagged.
+    A moderate number goes through the batched fix-up (gathered copy + exact general kernel); more than N / 8 flagged rows -
+    a low-norm block that is every row's nearest neighbour at one distance, or every row flagged by hand - through the exact
+    general kernel over all rows.  Either way the radii are the single-GPU call's bits."""
+    import numpy as np
+    from audio_metrics_amd import hip_ops as ops
+    k, rows, d = 5, 16500, 128
+    x = gi.randn(31, rows, d)
+    rng = np.random.default_rng(5)
+    if kind == "block":
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        dup = rng.choice(rows, 700, replace=False)
+        x[dup] = x[dup[0]]
+    elif kind == "hub":
+        dup = rng.choice(rows, 600, replace=False)
+        x[dup] = 0.05 * x[dup[0]]
+    x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to("cuda:0")
+    assert ops.knn_path(rows, rows, d, k) == 3
+    want = ops.knn_radii(x, k).cpu().numpy()
+    bounds = torch.cat([ops.knn_bounds(x, k, lo, hi - lo) for lo, hi in
+                        [(rows * p // nparts, rows * (p + 1) // nparts) for p in range(nparts)]])
+    lists = torch.stack([ops.knn_sym_part(x, k, p, nparts, bounds) for p in range(nparts)])
+    flagged = int(torch.isnan(lists[:, :, 0]).any(dim=0).sum())
+    if kind == "block":
+        assert 32 < flagged <= rows // 8, flagged                 # enough for the batched route, few enough for its copy
+    elif kind == "hub":
+        assert flagged > 600, flagged
+    else:
+        lists[0, :, 0] = float("nan")
+    got = ops.knn_lists_finish(lists, x, k).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_partitioned_exact_symmetric_kernel():
     """The partitioned form of the exact symmetric kernel (what the library takes where the f16 filter sweep does not apply:
     D > 4096, or the A/B build with AM_KNN_FAST=0) - in a subprocess, the knob is process-wide."""

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Time one rank's share of the partitioned symmetric k-NN at the BASELINE size (single GPU emulation)."""
+"""Time one rank's share of the partitioned symmetric k-NN at the BASELINE size (single GPU emulation).
+AB_DUPS=<rows>: that many rows are one and the same vector (AB_UNIT=1: unit-norm rows; else a low-norm vector among randn rows,
+every row's nearest neighbour)."""
 import os
 import sys
 import time
@@ -10,7 +12,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio_metrics_amd import hip_ops as ops  # noqa: E402
 
 n, d, k = 100000, 512, 5
-x = torch.randn(n, d, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+gen = torch.Generator(device="cuda").manual_seed(0)
+x = torch.randn(n, d, device="cuda", generator=gen)
+dups, unit = int(os.environ.get("AB_DUPS", "0")), os.environ.get("AB_UNIT", "0") == "1"
+if unit:
+    x += 0.5
+if dups:
+    x[torch.randperm(n, generator=gen, device="cuda")[:dups]] = x[0] * (1.0 if unit else 0.1)
+if unit:
+    x /= x.norm(dim=1, keepdim=True)
 
 
 def t(fn, reps=3):
@@ -33,4 +43,6 @@ for g in (2, 4, 8):
     lists = torch.stack([ops.knn_sym_part(x, k, p, g, bounds) for p in range(g)])
     tf = t(lambda: ops.knn_lists_finish(lists, x, k))
     tg = t(lambda: ops.knn_radii(x[:rows], k, columns=x))
-    print(f"world={g}: bounds {tb:.2f} ms + part {tp:.2f} ms + finish {tf:.2f} ms = {tb + tp + tf:.2f} ms   (general shard kernel {tg:.2f} ms)")
+    flagged = int(torch.isnan(lists[:, :, 0]).any(dim=0).sum())
+    assert torch.equal(ops.knn_lists_finish(lists, x, k), ops.knn_radii(x, k))
+    print(f"duplicates {dups} ({'unit-norm' if unit else 'randn'}) flagged rows {flagged} world={g}: bounds {tb:.2f} ms + part {tp:.2f} ms + finish {tf:.2f} ms = {tb + tp + tf:.2f} ms   (general shard kernel {tg:.2f} ms)")
