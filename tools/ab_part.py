@@ -35,11 +35,30 @@ def t(fn, reps=3):
     return best * 1e3
 
 
-for g in (2, 4, 8):
+for g in [int(v) for v in os.environ.get("AB_WORLDS", "2,4,8").split(",")]:
     rows = n // g
     tb = t(lambda: ops.knn_bounds(x, k, 0, rows))
     bounds = torch.cat([ops.knn_bounds(x, k, p * rows, rows) for p in range(g)])
-    tp = t(lambda: ops.knn_sym_part(x, k, 0, g, bounds))
+    prep = ops.prepare(x) if os.environ.get("AB_PREPARED", "0") == "1" else None
+    extra = {} if prep is None else {"prepared": prep}
+    tp = t(lambda: ops.knn_sym_part(x, k, int(os.environ.get("AB_PART", "0")), g, bounds, **extra))
+    if os.environ.get("AB_ONLY_PART", "0") == "1":                 # nothing but this rank's share, with the library's kernel clock
+        ops.kernel_clock_enable(True)
+        ops.filter_stats_enable("cuda:0", True)
+        line = []
+        for part in sorted({0, g // 2, g - 1}):
+            ops.knn_sym_part(x, k, part, g, bounds, **extra)
+            torch.cuda.synchronize()
+            for kid in (0, 2):
+                ops.kernel_clock_read(kid)
+            ops.filter_stats_read("cuda:0")
+            tpp = t(lambda: ops.knn_sym_part(x, k, part, g, bounds, **extra))
+            (c0, sweep), (c2, verify) = ops.kernel_clock_read(0), ops.kernel_clock_read(2)
+            st = ops.filter_stats_read("cuda:0")
+            line.append(f"part {part}: {tpp:.2f} ms (sweep {sweep / max(c0, 1):.2f}, verify {verify / max(c2, 1):.2f}, queued {st['knn_queued'] / max(c0, 1):.0f})")
+        print(f"world={g}: " + "  ".join(line))
+        ops.kernel_clock_enable(False)
+        continue
     lists = torch.stack([ops.knn_sym_part(x, k, p, g, bounds) for p in range(g)])
     tf = t(lambda: ops.knn_lists_finish(lists, x, k))
     tg = t(lambda: ops.knn_radii(x[:rows], k, columns=x))
