@@ -19,6 +19,12 @@ def make(kind, n, d, seed):
     if kind == "dups":                 # every row has an exact duplicate: zero radii, exact ties
         h = n // 2
         return torch.cat([x[:h], x[:n - h]])
+    if kind in ("silence", "hub"):     # a block of IDENTICAL rows (0.2 - 12 % of the set): silent windows embed to one vector;
+        m = max(40, int(n * [0.002, 0.01, 0.04, 0.12][seed % 4]))     # "hub": a low-norm one, every row's nearest neighbour
+        if kind == "silence":
+            x = x + 0.5
+        x[torch.randperm(n, generator=gen, device="cuda")[:m]] = x[0] * (1.0 if kind == "silence" else 0.1)
+        return x / x.norm(dim=1, keepdim=True) if kind == "silence" else x
     if kind == "lowrank":              # a 4-dimensional subspace plus tiny noise, large common offset
         basis = torch.randn(4, d, generator=gen, device="cuda")
         return torch.randn(n, 4, generator=gen, device="cuda") @ basis + 1e-4 * x + 3.0

@@ -17,7 +17,7 @@ for case in range(n_cases):
     dim = rnd.choice([int(v) for v in os.environ["FUZZ_DIMS"].split(",")] if os.environ.get("FUZZ_DIMS") else
                      [64, 67, 96, 128, 130, 200, 256, 257, 384, 512])
     k = rnd.choice([1, 3, 5, 8, 10])
-    data = rnd.choice(os.environ.get("FUZZ_DATA", "randn,clustered,scales,lowrank,unit,dups").split(","))
+    data = rnd.choice(os.environ.get("FUZZ_DATA", "randn,clustered,scales,lowrank,unit,dups,silence,hub").split(","))
     rows2 = rnd.choice([rows, rows, max(600, rows // 7), min(100000, rows * 2), 3001])      # candidate rows (membership only)
     base = dict(os.environ, AB_ROWS=str(rows), AB_ROWS2=str(rows2), AB_DIM=str(dim), AB_K=str(k), AB_REPS="1", AB_DATA=data,
                 AB_SEED=str(rnd.randrange(1000)), AB_WANT_MIN=str(rnd.randrange(2)))

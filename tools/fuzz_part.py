@@ -21,7 +21,7 @@ for case in range(n_cases):
     dim = rnd.choice([128, 136, 200, 256, 512])
     k = rnd.choice([1, 3, 5, 10])
     world = rnd.choice([2, 3, 4, 8])
-    data = rnd.choice(["randn", "clustered", "scales", "lowrank", "unit", "dups"])
+    data = rnd.choice(os.environ.get("FUZZ_DATA", "randn,clustered,scales,lowrank,unit,dups,silence,hub").split(","))
     x = make(data, rows, dim, rnd.randrange(1000))
     if not ops.knn_sym_eligible(rows, dim, k):
         print(f"case {case}: rows={rows} dim={dim} k={k}: not eligible, skipped")
