@@ -21,7 +21,7 @@ for share in [float(v) for v in os.environ.get("AB_SHARES", "0,0.001,0.003,0.01,
     if unit:
         x, y = x + 0.5, y + 0.5
     if m:
-        silent = torch.randn(1, d, generator=gen, device="cuda") * (1.0 if unit else 0.1) + (0.5 if unit else 0.0)
+        silent = torch.randn(1, d, generator=gen, device="cuda") * (1.0 if unit else float(os.environ.get("AB_SILENT_SCALE", "0.1"))) + (0.5 if unit else 0.0)
         x[torch.randperm(n, generator=gen, device="cuda")[:m]] = silent
         y[torch.randperm(n, generator=gen, device="cuda")[:m]] = silent
     if unit:
