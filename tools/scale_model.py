@@ -181,13 +181,23 @@ def simulate(seg, n, d, k, world, order, fabric):
     return end * 1e3, (end - busy) * 1e3, inbound
 
 
+def library_stamp():
+    """sources_sha256 of the library the segments were timed on (what bench.py's roofline.traffic_source carries too)."""
+    from audio_metrics_amd import _build, _lib
+    try:
+        with open(_build._stamp_path(_lib.library_path())) as fh:
+            return json.load(fh).get("sources_sha256")
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     n, d, k = int(os.environ.get("AB_ROWS", "100000")), 512, int(os.environ.get("AB_K", "5"))
     dev = torch.device("cuda:0")
     out = {"workload": f"bench.py: FAD+KD+PRDC(k={k}) cold evaluate of 2 x {n} x {d} ({os.environ.get('AB_DATA', 'randn')})", "measured_on": "ONE MI355X (rank 0 emulated)",
            "assumptions": {"xgmi_link_GBps_per_direction": LINK / 1e9, "links_per_gpu": 7, "collective_latency_us": LAT * 1e6,
                            "mesh": "all links at once at 70 % of the link rate", "ring": "one link per direction at 80 %"},
-           "worlds": {}}
+           "library": library_stamp(), "worlds": {}}
     for world in [int(w) for w in os.environ.get("AB_WORLDS", "1,2,4,8").split(",")]:
         seg = measure(n, d, k, world, dev)
         entry = {"compute_segments_ms": {key: round(v, 4) for key, v in sorted(seg.items())}}
