@@ -854,8 +854,9 @@ def test_kernel_clock_counts_tile_kernel_launches(am):
         n_knn, ms_knn = ops.kernel_clock_read(ops.KERNEL_KNN)
         n_cross, ms_cross = ops.kernel_clock_read(ops.KERNEL_PRDC_CROSS)
         assert n_knn == 2 and n_cross == 1
-        assert 0.0 < ms_knn <= outer["am_knn_radii_f32"][1] * 1.05
-        assert 0.0 < ms_cross <= outer["am_prdc_counts_f32"][1] * 1.05
+        # (both sides are hipEvent intervals: 5 % + 20 us for their resolution)
+        assert 0.0 < ms_knn <= outer["am_knn_radii_f32"][1] * 1.05 + 0.02
+        assert 0.0 < ms_cross <= outer["am_prdc_counts_f32"][1] * 1.05 + 0.02
         assert ops.kernel_clock_read(ops.KERNEL_KNN) == (0, 0.0)
         assert torch.equal(r_off, r_x)                       # the clock does not change results
         with pytest.raises(am._lib.HipLibraryError):
