@@ -69,19 +69,46 @@ static float* transpose_in_chain_order(const float* Y, int64_t M, int64_t ld, in
     return t;
 }
 
-/* d2 of row x against all M columns */
-static void d2_row(const float* x, float xn, int D, const float* Yt, const float* yn, int64_t M, const int* ord, int n,
-                   float* acc) {
-    for (int64_t j = 0; j < M; ++j) acc[j] = 0.f;
-    for (int q = 0; q < n; ++q) {
-        const int k = ord[q];
-        const float a = k < D ? x[k] : 0.f;
-        const float* y = Yt + (size_t)q * M;
-        for (int64_t j = 0; j < M; ++j) acc[j] = fmaf(y[j], a, acc[j]);
-    }
-    for (int64_t j = 0; j < M; ++j) {
-        const float d2 = fmaf(-2.f, acc[j], xn + yn[j]);
-        acc[j] = d2 != d2 ? INFINITY : (d2 < 0.f ? 0.f : d2);   /* NaN (a non-finite row) -> +inf: like torch's NaN it never counts */
+/* d2 of ROWS_AT_ONCE rows x_0 .. x_{R-1} (R <= ROWS_AT_ONCE) against all M columns: acc[r * M + j].  The rows share every load
+   of Yt, and a block of COLS_AT_ONCE columns keeps its partial sums in the L1 cache over the whole chain - the arithmetic of each
+   (row, column) pair is the same chain of fmaf in the same order as one row at a time (that form streamed all of Yt and the
+   sums through the caches once per row and chain step: 45 s for 40 000 x 40 000 x 512 on 32 cores). */
+#define ROWS_AT_ONCE 4
+#define COLS_AT_ONCE 1024
+static void d2_rows(const float* X, int64_t ldx, int R, const float* xn, int D, const float* Yt, const float* yn, int64_t M,
+                    const int* ord, int n, float* acc) {
+    float a[ROWS_AT_ONCE][512 + 8];
+    for (int64_t j0 = 0; j0 < M; j0 += COLS_AT_ONCE) {
+        const int64_t jn = M - j0 < COLS_AT_ONCE ? M - j0 : COLS_AT_ONCE;
+        float s[ROWS_AT_ONCE][COLS_AT_ONCE];
+        for (int r = 0; r < ROWS_AT_ONCE; ++r)
+            for (int64_t j = 0; j < jn; ++j) s[r][j] = 0.f;
+        for (int q0 = 0; q0 < n; q0 += 512) {                       /* (the row values of up to 512 chain steps at a time) */
+            const int qn = n - q0 < 512 ? n - q0 : 512;
+            for (int r = 0; r < ROWS_AT_ONCE; ++r)
+                for (int q = 0; q < qn; ++q) {
+                    const int k = ord[q0 + q];
+                    a[r][q] = (r < R && k < D) ? X[r * ldx + k] : 0.f;
+                }
+            for (int q = 0; q < qn; ++q) {
+                const float* y = Yt + (size_t)(q0 + q) * M + j0;
+                const float a0 = a[0][q], a1 = a[1][q], a2 = a[2][q], a3 = a[3][q];
+                float *s0 = s[0], *s1 = s[1], *s2 = s[2], *s3 = s[3];
+                for (int64_t j = 0; j < jn; ++j) {
+                    const float v = y[j];
+                    s0[j] = fmaf(v, a0, s0[j]);
+                    s1[j] = fmaf(v, a1, s1[j]);
+                    s2[j] = fmaf(v, a2, s2[j]);
+                    s3[j] = fmaf(v, a3, s3[j]);
+                }
+            }
+        }
+        for (int r = 0; r < R; ++r)
+            for (int64_t j = 0; j < jn; ++j) {
+                const float d2 = fmaf(-2.f, s[r][j], xn[r] + yn[j0 + j]);
+                /* NaN (a non-finite row) -> +inf: like torch's NaN it never counts */
+                acc[(size_t)r * M + j0 + j] = d2 != d2 ? INFINITY : (d2 < 0.f ? 0.f : d2);
+            }
     }
 }
 
@@ -117,22 +144,26 @@ int am_exact_knn_radii(const float* X, int64_t N, int64_t ldx, const float* Y, i
     const int k1 = k + 1;
 #pragma omp parallel
     {
-        float* acc = (float*)malloc(sizeof(float) * M);
+        float* acc = (float*)malloc(sizeof(float) * M * ROWS_AT_ONCE);
         float* best = (float*)malloc(sizeof(float) * k1);
-#pragma omp for schedule(dynamic, 16)
-        for (int64_t i = 0; i < N; ++i) {
-            d2_row(X + i * ldx, xn[i], D, Yt, yn, M, ord, n, acc);
-            for (int s = 0; s < k1; ++s) best[s] = INFINITY;
-            for (int64_t j = 0; j < M; ++j) {
-                float v = acc[j];
-                if (v < best[k1 - 1]) {
-                    int s = k1 - 1;
-                    while (s > 0 && best[s - 1] > v) { best[s] = best[s - 1]; --s; }
-                    best[s] = v;
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t i0 = 0; i0 < N; i0 += ROWS_AT_ONCE) {
+            const int R = N - i0 < ROWS_AT_ONCE ? (int)(N - i0) : ROWS_AT_ONCE;
+            d2_rows(X + i0 * ldx, ldx, R, xn + i0, D, Yt, yn, M, ord, n, acc);
+            for (int r = 0; r < R; ++r) {
+                const float* row = acc + (size_t)r * M;
+                for (int s = 0; s < k1; ++s) best[s] = INFINITY;
+                for (int64_t j = 0; j < M; ++j) {
+                    float v = row[j];
+                    if (v < best[k1 - 1]) {
+                        int s = k1 - 1;
+                        while (s > 0 && best[s - 1] > v) { best[s] = best[s - 1]; --s; }
+                        best[s] = v;
+                    }
                 }
+                if (out_r2) out_r2[i0 + r] = best[k1 - 1];
+                out_r[i0 + r] = sqrtf(best[k1 - 1]);
             }
-            if (out_r2) out_r2[i] = best[k1 - 1];
-            out_r[i] = sqrtf(best[k1 - 1]);
         }
         free(acc);
         free(best);
@@ -158,21 +189,26 @@ int am_exact_prdc_counts(const float* R, int64_t Nr, int64_t ldr, const float* C
     memset(col_count, 0, sizeof(int32_t) * Nc);
 #pragma omp parallel
     {
-        float* acc = (float*)malloc(sizeof(float) * Nc);
+        float* acc = (float*)malloc(sizeof(float) * Nc * ROWS_AT_ONCE);
         int32_t* local = (int32_t*)calloc(Nc, sizeof(int32_t));
-#pragma omp for schedule(dynamic, 16)
-        for (int64_t i = 0; i < Nr; ++i) {
-            d2_row(R + i * ldr, rn[i], D, Ct, cn, Nc, ord, n, acc);
-            float mn = INFINITY;
-            int any = 0;
-            for (int64_t j = 0; j < Nc; ++j) {
-                const float d2 = acc[j];
-                if (d2 < mn) mn = d2;
-                any |= d2 < tc[j];
-                local[j] += d2 < tr[i];
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t i0 = 0; i0 < Nr; i0 += ROWS_AT_ONCE) {
+            const int nr = Nr - i0 < ROWS_AT_ONCE ? (int)(Nr - i0) : ROWS_AT_ONCE;
+            d2_rows(R + i0 * ldr, ldr, nr, rn + i0, D, Ct, cn, Nc, ord, n, acc);
+            for (int r = 0; r < nr; ++r) {
+                const float* row = acc + (size_t)r * Nc;
+                const int64_t i = i0 + r;
+                float mn = INFINITY;
+                int any = 0;
+                for (int64_t j = 0; j < Nc; ++j) {
+                    const float d2 = row[j];
+                    if (d2 < mn) mn = d2;
+                    any |= d2 < tc[j];
+                    local[j] += d2 < tr[i];
+                }
+                row_min[i] = sqrtf(mn);
+                row_any[i] = (uint8_t)any;
             }
-            row_min[i] = sqrtf(mn);
-            row_any[i] = (uint8_t)any;
         }
 #pragma omp critical
         for (int64_t j = 0; j < Nc; ++j) col_count[j] += local[j];
