@@ -940,11 +940,21 @@ struct KnnPlan {
     int pre_windows;                // symmetric path: rows of this many top windows get a sampled bound
 };
 
-static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self) {
+static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self, bool partitioned = false) {
     static const int sym_min = env_int("AM_KNN_SYM_MIN_ROWS", 8192);
     static const int sym_min_dim = env_int("AM_KNN_SYM_MIN_DIM", 128);
     static const int cap_env = env_int("AM_KNN_SYM_CAP", 0);
-    static const int stride = env_int("AM_KNN_SYM_STRIDE", 16);
+    // Column sample of the bound pre-pass: every `stride`-th tile.  16 up to ~32 000 rows; larger sets keep about eight sampled
+    // 256-row tiles (stride up to 48): the pre-pass costs N x N / stride pairs, and a bound from a third of the columns queues
+    // 60 % more pairs at almost no cost (the regions grow with the stride) - 100 000 x 512: PRDC pass 25.94 -> 25.54 ms, CLAP-shaped
+    // 27.09 -> 26.52; 1M x 512: one k-NN call 650 -> 590 ms (profiles/r4/knn_sample_stride.txt).  Same results for any stride.
+    static const int stride_env = env_int("AM_KNN_SYM_STRIDE", 0);
+    int stride = 16;
+    if (stride_env > 0) stride = stride_env;
+    // (A rank of a PARTITIONED run sees an n-th of each row's columns: the bounds its own sweep publishes tighten little, the
+    // sampled bound carries the filter - with stride 48 a rank's eighth of the sweep queued 2.4x the pairs, 1.34 -> 1.56 ms.)
+    else if (self && !partitioned && knn_fast_enabled(N, D))
+        stride = (int)std::min<int64_t>(48, std::max<int64_t>(16, ceil_div(N, 256) / 8));
     const int pre_windows = 0;
     KnnPlan p;
     p.tile_rows = TB;
@@ -1336,7 +1346,7 @@ extern "C" int am_knn_list_width(int k) { return (k < 1 || k > AM_MAX_K) ? 0 : k
 
 extern "C" size_t am_knn_part_workspace_bytes(int64_t N, int D, int k) {
     if (N < 1 || D < 1 || k < 1 || k > AM_MAX_K) return 0;
-    const KnnPlan p = plan_knn(N, N, D, k, true);
+    const KnnPlan p = plan_knn(N, N, D, k, true, true);
     Carver c(nullptr, 0);
     KnnBuffers b;
     carve_knn(c, N, N, p, b);
@@ -1353,7 +1363,7 @@ static int knn_bounds_impl(const float* X, int64_t N, int64_t ld, int D, int k, 
     AM_REQUIRE(row0 >= 0 && nrows >= 1 && row0 + nrows <= N, AM_ERR_BAD_SHAPE, "row range [%lld, +%lld) outside %lld rows",
                (long long)row0, (long long)nrows, (long long)N);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const KnnPlan p = plan_knn(N, N, D, k, true);
+    const KnnPlan p = plan_knn(N, N, D, k, true, true);
     AM_REQUIRE(p.sym, AM_ERR_BAD_SHAPE, "the symmetric k-NN path does not apply to %lld x %d (see am_knn_sym_eligible)",
                (long long)N, D);
     Carver c(ws, ws_bytes);
@@ -1440,7 +1450,7 @@ static int knn_sym_part_impl(const float* X, int64_t N, int64_t ld, int D, int k
     AM_REQUIRE((int64_t)k + 1 <= N, AM_ERR_BAD_SHAPE, "k + 1 exceeds the number of rows");
     AM_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, AM_ERR_BAD_ARG, "part %d of %d", part, nparts);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const KnnPlan p = plan_knn(N, N, D, k, true);
+    const KnnPlan p = plan_knn(N, N, D, k, true, true);
     AM_REQUIRE(p.sym, AM_ERR_BAD_SHAPE, "the symmetric k-NN path does not apply to %lld x %d (see am_knn_sym_eligible)",
                (long long)N, D);
     Carver c(ws, ws_bytes);
