@@ -543,11 +543,18 @@ __global__ void knn_lists_finish_kernel(const float* __restrict__ lists, int npa
 // Exact recomputation of single rows (candidate-buffer overflow): one workgroup per row; every thread walks
 // columns j = tid, tid+256, ... with the engine's fmaf order (two columns at a time for ILP, float4 loads),
 // keeps a sorted list, and the 256 lists are merged pairwise through LDS.
+// FEW rows (fewer than the grid has workgroups; round 4): one workgroup streaming all N rows for ONE overflowed row takes
+// 10 ms at 100 000 x 512 and 100 ms at 1M - a single straggler row cost more than the whole call (2 flagged rows in 3 calls
+// at 200 000 rows: 119 instead of 93 ms per PRDC pass).  The columns of a row are then split among gridDim / rows
+// workgroups, each leaves the smallest values of its slice in split_lists, knn_fixup_merge_kernel selects.
+__device__ __forceinline__ int fixup_split(int rows, int grid) { return (rows > 0 && rows < grid) ? grid / rows : 1; }
+
 template <int KCAP>
 __global__ void __launch_bounds__(256) knn_fixup_kernel(const float* __restrict__ X, int64_t N, int64_t ld,
                                                         const float* __restrict__ xnorm, int D, int k1,
                                                         const int* __restrict__ ov_list, const int* __restrict__ ov_count,
-                                                        float* __restrict__ radii, int batched_from, int batched_cap) {
+                                                        float* __restrict__ radii, int batched_from, int batched_cap,
+                                                        float* __restrict__ split_lists) {
     extern __shared__ __attribute__((aligned(16))) float xrow[];      // D padded to a multiple of 32
     __shared__ float lists[256 * KCAP];
     const int n_ov = *ov_count;
@@ -572,7 +579,11 @@ __global__ void __launch_bounds__(256) knn_fixup_kernel(const float* __restrict_
         da = a;
         db = b;
     };
-    for (int ov = first_row + blockIdx.x; ov < n_ov; ov += gridDim.x) {
+    const int nloc = n_ov - first_row;
+    const int split = split_lists != nullptr ? fixup_split(nloc, (int)gridDim.x) : 1;
+    for (int64_t item = blockIdx.x; item < (int64_t)nloc * split; item += gridDim.x) {
+        const int ov = first_row + (int)(item / split), piece = (int)(item % split);
+        const int64_t j_begin = N * piece / split, j_end = N * (piece + 1) / split;
         const int64_t i = ov_list[ov];
         for (int k = threadIdx.x; k < dp; k += 256) xrow[k] = k < D ? X[i * ld + k] : 0.f;
         __syncthreads();
@@ -580,13 +591,13 @@ __global__ void __launch_bounds__(256) knn_fixup_kernel(const float* __restrict_
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) m[s] = INFINITY;
         const float xi = xnorm[i];
-        for (int64_t j = threadIdx.x; j < N; j += 512) {
+        for (int64_t j = j_begin + threadIdx.x; j < j_end; j += 512) {
             const int64_t j2 = j + 256;
             float da, db;
-            dot(X + j * ld, j2 < N ? X + j2 * ld : nullptr, da, db);
+            dot(X + j * ld, j2 < j_end ? X + j2 * ld : nullptr, da, db);
             const float d2a = clamp0(fmaf(-2.f, da, xi + xnorm[j]));
             if (d2a < m[KCAP - 1]) list_insert<KCAP>(m, d2a);
-            if (j2 < N) {
+            if (j2 < j_end) {
                 const float d2b = clamp0(fmaf(-2.f, db, xi + xnorm[j2]));
                 if (d2b < m[KCAP - 1]) list_insert<KCAP>(m, d2b);
             }
@@ -604,14 +615,52 @@ __global__ void __launch_bounds__(256) knn_fixup_kernel(const float* __restrict_
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            float r2 = m[0];
+            if (split > 1) {
 #pragma unroll
-            for (int s = 1; s < KCAP; ++s)
-                if (s == k1 - 1) r2 = m[s];
-            radii[i] = sqrt_rn(r2);
+                for (int s = 0; s < KCAP; ++s) split_lists[item * KCAP + s] = m[s];
+            } else {
+                float r2 = m[0];
+#pragma unroll
+                for (int s = 1; s < KCAP; ++s)
+                    if (s == k1 - 1) r2 = m[s];
+                radii[i] = sqrt_rn(r2);
+            }
         }
         __syncthreads();
     }
+}
+
+// second half of the few-rows form of knn_fixup_kernel (same grid size there): thread r merges the `split` lists of row r
+template <int KCAP>
+__global__ void __launch_bounds__(256) knn_fixup_merge_kernel(const float* __restrict__ split_lists, int k1, const int* __restrict__ ov_list,
+                                                              const int* __restrict__ ov_count, float* __restrict__ radii,
+                                                              int batched_from, int batched_cap, int fixup_grid) {
+    const int n_ov = *ov_count;
+    const int first_row = (batched_from > 0 && n_ov >= batched_from) ? (n_ov < batched_cap ? n_ov : batched_cap) : 0;
+    const int nloc = n_ov - first_row, split = fixup_split(nloc, fixup_grid);
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (split <= 1 || r >= nloc) return;
+    float m[KCAP];
+#pragma unroll
+    for (int s = 0; s < KCAP; ++s) m[s] = INFINITY;
+    for (int piece = 0; piece < split; ++piece)
+        for (int s = 0; s < KCAP; ++s) list_insert<KCAP>(m, split_lists[((int64_t)r * split + piece) * KCAP + s]);
+    float r2 = m[0];
+#pragma unroll
+    for (int s = 1; s < KCAP; ++s)
+        if (s == k1 - 1) r2 = m[s];
+    radii[ov_list[first_row + r]] = sqrt_rn(r2);
+}
+
+constexpr int KNN_FIXUP_GRID = 256;
+// both halves; split_lists: KNN_FIXUP_GRID x KCAP floats
+template <int KCAP>
+static void launch_knn_fixup(const float* X, int64_t N, int64_t ld, const float* xn, int D, int k1, const int* ov_list, const int* ov_count,
+                             float* radii, int batched_from, int batched_cap, float* split_lists, hipStream_t st) {
+    hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(KNN_FIXUP_GRID), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
+                       xn, D, k1, ov_list, ov_count, radii, batched_from, batched_cap, split_lists);
+    hipLaunchKernelGGL(knn_fixup_merge_kernel<KCAP>, dim3(1), dim3(256), 0, st, split_lists, k1, ov_list, ov_count, radii,
+                       batched_from, batched_cap, KNN_FIXUP_GRID);
 }
 
 // --------------------------------------------------------- PRDC counts epilogue
@@ -916,8 +965,8 @@ static int launch_knn_sym(const float* X, int64_t N, int64_t ld, const float* xn
                        cand, cnt, cap, out_r, ov_list, ov_count, out_lists);
     AM_LAUNCH_CHECK();
     if (out_lists != nullptr) return AM_OK;            // partitioned form: fix-up happens after the lists are merged
-    hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
-                       xn, D, k1, ov_list, ov_count, out_r, 0, 0);
+    // (the per-window lists have been merged: their memory - at least N x KCAP floats - holds the split lists of a few-row fix-up)
+    launch_knn_fixup<KCAP>(X, N, ld, xn, D, k1, ov_list, ov_count, out_r, 0, 0, partial, st);
     AM_LAUNCH_CHECK();
     return AM_OK;
 }

@@ -1258,8 +1258,8 @@ static int run_knn_fixup(const float* X, int64_t N, int64_t ld, const float* xn,
     int rc;
     const int fcap = (int)x.capacity;
     const int64_t ldr = (D + 3) / 4 * 4;
-    hipLaunchKernelGGL(knn_fixup_kernel<KCAP>, dim3(256), dim3(256), (size_t)((D + 31) / 32 * 32) * sizeof(float), st, X, N, ld,
-                       xn, D, k1, ov_list, ov_count, out_r, KNN_FIX_BATCH_FROM, fcap);
+    // (x.partial, at least capacity x KCAP floats, is free until the batched form's general kernel below: split lists of a few rows)
+    launch_knn_fixup<KCAP>(X, N, ld, xn, D, k1, ov_list, ov_count, out_r, KNN_FIX_BATCH_FROM, fcap, x.partial, st);
     hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(1024), dim3(256), 0, st, X, ld, D, xn, ov_list, ov_count, KNN_FIX_BATCH_FROM, fcap,
                        x.rows, ldr, x.norms);
     AM_LAUNCH_CHECK();

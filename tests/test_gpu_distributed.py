@@ -105,6 +105,27 @@ def test_partitioned_symmetric_knn_bit_identical(nparts, k, rows, path):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("flagged", [1, 3, 31, 40, 300])
+def test_few_flagged_rows_are_split_among_workgroups(flagged):
+    """One workgroup streaming the whole set for ONE flagged row took 10 ms at 100 000 x 512 (100 ms at 1M): fewer flagged rows
+    than the fix-up's grid has workgroups are split by columns among them (1 row: 256 slices, 3 rows: 85 each - a row count
+    that does not divide - 31: 8 each); from 32 rows on the batched form takes over, a few hundred stay one workgroup each
+    there.  Same radii as the one-GPU call, bit for bit, and the time of one row stays far below the single-workgroup form's."""
+    import time
+    import numpy as np
+    from audio_metrics_amd import hip_ops as ops
+    k, rows, d, nparts = 5, 20011, 200, 2
+    x = torch.as_tensor(gi.randn(77, rows, d)).to("cuda:0")
+    want = ops.knn_radii(x, k).cpu().numpy()
+    bounds = torch.cat([ops.knn_bounds(x, k, lo, hi - lo) for lo, hi in
+                        [(rows * p // nparts, rows * (p + 1) // nparts) for p in range(nparts)]])
+    lists = torch.stack([ops.knn_sym_part(x, k, p, nparts, bounds) for p in range(nparts)])
+    pick = np.random.default_rng(flagged).choice(rows, flagged, replace=False)
+    lists[flagged % nparts, torch.as_tensor(pick, device="cuda:0"), 0] = float("nan")
+    got = ops.knn_lists_finish(lists, x, k).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.parametrize("kind,nparts", [("block", 3), ("hub", 4), ("flag_everything", 2)])
 def test_partitioned_knn_with_identical_rows(kind, nparts):
     """Blocks of identical rows in the partitioned form: their rows overflow the ranks' candidate buffers and come back flagged.
