@@ -22,6 +22,9 @@ def am():
 
 def make(am, metrics, **kw):
     c = gi.E2E
+    # one embedder replica unless a test asks otherwise: the goldens were produced by ONE process, and the kernel-distance
+    # subsets are drawn by row index - on a box with several GPUs the default (None = every visible GPU) stores another order
+    kw.setdefault("device_indices", [0])
     return am.AudioMetrics(metrics=metrics, embedder=gi.NumpyEmbedder(c["dim"], c["sr"]), mix_function=gi.e2e_mix,
                            win_dur=c["win_dur"], **kw)
 
