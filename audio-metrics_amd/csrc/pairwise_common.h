@@ -161,6 +161,7 @@ constexpr unsigned FAST_HOLE = 0xffffffffu;                                  // 
 template <int KCAP, class Lane = LaneInfo, int TBX = TB, int MT = 2>
 struct KnnFastEpilogue {
     static constexpr int NWAVES = TBX == WIDE_TILE_ROWS ? 8 : 4;   // waves per workgroup
+    static constexpr int NT = Lane::NT;                             // 32-row P tiles per wave
     const float* qnorm;
     const float* thr;
     int64_t n, pblock;
@@ -180,10 +181,10 @@ struct KnnFastEpilogue {
     int* cnt;
     int cap;
     float dsc;                  // -2 / (operand scale)^2
-    unsigned prow[2];           // (row indices fit 32 bits: the filter path is limited to < 2^31 rows)
-    float xn[2], flt[2];        // xn = +inf for rows past the end: every approximate value is +inf and passes no test
+    unsigned prow[NT];           // (row indices fit 32 bits: the filter path is limited to < 2^31 rows)
+    float xn[NT], flt[NT];        // xn = +inf for rows past the end: every approximate value is +inf and passes no test
     float e2c, e2n;             // 2 E_i = e2c * |x_i|^2 + e2n  (recomputed per tile group: two registers less than keeping it)
-    float best[2][KCAP];        // ascending; the first KCAP - (k+1) slots are -inf pads, so best[KCAP-1] is the (k+1)-th smallest
+    float best[NT][KCAP];        // ascending; the first KCAP - (k+1) slots are -inf pads, so best[KCAP-1] is the (k+1)-th smallest
     float aux_n, aux_t;
     const Lane& L;
 
@@ -230,7 +231,7 @@ struct KnnFastEpilogue {
             aux[(t & 1) * 2 * TBX + TBX + L.tid] = aux_t;
         }
     }
-    __device__ __forceinline__ void finish(int t, int64_t qtile, f32x16 (&acc)[MT][2]) {
+    __device__ __forceinline__ void finish(int t, int64_t qtile, f32x16 (&acc)[MT][NT]) {
         const float* a = aux + (t & 1) * 2 * TBX + L.wm * (MT * 32) + L.h * 4;
         const bool mirror = qtile != pblock;                // the diagonal tile holds both directions itself
 #ifdef AM_DEV_KNOBS
@@ -248,7 +249,7 @@ struct KnnFastEpilogue {
                 tq[g4] = *reinterpret_cast<const f32x4*>(a + TBX + mt * 32 + g4 * 8);
             }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NT; ++nt) {
                 // Fast path: per group of four accumulator registers (four columns) the smallest value and the smallest margin
                 // against the columns' bounds.  The row's own norm is added to the minima, not to every element (the extra
                 // rounding is one of those fast_c's 2^-19 term pays for).
@@ -324,5 +325,23 @@ int launch_knn_wide(int kcap, unsigned nwg, const float* Xb, int64_t N, int64_t 
                     int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
                     uint2* wgq, float* wgv, int qcap, int* wgq_count, int part, int nparts, float fc, uint2* ovq, float* ovv,
                     unsigned long long* ovn, int ovcap, const int* skip, int* region_counter, hipStream_t st);
+
+// ---- the same two kernels on the operand-stationary engine (pairwise_pstat.hip, pstat_engine.h): rows of up to 512 f16
+bool pstat_supported(int Dh);
+int launch_cross_pstat(bool want_min, unsigned blocks, const float* Rb, int64_t Nr, int64_t ldr, const float* rnorm, const float* rthr,
+                       const float* Cb, int64_t Nc, int64_t ldc, const float* cnorm, const float* cthr, int Dh, int nchunks,
+                       int grp_rows, const unsigned* maxn, unsigned* rmin_approx, unsigned* row_any, unsigned* row_cover,
+                       int32_t* col_count, uint2* wgq, int qcap, int* wgq_count, uint2* items, uint2* ovq, int* ov_count, int ovcap,
+                       int* fail, float fc, hipStream_t st);
+int launch_knn_pstat(int kcap, unsigned nwg, const float* Xb, int64_t N, int64_t ldh, const float* xnorm, float* thr, int Dh,
+                     int win_tiles, int nwin, int per_win, int k1, const unsigned* maxn, float* partial, int* cnt, int cap,
+                     uint2* wgq, float* wgv, int qcap, int* wgq_count, int part, int nparts, float fc, uint2* ovq, float* ovv,
+                     unsigned long long* ovn, int ovcap, const int* skip, int* region_counter, hipStream_t st);
+// which of the two 256-row engines multiplies the tiles of the main filter passes: a pure function of the row length
+// (AM_WIDE_STATIONARY=0 in the A/B build: wide_engine.h for every shape)
+static inline bool wide_stationary(int Dh) {
+    static const int on = env_int("AM_WIDE_STATIONARY", 1);
+    return on != 0 && pstat_supported(Dh);
+}
 
 }  // namespace am

@@ -833,7 +833,9 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
         const long long limit_total = std::max<long long>(pairs / 128, 65536);
         const int limit_overflow = (int)std::min<long long>(std::max<long long>((pairs >> 22) * D, 65536), p.ovcap);
         clock_begin(AM_KERNEL_PRDC_CROSS, st);
-        if ((rc = launch_cross_wide(want_min, (unsigned)p.blocks, Rb, Nr, ldb / 2, rn, rt, Cb, Nc, ldb / 2, cn, ct, Dh, p.nchunks,
+        // rows of up to 512 f16: the operand-stationary engine (pstat_engine.h), wider ones: both operands through LDS
+        const auto launch_main = wide_stationary(Dh) ? &launch_cross_pstat : &launch_cross_wide;
+        if ((rc = launch_main(want_min, (unsigned)p.blocks, Rb, Nr, ldb / 2, rn, rt, Cb, Nc, ldb / 2, cn, ct, Dh, p.nchunks,
                                     p.grp_rows, b.maxn, b.rmin_approx, rany, rcov, col_count, b.wgq, p.qcap, b.wgq_count, b.items,
                                     b.ovq, b.ov_count, limit_overflow, fail, fast_c(D), st)) != AM_OK)
             return rc;
@@ -1509,7 +1511,8 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     static const int ovcap = std::max(0, std::min(env_int("AM_KNN_FAST_OVCAP", KNN_FAST_OVCAP), KNN_FAST_OVCAP));   // (tests shrink it)
     clock_begin(AM_KERNEL_KNN, st);
     if (p.tile_rows == WIDE_TILE_ROWS) {
-        if ((rc = launch_knn_wide(KCAP, nwg, Xb, N, ldh, b.xn, thr, Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt,
+        const auto launch_sweep = wide_stationary(Dh) ? &launch_knn_pstat : &launch_knn_wide;
+        if ((rc = launch_sweep(KCAP, nwg, Xb, N, ldh, b.xn, thr, Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt,
                                   p.cap, b.wgq, f.wgv, qcap, b.wgq_count, part, nparts, fast_c(D), f.ovq, f.ovv, f.ovn, ovcap,
                                   skip_sweep, region_counter, st)) != AM_OK)
             return rc;

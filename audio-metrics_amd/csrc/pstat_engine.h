@@ -1,0 +1,216 @@
+// Operand-stationary form of the 256-row f16 filter engine (round 5): the workgroup's P block never moves again.
+//
+// wide_engine.h streams BOTH operands of a 256 x 256 tile through LDS: 64 KB of LDS-DMA and 24 fragment reads per wave for
+// every 8.4 MFLOP of a CU, and its stage takes 2.18 us (L2-missing operands, the real kernels' regime) for 1.0 us of MFMA
+// time - the fill path, not the instruction order, bounds it (rounds 2-4).  A filter kernel's work item pairs ONE
+// 256-row P block with MANY Q tiles, so here the P block is read once, straight into registers, as MFMA B fragments:
+//   * 512 threads = 8 wave64; wave w owns P rows 32 w .. 32 w + 31 for the whole inner dimension: KSLABS * 4 fragments of
+//     16 B per lane (128 registers at D = 512), loaded with buffer loads at the start of the work item and never re-read;
+//   * a stage is a 64-element slab of 128 Q rows (half a 256-row tile) = 16 KB, eight of them make a unit (half tile x D = 512);
+//     a wave multiplies its 32 P rows with all 128 Q rows: 4 x 1 MFMA tiles, 64 accumulator registers, 16 MFMAs and 16
+//     fragment reads per stage (Q only);
+//   * the Q slabs travel through a ring of four 16-KB LDS slots by LDS-DMA, three stages ahead, two pieces per wave and
+//     stage, with COUNTED vmcnt and raw s_barrier: the barrier at the end of stage g publishes stage g + 2, so the first
+//     fragments of stage g + 1 are read under the last MFMAs of stage g and no DMA is ever drained inside a unit;
+//   * one set of four Q fragments per wave: fragment m of the next k-step is read right behind the MFMA that used fragment m.
+// Per 8.4 MFLOP the load path moves 32 KB instead of 64 KB, and the L2 of an XCD only has to hold the Q window its 32
+// workgroups walk in lockstep - the 32 P blocks (8 MB against 4 MB of L2) that thrashed it are gone.
+// tools/ubench/pstat.hip (random f16 operands, same unit): 1.55-1.60 us per 8.4 MFLOP against 1.73 (L2-resident source) /
+// 2.19 (200 MB source) for wide_engine.h's adopted schedule on the same box (profiles/r5/ubench_pstat.txt).
+//
+// LDS image of a slot: 128 rows of 128 B, 16-B chunks XOR-swizzled by (row >> 1) & 7 (wide_engine.h).  MFMA roles, k order and
+// therefore every accumulator value are those of wide_engine.h: P rows lane-local (MFMA column = lane & 31), Q rows in the
+// registers, logical chunk 2c + h of slab kt in k-step 4 kt + c.
+//
+// Hazards (MI355X_MICROARCH.md, "LDS-DMA requests stay in flight across s_barrier"):
+//   RAW  stage g + 2 is read (first: the pre-read at the end of stage g + 1) only after the barrier that ends stage g, before
+//        which every wave has waited for its own pieces of that stage (vmcnt(PIECES): only the pieces of stage g + 3, issued
+//        during stage g, may still be in flight);
+//   WAR  the pieces of stage g + 3 are issued during stage g into the slot stage g - 1 was read from; every wave's reads of
+//        stage g - 1 had returned (they fed its MFMAs) before it arrived at the barrier that ends stage g - 1.
+#pragma once
+#include "wide_engine.h"
+
+namespace am {
+
+constexpr int PQ_ROWS = 128;                          // Q rows of a stage: half a 256-row tile
+constexpr int PSTAGE_WORDS = PQ_ROWS * WROW;          // 16 KB
+constexpr int PRING = 4;
+constexpr int PTHREADS = 512;
+// Of a P row's KSLABS 64-element slabs the first PREG_SLABS live in registers (16 per slab); slabs 7 and 8 would leave
+// the epilogues 48 registers beside 64 accumulators and the compiler spills P fragments into the main loop - they stay in LDS
+// instead (32 KB per slab, each wave reading only its own 32 rows: no barrier involved), one extra ds_read_b128 per k-step.
+constexpr int PREG_SLABS = 6;
+constexpr int pstat_lds_slabs(int kslabs) { return kslabs > PREG_SLABS ? kslabs - PREG_SLABS : 0; }
+constexpr int pstat_lds_words(int kslabs) { return PRING * PSTAGE_WORDS + pstat_lds_slabs(kslabs) * WTB * WROW; }   // 64 KB + 32 KB per LDS slab
+
+// Lane geometry the epilogues see.  `wm` = which 128-row half of the Q tile the accumulators of the CURRENT finish() call belong
+// to (the engine sets it; in wide_engine.h it is a property of the wave), NT = 32-row P tiles per wave.
+struct PLane {
+    static constexpr int NT = 1;
+    static constexpr int LISTS = 2;                   // partial per-row lists after the sweep: the two lane halves
+    int tid, lane, wave, wm, r, h;
+    __device__ __forceinline__ PLane() {
+        tid = threadIdx.x;
+        lane = tid & 63;
+        wave = tid >> 6;
+        wm = 0;
+        r = lane & 31;
+        h = lane >> 5;
+    }
+    __device__ __forceinline__ int prow(int) const { return wave * 32 + r; }          // row of the P block this lane owns
+    __device__ __forceinline__ int list_slot() const { return h; }
+};
+
+template <int N>
+__device__ __forceinline__ void pstat_wait() {        // vmcnt(N) and lgkmcnt(0): the stage's own LDS writes (side data) are out too
+    static_assert(N >= 0 && N < 64, "vmcnt");
+    __builtin_amdgcn_s_waitcnt(0x0070 | (N & 15) | ((N >> 4) << 14));
+}
+
+// Q, P: f16 matrices viewed as f32 words (ld in words), rows of KSLABS * 32 words.  tmap(t) = index of the 256-row Q tile that
+// local tile t multiplies; P block = rows prow0 .. prow0 + 255.  Epi:
+//   aux_issue(t, qtile) / aux_commit(t)   per-TILE side data through LDS (as in wide_engine.h)
+//   finish(t, qtile, acc[4][1])           once per HALF tile, L.wm telling which
+template <int KSLABS, class TileMap, class Epi>
+__device__ __forceinline__ void pstat_pipeline(const float* __restrict__ Q, int64_t nq, int64_t ldq, const TileMap& tmap,
+                                               const float* __restrict__ P, int64_t np, int64_t ldp, int64_t prow0, int ntiles,
+                                               float* __restrict__ lds, PLane& L, Epi& epi) {
+    static_assert(KSLABS >= 1 && KSLABS <= 8, "P fragments of at most 512 f16 per row fit the register file");
+    constexpr int KREG = KSLABS < PREG_SLABS ? KSLABS : PREG_SLABS;      // slabs of the P rows held in registers
+    constexpr int KLDS = KSLABS - KREG;                                   // ... and in LDS
+    constexpr int KSTEPS = KREG * 4;
+    constexpr int PIECES = 2;                         // 1-KB LDS-DMA pieces per wave and stage
+    constexpr int DEPTH = 3;                          // stages in flight ahead of the one being multiplied
+    const int wave = __builtin_amdgcn_readfirstlane(L.wave);
+
+    // ---- the stationary operand
+    f32x4 pf[KSTEPS];
+    {
+        const TileRsrc prs = make_wide_rsrc(P, ldp, np, prow0, 0);
+        const unsigned vop = (unsigned)(((int64_t)(wave * 32 + L.r) * ldp + L.h * 4) * 4);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+            pf[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs.rsrc, (int)vop, s * 32, 0));
+        // the slabs kept in LDS: [slab][256 rows][128 B], swizzled like a Q slot; this wave's 32 rows = 4 pieces per slab
+        const int lr8 = L.lane >> 3, s8 = L.lane & 7;
+#pragma unroll
+        for (int sl = 0; sl < KLDS; ++sl)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wave * 32 + i * 8 + lr8;
+                const unsigned vo = (unsigned)(((int64_t)row * ldp + (s8 ^ ((row >> 1) & 7)) * 4) * 4);
+                lds_direct_b128(prs, lds + PRING * PSTAGE_WORDS + sl * WTB * WROW + (wave * 32 + i * 8) * WROW, vo, (unsigned)((KREG + sl) * 128));
+            }
+    }
+    const float* plds = lds + PRING * PSTAGE_WORDS + wave * 32 * WROW;     // this wave's rows of LDS slab 0
+
+    // ---- Q slabs: piece p = 8 rows x 128 B; wave w fetches pieces 2 w, 2 w + 1 (rows 16 w .. 16 w + 15 of the half tile)
+    const int lr = L.lane >> 3, slot8 = L.lane & 7;
+    unsigned voq[2];                                  // even / odd piece: the swizzle of a row depends on (row >> 1) & 7
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int row = par * 8 + lr;
+        voq[par] = (unsigned)(((int64_t)row * ldq + (slot8 ^ ((row >> 1) & 7)) * 4) * 4);
+    }
+    const unsigned wave_soff = (unsigned)((int64_t)wave * 16 * ldq * 4), half_soff = (unsigned)((int64_t)PQ_ROWS * ldq * 4);
+    const int64_t q_tiles_total = (nq + WTB - 1) / WTB;
+    auto qtile_of = [&](int t) -> int64_t { return t < ntiles ? tmap(t) : q_tiles_total; };   // past the end: empty descriptor
+    int ft = 0, fh = 0, fk = 0, fslot = 0;            // (tile, half, slab, ring slot) of the stage being fetched
+    TileRsrc qrs = make_wide_rsrc(Q, ldq, nq, qtile_of(0) * WTB);
+    auto fetch_stage = [&](int i) {                   // piece i of the stage under the fetch cursor
+        float* dst = lds + fslot * PSTAGE_WORDS + (wave * 2 + i) * 8 * WROW;
+        lds_direct_b128(qrs, dst, voq[i], (unsigned)(fk * 128) + (fh ? half_soff : 0u) + wave_soff);
+    };
+    auto advance_fetch = [&]() {
+        fslot = (fslot + 1) & (PRING - 1);
+        if (++fk == KSLABS) {
+            fk = 0;
+            fh ^= 1;
+            if (fh == 0) {
+                ++ft;
+                qrs = make_wide_rsrc(Q, ldq, nq, qtile_of(ft) * WTB);
+            }
+        }
+    };
+
+    // fragment addresses: logical 16-B chunk 2c+h of row r sits in slot (2c+h) ^ ((r >> 1) & 7)
+    const int sw = (L.r >> 1) & 7;
+    int coff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) coff[c] = L.r * WROW + ((2 * c + L.h) ^ sw) * 4;
+    auto qfrag = [&](int ring_slot, int c, int m) -> f32x4 {
+        return *reinterpret_cast<const f32x4*>(lds + ring_slot * PSTAGE_WORDS + m * 32 * WROW + coff[c]);
+    };
+
+    f32x16 acc[4][1];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // prologue: DEPTH stages in flight, the first two landed and published
+#pragma unroll
+    for (int g = 0; g < DEPTH; ++g) {
+        fetch_stage(0);
+        fetch_stage(1);
+        advance_fetch();
+    }
+    epi.aux_issue(0, qtile_of(0));
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): side data (and the P fragments) are here
+    epi.aux_commit(0);
+    pstat_wait<0>();
+    __builtin_amdgcn_s_barrier();
+
+    // ONE fragment set: the fragment of row tile m for the next k-step is read right behind the MFMA that used this one
+    // (ubench: as fast as two sets read a k-step ahead - 1.49-1.50 us per 8.4 MFLOP - and sixteen registers less)
+    f32x4 q[4];
+    f32x4 pl[2];                                      // P fragments of the LDS slabs, read one k-step ahead
+    int slot = 0;                                     // ring slot of the stage being multiplied
+#pragma unroll
+    for (int m = 0; m < 4; ++m) q[m] = qfrag(0, 0, m);
+    const int units = 2 * ntiles;
+    for (int u = 0; u < units; ++u) {
+        const int t = u >> 1;
+        const bool second = (u & 1) != 0;
+#pragma unroll
+        for (int ks = 0; ks < KSLABS; ++ks) {
+            const bool last_stage = ks == KSLABS - 1;
+            const int next_slot = (slot + 1) & (PRING - 1);
+            if (last_stage && second && t + 1 < ntiles) epi.aux_issue(t + 1, qtile_of(t + 1));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int step = ks * 4 + c;          // k-step of the unit; steps >= KSTEPS take their P fragment from LDS
+                if (KLDS > 0 && step + 1 >= KSTEPS && step + 1 < KSLABS * 4)
+                    pl[(step + 1) & 1] = *reinterpret_cast<const f32x4*>(plds + ((step + 1) / 4 - KREG) * WTB * WROW + coff[(step + 1) & 3]);
+                if (KLDS > 0 && step == 0 && KSTEPS == 0) pl[0] = *reinterpret_cast<const f32x4*>(plds + coff[0]);
+                const f32x4 pfrag = step < KSTEPS ? pf[step < KSTEPS ? step : 0] : pl[step & 1];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, q[m]), __builtin_bit_cast(f16x8, pfrag),
+                                                                         (ks == 0 && c == 0) ? zero : acc[m][0], 0, 0, 0);
+                    if (c < 3) q[m] = qfrag(slot, c + 1, m);
+                    else if (!last_stage) q[m] = qfrag(next_slot, 0, m);     // published by the barrier of the stage before
+                    if (m == 1 && (c & 1) == 0) fetch_stage(c >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            advance_fetch();
+            if (last_stage) {
+                L.wm = second ? 1 : 0;
+                epi.finish(t, qtile_of(t), acc);
+                if (second && t + 1 < ntiles) epi.aux_commit(t + 1);
+            }
+            // this wave's pieces of stage g + 2 have landed; the barrier publishes that stage
+            pstat_wait<PIECES>();
+            __builtin_amdgcn_s_barrier();
+            slot = next_slot;
+            if (last_stage) {                         // a unit's first fragments are read behind its predecessor's epilogue:
+#pragma unroll                                        // no fragment register is live across the epilogue
+                for (int m = 0; m < 4; ++m) q[m] = qfrag(slot, 0, m);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // the (empty) fetches past the end: nothing in flight when LDS is reused
+    __syncthreads();
+}
+
+}  // namespace am

@@ -47,6 +47,7 @@ constexpr int ENGINE_LDS_FLOATS = 2 * STAGE_FLOATS;
 constexpr int ENGINE_THREADS = 256;
 
 struct LaneInfo {
+    static constexpr int NT = 2;                 // 32-row P tiles per wave (pstat_engine.h: 1)
     int tid, lane, wm, wn, r, h;
     __device__ __forceinline__ LaneInfo() {
         tid = threadIdx.x;

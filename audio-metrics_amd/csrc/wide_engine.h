@@ -38,6 +38,8 @@ constexpr int WSTAGE_WORDS = 2 * WTILE_WORDS;         // Q slab then P slab
 constexpr int WENGINE_LDS_WORDS = 2 * WSTAGE_WORDS;   // two stages, 128 KB
 
 struct WLane {
+    static constexpr int NT = 2;                      // 32-row P tiles per wave
+    static constexpr int LISTS = 4;                   // partial per-row lists after a sweep: Q half x lane half
     int tid, lane, wave, wm, wn, r, h;
     __device__ __forceinline__ WLane() {
         tid = threadIdx.x;
@@ -48,6 +50,8 @@ struct WLane {
         r = lane & 31;
         h = lane >> 5;
     }
+    __device__ __forceinline__ int prow(int nt) const { return wn * 64 + nt * 32 + r; }   // row of the P block behind acc[.][nt]
+    __device__ __forceinline__ int list_slot() const { return wm * 2 + h; }
 };
 
 // descriptor over the valid rows of a 256-row tile starting at row0 (rows past the end read as zero)

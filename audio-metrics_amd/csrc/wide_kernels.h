@@ -1,0 +1,430 @@
+// Bodies of the two 256-row f16 FILTER kernels of the PRDC path - the membership filter and the symmetric k-NN sweep -
+// written once over an ENGINE policy (which pipeline multiplies the tiles, what its lanes own):
+//   WideEng          wide_engine.h   both operands streamed through LDS, a wave owns 128 Q x 64 P rows   (pairwise_wide.hip)
+//   PstatEng<KSLABS> pstat_engine.h  P block stationary in registers, a wave owns 128 Q x 32 P rows      (pairwise_pstat.hip)
+// Algorithms, error bound and queue protocol are documented in pairwise_fast.h, which holds the 128-row forms of the same
+// filters and everything that runs around these kernels.
+#pragma once
+#include "pairwise_common.h"
+#include "wide_engine.h"
+#include <algorithm>
+
+namespace am {
+
+// ---- the same filter on the 256 x 256 f16 engine (wide_engine.h): main pass only ---------------------------------
+constexpr int WIDE_AUX_WORDS = 6 * WTB;                                    // LDS [2][3][256]: what finish() reads
+constexpr int WIDE_RAW_WORDS = 4 * WTB;                                    // LDS [2][2][256]: DMA landing zone of the side data
+template <class Eng> constexpr size_t wide_cross_lds_bytes() { return (Eng::LDS_WORDS + WIDE_AUX_WORDS + WIDE_RAW_WORDS) * sizeof(float) + 16; }
+
+template <class Lane>
+struct CrossWideEpilogue {
+    static constexpr int NT = Lane::NT;
+    const float* qnorm;
+    const float* qthr;
+    int64_t nq;
+    float fc, rnmax_c;
+    float* aux;                 // LDS [2][3][256] : |c_j|^2, T'_j + E'_j, T'_j - E'_j of the tile
+    int32_t* col_count;
+    uint2* wgq;
+    int* qn;
+    int qcap;
+    uint2* ovq;
+    int* ov_count;
+    int ovcap;
+    int* fail;
+    float dsc;
+    int64_t prow[NT];
+    float xn[NT], thi[NT], tlo[NT], e2[NT], m[NT];
+    bool rowok[NT], anyf[NT], covf[NT];
+    float aux_n, aux_hi;
+    const Lane& L;
+
+    __device__ __forceinline__ CrossWideEpilogue(const Lane& l) : L(l) {}
+    __device__ __forceinline__ void push(int64_t i, unsigned jflag) {
+        const int slot = atomicAdd(qn, 1);
+        if (slot < qcap) {
+            wgq[slot] = make_uint2((unsigned)i, jflag);
+        } else if (*reinterpret_cast<volatile int*>(fail) == 0) {   // (see CrossFastEpilogue::push)
+            const unsigned s2 = atomicAdd(reinterpret_cast<unsigned*>(ov_count), 1u);
+            if (s2 < (unsigned)ovcap) ovq[s2] = make_uint2((unsigned)i, jflag);
+            else *fail = 1;
+        }
+    }
+    // loads only: the values are first used in aux_commit, after the stage's MFMAs (an arithmetic use here would park
+    // waves 0-3 on a full memory round trip at the start of the last stage of every tile)
+    __device__ __forceinline__ void aux_issue(int, int64_t qtile) {
+        if (L.tid < WTB) {
+            const int64_t j = qtile * WTB + L.tid;
+            const bool in = j < nq;
+            aux_n = in ? qnorm[j] : INFINITY;               // a = +inf: never below anything
+            aux_hi = in ? qthr[j] : -INFINITY;
+        }
+    }
+    __device__ __forceinline__ void aux_commit(int t) {
+        if (L.tid < WTB) {
+            float* d = aux + (t & 1) * 3 * WTB + L.tid;
+            const bool in = aux_hi > -INFINITY;               // thresholds are >= 0; -inf marks a column past the end
+            const float e = fmaf(fc, aux_n, rnmax_c);
+            d[0] = aux_n;
+            d[WTB] = in ? aux_hi + e : -INFINITY;
+            d[2 * WTB] = in ? aux_hi - e : -INFINITY;
+        }
+    }
+    // NEED_ANY = false: every row of this block already has its "any" witness - the column-threshold test (one subtraction
+    // and half a min3 per accumulator element, and the threshold loads) is not compiled in
+    template <bool WANT_MIN, bool NEED_ANY>
+    __device__ __forceinline__ void finish_impl(int t, int64_t qtile, f32x16 (&acc)[4][NT]) {
+        const float* a = aux + (t & 1) * 3 * WTB + L.wm * 128 + L.h * 4;
+        const int64_t jbase = qtile * WTB + L.wm * 128 + L.h * 4;
+#ifdef AM_DEV_KNOBS
+        if (g_wide_dbg & 2) return;                            // timing experiment: MFMA pipeline only
+#endif
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x4 yn[4], th[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                yn[g4] = *reinterpret_cast<const f32x4*>(a + mt * 32 + g4 * 8);
+                if constexpr (NEED_ANY) th[g4] = *reinterpret_cast<const f32x4*>(a + WTB + mt * 32 + g4 * 8);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                // Fast path: per group of four accumulator registers (four columns), the smallest value and the smallest margin
+                // against the column thresholds.  The row's own norm is added to the minima, not to every element (the extra
+                // rounding is one of those fast_c's 2^-19 term pays for).  (Comparing a group's minimum with the LARGEST of its
+                // four column thresholds - one subtraction per group - was measured: the thresholds of neighbouring columns
+                // differ by more than the distance distribution allows this far out in its tail, four in five groups pass
+                // such a gate, 10.6 -> 13.0 ms.)
+                float tmin4[4], marg4[4];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float tm = INFINITY, mg = INFINITY;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = fmaf(dsc, acc[mt][nt][g4 * 4 + e], yn[g4][e]);
+                        tm = fminf(tm, t);
+                        if constexpr (NEED_ANY) mg = fminf(mg, t - th[g4][e]);
+                    }
+                    tmin4[g4] = tm + xn[nt];
+                    if constexpr (NEED_ANY) marg4[g4] = mg + xn[nt];
+                }
+                const float tmin = fminf(fminf(tmin4[0], tmin4[1]), fminf(tmin4[2], tmin4[3]));
+                if constexpr (WANT_MIN) m[nt] = fminf(m[nt], fmaxf(tmin, 0.f));
+                const float prow_thr = WANT_MIN ? fmaxf(thi[nt], m[nt] + e2[nt]) : thi[nt];
+                // Gate 1, one wave-uniform branch per accumulator tile (1024 pairs).  The row direction (column counts,
+                // coverage, row minimum) has a candidate in 0.2 % of the 32 x 32 tiles of the bench problem, the "any"
+                // direction of the rows that still lack a witness in 16 % - the other tiles used to pay four group gates each.
+                {
+                    bool hit = rowok[nt] && tmin <= prow_thr;
+                    if constexpr (NEED_ANY) hit = hit || (rowok[nt] && !anyf[nt] && fminf(fminf(marg4[0], marg4[1]), fminf(marg4[2], marg4[3])) <= 0.f);
+                    if (!__any(hit)) continue;
+                }
+                // Detail path, per register group and direction, behind wave-uniform gates - those groups run without ballots
+                // and counts.  (One loop with switches, not two loops: a second unrolled copy pushes the epilogue over the
+                // compiler's unroll budget and the accumulator array into scratch.)
+                const float* alo = a + 2 * WTB + mt * 32;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const bool row_hit = __any(rowok[nt] && tmin4[g4] <= prow_thr);
+                    bool any_hit = false;
+                    if constexpr (NEED_ANY) any_hit = __any(rowok[nt] && !anyf[nt] && marg4[g4] <= 0.f);
+#ifdef AM_DEV_KNOBS
+                    if (g_wide_dbg & 8) any_hit = false;               // timing experiment: the gate's cost without its loop
+#endif
+                    if (!(row_hit || any_hit)) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int reg = g4 * 4 + e;
+                        const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[g4][e]);
+                        const int64_t j = jbase + mt * 32 + g4 * 8 + e;
+                        bool sure = false, want = false;
+                        if (row_hit) {
+                            sure = rowok[nt] && u < tlo[nt];
+                            const unsigned long long mask = __ballot(sure);
+                            if (mask != 0ull && L.lane == 0) {               // lanes 0-31: column j, lanes 32-63: column j + 4
+                                const int lo = __popcll(mask & 0xffffffffull);
+                                const int hi = __popcll(mask >> 32);
+                                if (lo) atomicAdd(col_count + j - L.h * 4, lo);
+                                if (hi) atomicAdd(col_count + j - L.h * 4 + 4, hi);
+                            }
+                            covf[nt] = covf[nt] || sure;
+                            want = rowok[nt] && !sure && u <= thi[nt];
+                            if constexpr (WANT_MIN) want = want || (rowok[nt] && u <= m[nt] + e2[nt]);
+                        }
+                        if constexpr (NEED_ANY) {
+                            if (rowok[nt] && !anyf[nt] && u <= th[g4][e]) {
+                                if (u < alo[g4 * 8 + e]) anyf[nt] = true;       // certain witness
+                                else want = true;                               // ambiguous "any"
+                            }
+                        }
+                        if (want) push(prow[nt], (unsigned)j | (sure ? FAST_COUNTED : 0u));
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <class Lane, bool WANT_MIN, bool NEED_ANY>
+struct CrossWideShim {
+    CrossWideEpilogue<Lane>& e;
+    __device__ __forceinline__ void aux_issue(int t, int64_t q) { e.aux_issue(t, q); }
+    __device__ __forceinline__ void aux_commit(int t) { e.aux_commit(t); }
+    __device__ __forceinline__ void finish(int t, int64_t q, f32x16 (&acc)[4][Lane::NT]) { e.template finish_impl<WANT_MIN, NEED_ANY>(t, q, acc); }
+};
+
+struct WideTiles {
+    int64_t q0;
+    __device__ __forceinline__ int64_t operator()(int t) const { return q0 + t; }
+};
+
+// work item = (256-row block, column chunk), XCD-grouped: block b runs on XCD b % 8; the 32 workgroups resident on an
+// XCD (one per CU) form a group of grp_rows row blocks x 32 / grp_rows chunks, so a group keeps grp_rows P blocks
+// (256 KB each) in the 4 MB L2 and fetches each Q tile once.
+struct WideWork {
+    int64_t rb, qtile0;
+    int ntiles;
+};
+inline int64_t wide_grouped_blocks_impl(int64_t row_blocks, int nchunks, int grp_rows) {
+    const int grp_chunks = 32 / grp_rows;
+    const int64_t groups = ceil_div(row_blocks, grp_rows) * ceil_div(nchunks, grp_chunks);
+    return ceil_div(groups, 8) * 8 * 32;
+}
+__device__ __forceinline__ WideWork wide_work(int64_t q_tiles, int nchunks, int64_t row_blocks, int grp_rows) {
+    const int grp_chunks = 32 / grp_rows;
+    const int64_t cgroups = (nchunks + grp_chunks - 1) / grp_chunks;
+    const int xcd = blockIdx.x & 7;
+    const int64_t seq = blockIdx.x >> 3;
+    const int64_t g = (seq >> 5) * 8 + xcd;
+    const int within = (int)(seq & 31);
+    WideWork w;
+    w.rb = (g / cgroups) * grp_rows + within / grp_chunks;
+    const int chunk = (int)((g % cgroups) * grp_chunks + within % grp_chunks);
+    w.qtile0 = 0;
+    w.ntiles = 0;
+    if (w.rb < row_blocks && chunk < nchunks) {
+        w.qtile0 = q_tiles * chunk / nchunks;
+        w.ntiles = (int)(q_tiles * (chunk + 1) / nchunks - w.qtile0);
+    }
+    return w;
+}
+
+template <class Eng, bool WANT_MIN>
+__device__ __forceinline__ void
+cross_wide_body(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const float* __restrict__ rnorm,
+                  const float* __restrict__ rthr, const float* __restrict__ Cb, int64_t Nc, int64_t ldc,
+                  const float* __restrict__ cnorm, const float* __restrict__ cthr, int Dh, int nchunks, int grp_rows,
+                  const unsigned* __restrict__ maxn, unsigned* __restrict__ rmin_approx, unsigned* __restrict__ row_any,
+                  unsigned* __restrict__ row_cover, int32_t* __restrict__ col_count, uint2* __restrict__ wgq, int qcap,
+                  int* __restrict__ wgq_count, uint2* __restrict__ items, uint2* __restrict__ ovq, int* __restrict__ ov_count,
+                  int ovcap, int* __restrict__ fail, float fc) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using Lane = typename Eng::Lane;
+    Lane L;
+    const WideWork w = wide_work((Nc + WTB - 1) / WTB, nchunks, (Nr + WTB - 1) / WTB, grp_rows);
+    // (fail already raised - by an earlier workgroup whose entries no longer fit the overflow queue's budget, see
+    // cross_fast_decide_kernel: the exact kernel will redo the whole call, the rest of this grid has nothing to add)
+    if (w.ntiles == 0 || *reinterpret_cast<volatile int*>(fail) != 0) {
+        if (L.tid == 0) wgq_count[blockIdx.x] = 0;
+        return;
+    }
+    int* qn = reinterpret_cast<int*>(lds + Eng::LDS_WORDS + WIDE_AUX_WORDS + WIDE_RAW_WORDS);
+    if (L.tid == 0) *qn = 0;
+    const float gmax = fmaxf(__uint_as_float(maxn[0]), __uint_as_float(maxn[1]));
+    CrossWideEpilogue<Lane> epi(L);
+    epi.fc = fc;
+    epi.qnorm = cnorm;
+    epi.qthr = cthr;
+    epi.nq = Nc;
+    epi.rnmax_c = fc * gmax;
+    epi.aux = lds + Eng::LDS_WORDS;
+    epi.col_count = col_count;
+    epi.wgq = wgq + (int64_t)blockIdx.x * qcap;
+    epi.qn = qn;
+    epi.qcap = qcap;
+    epi.ovq = ovq;
+    epi.ov_count = ov_count;
+    epi.ovcap = ovcap;
+    epi.fail = fail;
+    epi.dsc = half_unscale(maxn[2], maxn[3]);
+    if (blockIdx.x == 0 && L.tid == 0 && !(half_scale_ok(maxn[2]) && half_scale_ok(maxn[3]))) *fail = 1;
+    const int64_t prow0 = w.rb * WTB;
+#pragma unroll
+    for (int nt = 0; nt < Lane::NT; ++nt) {
+        const int64_t i = prow0 + L.prow(nt);
+        const bool ok = i < Nr;
+        epi.prow[nt] = i;
+        epi.rowok[nt] = ok;
+        epi.xn[nt] = ok ? rnorm[i] : 0.f;
+        const float e = fc * ((ok ? rnorm[i] : 0.f) + gmax);
+        epi.thi[nt] = ok ? rthr[i] + e : -INFINITY;
+        epi.tlo[nt] = ok ? rthr[i] - e : -INFINITY;
+        epi.e2[nt] = 2.f * e;
+        epi.m[nt] = (WANT_MIN && ok) ? __uint_as_float(rmin_approx[i]) : INFINITY;
+        epi.anyf[nt] = ok ? (row_any[i] != 0u) : true;
+        epi.covf[nt] = false;
+    }
+#ifdef AM_DEV_KNOBS
+    if (g_wide_dbg & 4) {                                      // timing experiment: no block needs the "any" test
+        CrossWideShim<Lane, WANT_MIN, false> quick{epi};
+        Eng::run(Cb, Nc, ldc, WideTiles{w.qtile0}, Rb, Nr, ldr, prow0, w.ntiles, Dh, lds, L, quick);
+    } else
+#endif
+    {
+        CrossWideShim<Lane, WANT_MIN, true> shim{epi};
+        Eng::run(Cb, Nc, ldc, WideTiles{w.qtile0}, Rb, Nr, ldr, prow0, w.ntiles, Dh, lds, L, shim);
+    }
+#pragma unroll
+    for (int nt = 0; nt < Lane::NT; ++nt) {
+        const float mn = fminf(epi.m[nt], __shfl_xor(epi.m[nt], 32));
+        const int other = __shfl_xor((int)epi.anyf[nt], 32);
+        const int other_c = __shfl_xor((int)epi.covf[nt], 32);
+        const bool any = epi.anyf[nt] || other != 0;
+        const bool cov = epi.covf[nt] || other_c != 0;
+        if (L.h == 0 && epi.rowok[nt]) {
+            if constexpr (WANT_MIN) atomicMin(rmin_approx + epi.prow[nt], __float_as_uint(mn));
+            if (any) atomicOr(row_any + epi.prow[nt], 1u);
+            if (cov) atomicOr(row_cover + epi.prow[nt], 1u);
+        }
+    }
+    __syncthreads();
+    // the region's entries in batches of 64, appended to the list of work items of cross_verify_regions_kernel
+    // (ov_count[2] = number of items; the order of the list does not matter: the verification only feeds integer atomics)
+    if (L.tid == 0) {
+        const int n = *qn < qcap ? *qn : qcap, nb = (n + 63) / 64;
+        wgq_count[blockIdx.x] = n;
+        qn[0] = n;
+        qn[1] = nb > 0 ? atomicAdd(ov_count + 2, nb) : 0;
+    }
+    __syncthreads();
+    const int n = qn[0], base = qn[1];
+    for (int t = L.tid; t * 64 < n; t += WTHREADS) items[base + t] = make_uint2(blockIdx.x, (unsigned)(t * 64));
+}
+
+
+
+// The same sweep on the 256 x 256 f16 engine (wide_engine.h): row blocks and column tiles of 256 rows, 512 threads.
+template <class Eng> constexpr size_t knn_wide_lds_bytes() { return (Eng::LDS_WORDS + 8 * WTB) * sizeof(float) + 16; }   // + aux [2][2][256] + raw [2][2][256]
+
+template <int KCAP, class Lane>
+using KnnWideEpilogue = KnnFastEpilogue<KCAP, Lane, WTB, 4>;
+
+template <class Eng, int KCAP>
+__device__ __forceinline__ void
+knn_wide_body(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float* __restrict__ xnorm, float* thr, int Dh,
+                int win_tiles, int nwin, int per_win, int k1, const unsigned* __restrict__ maxn, float* __restrict__ partial,
+                int* __restrict__ cnt, int cap, uint2* __restrict__ wgq, float* __restrict__ wgv, int qcap,
+                int* __restrict__ wgq_count, int part, int nparts, float fc, uint2* __restrict__ ovq, float* __restrict__ ovv,
+                unsigned long long* __restrict__ ovn, int ovcap, const int* __restrict__ skip, int* __restrict__ region_counter) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using Lane = typename Eng::Lane;
+    Lane L;
+    const int64_t T = (N + WTB - 1) / WTB;
+    const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
+    constexpr int NW = KnnWideEpilogue<KCAP, Lane>::NWAVES;
+    if (sw.ntiles == 0 || (skip != nullptr && *skip != 0)) {      // (skip: the data-dependent fallback took over, pairwise_fast.h)
+        if (region_counter == nullptr && L.tid <= NW) wgq_count[(int64_t)blockIdx.x * (NW + 1) + L.tid] = 0;
+        return;
+    }
+    // Queue region of this workgroup: its own index - or, in a PARTITIONED run (region_counter given), the next free one:
+    // only the workgroups of this rank's row blocks queue anything, so the memory of all regions is cut into as many (larger)
+    // regions as there are active workgroups and handed out in arrival order (the counts were zeroed by the host).  With
+    // regions indexed by workgroup a rank used 1 / nparts of them, and at 1M rows the busiest ones overflowed: 14 000 rows
+    // went through the row-at-a-time fix-up (6 - 11 s per set on 8 ranks, tools/scale_model.py).
+    int64_t region = blockIdx.x;
+    if (region_counter != nullptr) {
+        int* slot = reinterpret_cast<int*>(lds + Eng::LDS_WORDS + 8 * WTB) + 1;
+        if (L.tid == 0) *slot = atomicAdd(region_counter, 1);
+        __syncthreads();
+        region = __builtin_amdgcn_readfirstlane(*slot);
+    }
+    const float nmax = __uint_as_float(maxn[0]);
+    KnnWideEpilogue<KCAP, Lane> epi(L);
+    epi.qnorm = xnorm;
+    epi.thr = thr;
+    epi.n = N;
+    epi.pblock = sw.pb;
+    epi.aux = lds + Eng::LDS_WORDS;
+    const int wave = __builtin_amdgcn_readfirstlane(L.wave);
+    epi.wcap = qcap / (2 * NW);                       // private sub-regions: half of the workgroup's region in all
+    epi.wgq = wgq + region * qcap + wave * epi.wcap;
+    epi.wgv = wgv + region * qcap + wave * epi.wcap;
+    epi.wq = 0;
+    epi.shcap = qcap - NW * epi.wcap;                 // the shared part behind them
+    epi.shq = wgq + region * qcap + NW * epi.wcap;
+    epi.shv = wgv + region * qcap + NW * epi.wcap;
+    epi.qn = reinterpret_cast<int*>(lds + Eng::LDS_WORDS + 8 * WTB);
+    if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
+    epi.ovq = ovq;
+    epi.ovv = ovv;
+    epi.ovn = ovn;
+    epi.ovcap = ovcap;
+    epi.cnt = cnt;
+    epi.cap = cap;
+    epi.dsc = half_unscale(maxn[2], maxn[2]);
+#pragma unroll
+    for (int nt = 0; nt < Lane::NT; ++nt) {
+        const int64_t i = sw.pb * WTB + L.prow(nt);
+        epi.prow[nt] = (unsigned)i;
+        epi.xn[nt] = i < N ? xnorm[i] : INFINITY;
+        epi.e2c = 2.f * fc;
+        epi.e2n = 2.f * fc * nmax;
+        epi.flt[nt] = i < N ? __hip_atomic_load(thr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = s < KCAP - k1 ? -INFINITY : INFINITY;
+    }
+    Eng::run(Xb, N, ldh, WideTiles{sw.qa}, Xb, N, ldh, sw.pb * WTB, sw.ntiles, Dh, lds, L, epi);
+    float* mg = lds;                                   // [256][LISTS][KCAP]: the engine's buffers are free now
+    constexpr int LISTS = Lane::LISTS;
+#pragma unroll
+    for (int nt = 0; nt < Lane::NT; ++nt) {
+        float* dst = mg + (L.prow(nt) * LISTS + L.list_slot()) * KCAP;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
+    }
+    __syncthreads();
+    if (L.lane == 0) wgq_count[region * (NW + 1) + wave] = min(epi.wq, epi.wcap);
+    if (L.tid == 0) wgq_count[region * (NW + 1) + NW] = min(*epi.qn, epi.shcap);
+    if (L.tid < WTB) {
+        const int64_t i = sw.pb * WTB + L.tid;
+        if (i < N) {
+            const float* src = mg + L.tid * LISTS * KCAP;
+            float m[KCAP];
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) m[s] = src[s];
+            for (int s = KCAP; s < LISTS * KCAP; ++s)
+                if (src[s] > -INFINITY) list_insert<KCAP>(m, src[s]);
+            // CUMULATIVE list: this window's values merged with the cumulative list of the row block's previous window in
+            // processing order (the nearest higher window in which the block owned tiles; windows are dispatched in
+            // descending order) - distinct columns, so the (k+1)-th smallest still bounds the row's final value from above.
+            // One list is read (KCAP independent loads) instead of the own lists of ALL higher windows one value at a time:
+            // the compiler kept those agent-scope loads strictly serial (s_waitcnt vmcnt(0) behind each), up to 21 x KCAP
+            // L2-missing round trips at the end of every workgroup - ~10 % of the kernel at 100k rows.
+            // (A block still running, or not started, leaves +inf pads or a partly written list there: any subset is valid.)
+            int prev = -1;
+            for (int w2 = sw.W + 1; w2 < nwin && prev < 0; ++w2)
+                if (sym_item(T, win_tiles, w2, sw.pb, part, nparts).ntiles > 0) prev = w2;
+            if (prev >= 0) {
+                const float* src2 = partial + ((int64_t)prev * N + i) * KCAP;
+                float v[KCAP];
+#pragma unroll
+                for (int s = 0; s < KCAP; ++s) v[s] = __hip_atomic_load(src2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int s = 0; s < KCAP; ++s)
+                    if (v[s] > -INFINITY) list_insert<KCAP>(m, v[s]);
+            }
+            // write-through stores / agent-scope loads: other XCDs read these lists while the kernel runs
+            float* out = partial + ((int64_t)sw.W * N + i) * KCAP;
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) __hip_atomic_store(out + s, m[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float kthv = m[KCAP - 1];
+            const float bound = kthv + 2.f * fc * (xnorm[i] + nmax);
+            // (a row taken out of the sweep keeps its -inf: knn_fast_mask_flat_kernel; nobody else writes thr[i])
+            if (epi_row_in_sweep(thr, i)) atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
+        }
+    }
+}
+
+
+
+}  // namespace am
