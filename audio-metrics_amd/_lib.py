@@ -22,6 +22,8 @@ SIGNATURES = {
     "am_scatter_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "am_stats_f64_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "am_stats_f64": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
+    "am_colsum_f64": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_size_t, _P]),
+    "am_scatter_f64": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "am_stats_merge_f64": (c_int, [c_int64, _P, _P, c_int64, _P, _P, c_int, _P, _P, _P]),
     "am_stats_push_max_rows": (c_int, []),
     "am_stats_push_f32": (c_int, [_P, c_int64, c_int, c_int64, c_int64, _P, _P, _P, _P, c_int64, _P]),
@@ -59,9 +61,20 @@ SIGNATURES = {
     "am_knn_sym_part_prepared_f32": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "am_prdc_counts_prepared_f32": (c_int, [_P, c_int64, c_int64, _P, _P, c_int64, c_int64, _P, c_int, _P, _P, _P, _P, _P, _P,
                                             _P, c_size_t, _P]),
+    "am_knn_f64_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
+    "am_knn_radii_f64": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, c_int, _P, _P, c_size_t, _P]),
+    "am_prdc_f64_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "am_prdc_counts_f64": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P,
+                                   _P, c_size_t, _P]),
+    "am_kd_f64_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "am_kd_poly_f64": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, _P, _P, c_int, c_int,
+                               c_double, c_double, c_int, _P, _P, c_size_t, _P]),
+    "am_kd_rbf_f64": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, _P, _P, c_int, c_int, c_double, _P, _P,
+                              c_size_t, _P]),
     "am_eigh_workspace_bytes": (c_size_t, [c_int]),
     "am_eigh_sym_f64": (c_int, [_P, c_int, _P, _P, c_int, _P, c_size_t, _P]),
     "am_project_f64": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, c_int, _P, _P]),
+    "am_project_rows_f64": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, c_int, _P, _P]),
     "am_evaluate_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int, c_int, ctypes.c_uint]),
     "am_evaluate_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, ctypes.c_uint, c_int, _P, _P, c_int, c_int,
                                 c_double, c_double, c_int, _P, _P, _P, _P, c_size_t, _P, _P]),

@@ -249,6 +249,8 @@ class AudioMetrics:
         for side in (ref, cand):
             if rows and (side.embeddings is None or side.embeddings.shape[1] != d):
                 return None
+            if rows and side.embeddings.dtype == torch.float64:      # float64 rows (PCA output, f64 embedders): the f64 entry points
+                return None
             if tuple(side.cov.shape) != (d, d) or side.mean.device != self.device:
                 return None
         from . import distributed, hip_ops

@@ -382,7 +382,8 @@ __global__ void __launch_bounds__(256) jacobi_sort_kernel(const double* __restri
 
 // out[row][j] = sum_d (X[row][d] - mean[d]) * C[j][d]   on v_mfma_f64_16x16x4_f64: a workgroup takes 64 rows x 16
 // components, each wave 16 rows; lane (l15, l4) feeds element d = d0 + l4 of row / component l15
-__global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ X, int64_t N, int64_t ld, int D,
+template <class TX>
+__global__ void __launch_bounds__(256) project_kernel(const TX* __restrict__ X, int64_t N, int64_t ld, int D,
                                                       const double* __restrict__ mean, const double* __restrict__ C, int p,
                                                       double* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -390,7 +391,7 @@ __global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ 
     const int64_t row = (int64_t)blockIdx.x * 64 + wave * 16 + l15;
     const int comp = blockIdx.y * 16 + l15;
     const bool row_ok = row < N, comp_ok = comp < p;
-    const float* x = X + (row_ok ? row : 0) * ld;
+    const TX* x = X + (row_ok ? row : 0) * ld;
     const double* c = C + (int64_t)(comp_ok ? comp : 0) * D;
     f64x4e acc = {0, 0, 0, 0};
     for (int d0 = 0; d0 < D; d0 += 4) {
@@ -491,7 +492,17 @@ extern "C" int am_project_f64(const float* X, int64_t N, int64_t ld, int D, cons
                               double* out, am_stream_t stream) {
     AM_REQUIRE(X && mean && components && out, AM_ERR_BAD_ARG, "null pointer");
     AM_REQUIRE(N >= 1 && D >= 1 && p >= 1 && ld >= D, AM_ERR_BAD_SHAPE, "N=%lld D=%d p=%d ld=%lld", (long long)N, D, p, (long long)ld);
-    hipLaunchKernelGGL(project_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(p, 16)), dim3(256), 0,
+    hipLaunchKernelGGL(project_kernel<float>, dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(p, 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), X, N, ld, D, mean, components, p, out);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+extern "C" int am_project_rows_f64(const double* X, int64_t N, int64_t ld, int D, const double* mean, const double* components, int p,
+                                   double* out, am_stream_t stream) {
+    AM_REQUIRE(X && mean && components && out, AM_ERR_BAD_ARG, "null pointer");
+    AM_REQUIRE(N >= 1 && D >= 1 && p >= 1 && ld >= D, AM_ERR_BAD_SHAPE, "N=%lld D=%d p=%d ld=%lld", (long long)N, D, p, (long long)ld);
+    hipLaunchKernelGGL(project_kernel<double>, dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(p, 16)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), X, N, ld, D, mean, components, p, out);
     AM_LAUNCH_CHECK();
     return AM_OK;

@@ -275,6 +275,11 @@ struct KnnFastEpilogue {
                 // the four group gates of every tile and kept their outcomes as values for two later loops: ~100 VALU
                 // instructions per accumulator tile of which ~50 were flag bookkeeping.)
                 if (!__any(tmin <= pl || (mirror && mmin <= 0.f))) continue;
+#ifdef AM_DEV_KNOBS
+                if constexpr (TBX == WIDE_TILE_ROWS) {
+                    if (g_wide_dbg & 16) continue;              // timing experiment: fast path and gate only, no detail path
+                }
+#endif
                 // Gate 2 per register group, then ONE pass over the group's four registers: test, ballot, slot, store.
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {

@@ -589,34 +589,78 @@ extern "C" size_t am_stats_f64_workspace_bytes(int64_t N, int D) {
     return stats64_ws(D, plan_stats64(N, D));
 }
 
+// D above ~11 500 would need more than 65 535 triangle blocks in grid.y of the reduce (and the operands are read straight
+// from memory with a row stride): far beyond any embedding width, refused instead of failing at launch
+static int check_x64(const double* X, int64_t N, int D, int64_t ld) {
+    AM_REQUIRE(X != nullptr, AM_ERR_BAD_ARG, "X is null");
+    AM_REQUIRE(N >= 1 && D >= 1, AM_ERR_BAD_SHAPE, "X has shape %lld x %d", (long long)N, D);
+    AM_REQUIRE(D <= 8192, AM_ERR_BAD_SHAPE, "float64 statistics take rows of up to 8192 elements (D=%d)", D);
+    AM_REQUIRE(ld >= D, AM_ERR_BAD_ARG, "ld=%lld < D=%d", (long long)ld, D);
+    return AM_OK;
+}
+
+static int run_colsum64(const double* X, int64_t N, int D, int64_t ld, double scale, double* out, double* cs_part, const Stats64Plan& p,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(colsum64_partial_kernel, dim3(p.cs_blocks), dim3(256), 0, st, X, N, ld, D, p.cs_rows, cs_part);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)ceil_div(D, CSR_COLS)), dim3(256), 0, st, cs_part, p.cs_blocks, D, scale, out);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+static int run_scatter64(const double* X, int64_t N, int D, int64_t ld, const double* mean, double scale, double* out, double* sc_part,
+                         const Stats64Plan& p, hipStream_t st) {
+    hipLaunchKernelGGL(scatter64_partial_kernel, dim3((unsigned)(p.ntri * p.nslabs)), dim3(256), 0, st, X, N, ld, D, mean, p.slab_rows,
+                       p.ntri, sc_part);
+    AM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scatter64_reduce_kernel, dim3(S64_TILE * S64_TILE / 256, (unsigned)p.ntri), dim3(256), 0, st, sc_part,
+                       p.nslabs, p.ntri, D, scale, out);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+extern "C" int am_colsum_f64(const double* X, int64_t N, int D, int64_t ld, double* colsum, void* ws, size_t ws_bytes, am_stream_t stream) {
+    int rc;
+    if ((rc = check_x64(X, N, D, ld)) != AM_OK) return rc;
+    AM_REQUIRE(colsum != nullptr, AM_ERR_BAD_ARG, "colsum is null");
+    const Stats64Plan p = plan_stats64(N, D);
+    Carver c(ws, ws_bytes);
+    double* cs_part = c.take<double>((size_t)p.cs_blocks * D);
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    return run_colsum64(X, N, D, ld, 1.0, colsum, cs_part, p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int am_scatter_f64(const double* X, int64_t N, int D, int64_t ld, const double* mean, double* scatter, void* ws, size_t ws_bytes,
+                              am_stream_t stream) {
+    int rc;
+    if ((rc = check_x64(X, N, D, ld)) != AM_OK) return rc;
+    AM_REQUIRE(mean && scatter, AM_ERR_BAD_ARG, "mean/scatter is null");
+    const Stats64Plan p = plan_stats64(N, D);
+    Carver c(ws, ws_bytes);
+    c.take<double>((size_t)p.cs_blocks * D);
+    double* sc_part = c.take<double>((size_t)p.nslabs * p.ntri * S64_TILE * S64_TILE);
+    AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    return run_scatter64(X, N, D, ld, mean, 1.0, scatter, sc_part, p, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int am_stats_f64(const double* X, int64_t N, int D, int64_t ld, double* mean, double* cov, void* ws, size_t ws_bytes,
                             am_stream_t stream) {
-    AM_REQUIRE(X && mean && cov, AM_ERR_BAD_ARG, "null pointer");
-    AM_REQUIRE(N >= 1 && D >= 1, AM_ERR_BAD_SHAPE, "X has shape %lld x %d", (long long)N, D);
-    AM_REQUIRE(ld >= D, AM_ERR_BAD_ARG, "ld=%lld < D=%d", (long long)ld, D);
+    int rc;
+    if ((rc = check_x64(X, N, D, ld)) != AM_OK) return rc;
+    AM_REQUIRE(mean && cov, AM_ERR_BAD_ARG, "mean/cov is null");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Stats64Plan p = plan_stats64(N, D);
     Carver c(ws, ws_bytes);
     double* cs_part = c.take<double>((size_t)p.cs_blocks * D);
     double* sc_part = c.take<double>((size_t)p.nslabs * p.ntri * S64_TILE * S64_TILE);
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
-    hipLaunchKernelGGL(colsum64_partial_kernel, dim3(p.cs_blocks), dim3(256), 0, st, X, N, ld, D, p.cs_rows, cs_part);
-    AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)ceil_div(D, CSR_COLS)), dim3(256), 0, st, cs_part, p.cs_blocks, D,
-                       1.0 / (double)N, mean);
-    AM_LAUNCH_CHECK();
+    if ((rc = run_colsum64(X, N, D, ld, 1.0 / (double)N, mean, cs_part, p, st)) != AM_OK) return rc;
     if (N == 1) {                                          // data.py:40-42
         hipLaunchKernelGGL(zero_f64_kernel, dim3((unsigned)ceil_div((int64_t)D * D, 256)), dim3(256), 0, st, cov, (int64_t)D * D);
         AM_LAUNCH_CHECK();
         return AM_OK;
     }
-    hipLaunchKernelGGL(scatter64_partial_kernel, dim3((unsigned)(p.ntri * p.nslabs)), dim3(256), 0, st, X, N, ld, D, mean, p.slab_rows,
-                       p.ntri, sc_part);
-    AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scatter64_reduce_kernel, dim3(S64_TILE * S64_TILE / 256, (unsigned)p.ntri), dim3(256), 0, st, sc_part,
-                       p.nslabs, p.ntri, D, 1.0 / (double)(N - 1), cov);
-    AM_LAUNCH_CHECK();
-    return AM_OK;
+    return run_scatter64(X, N, D, ld, mean, 1.0 / (double)(N - 1), cov, sc_part, p, st);
 }
 
 extern "C" int am_stats_merge_f64(int64_t n1, const double* mean1, const double* cov1, int64_t n2, const double* mean2,

@@ -118,6 +118,9 @@ struct CrossWideEpilogue {
                     bool hit = rowok[nt] && tmin <= prow_thr;
                     if constexpr (NEED_ANY) hit = hit || (rowok[nt] && !anyf[nt] && fminf(fminf(marg4[0], marg4[1]), fminf(marg4[2], marg4[3])) <= 0.f);
                     if (!__any(hit)) continue;
+#ifdef AM_DEV_KNOBS
+                    if (g_wide_dbg & 16) continue;                 // timing experiment: fast path and gate only, no detail path
+#endif
                 }
                 // Detail path, per register group and direction, behind wave-uniform gates - those groups run without ballots
                 // and counts.  (One loop with switches, not two loops: a second unrolled copy pushes the epilogue over the

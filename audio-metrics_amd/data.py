@@ -5,9 +5,9 @@ Host-side mirror of the reference's ``AudioMetricsData``
 argument meaning, same quirks - but every tensor lives in MI355X HBM and every
 computation is a call into the HIP library:
 
-  add / recompute_stats  -> am_stats_f32          (data.py:37-58)
-  _update_stats          -> am_stats_merge_f64    (data.py:77-94)
-  get_radii              -> am_knn_radii_f32      (data.py:60-66, prdc.py:4-14)
+  add / recompute_stats  -> am_stats_f32 / am_stats_f64        (data.py:37-58; in the dtype of the rows, as the reference)
+  _update_stats          -> am_stats_merge_f64                 (data.py:77-94)
+  get_radii              -> am_knn_radii_f32 / am_knn_radii_f64 (data.py:60-66, prdc.py:4-14)
   _update_embeddings     -> amortised-doubling HBM buffer instead of the
                             reference's per-batch torch.cat (data.py:68-72)
 """
@@ -46,16 +46,15 @@ class AudioMetricsData:
     def __init__(self, store_embeddings=True, device=None):
         self.n = self.mean = self.cov = None
         self.store_embeddings = bool(store_embeddings)
-        self._embeddings = None           # [n, D] f32 view of self._buf (property `embeddings`)
-        self.radii = {}                   # "radii_{k}" -> f32[n]
+        self._embeddings = None           # [n, D] view of self._buf (property `embeddings`): f32, or f64 once float64 rows came in
+        self.radii = {}                   # "radii_{k}" -> [n] in the dtype of the rows
         self.dtype = torch.float64        # dtype of the statistics
         self._device = torch.device(device) if device is not None else None
-        self._buf = None                  # [capacity, ld] f32, rows 16-B aligned
+        self._buf = None                  # [capacity, ld] f32 / f64, rows 16-B aligned
         self._mean_spare = None           # second mean buffer of the one-launch add (am_stats_push_f32 reads one, writes the other)
         self._content_version = 0         # bumped whenever the stored rows change: validity of the cached PreparedSet
         self._prepared = None
         self._prepared_version = -1
-        self._fed_f64 = False             # float64 rows went through add(): the statistics come from the f64 values
 
     @property
     def embeddings(self):
@@ -82,7 +81,7 @@ class AudioMetricsData:
             e = e.to(self.device, non_blocking=True)
         elif self._device is None:
             self._device = e.device
-        return ops.as_matrix(e)           # f32 (f64 embedder outputs are narrowed to the path's f32)
+        return ops.as_rows(e)             # float64 rows stay float64 (the reference keeps the dtype it is given), the rest is f32
 
     # ------------------------------------------------------------ reference API
     def serialize(self):
@@ -105,8 +104,8 @@ class AudioMetricsData:
             self.cov = ensure_tensor(state["cov"]).to(dev, torch.float64)
         if state.get("embeddings") is not None:
             self._append(self._to_device_matrix(state["embeddings"]))
-        # the kernels compare in f32; a reference-written state may carry f64 radii (f64 embeddings after its PCA)
-        self.radii = {k: ensure_tensor(v).to(dev, torch.float32) for k, v in (state.get("radii") or {}).items()}
+        # radii in the dtype they were written in (f64 for float64 rows - the reference's PCA output -, else f32)
+        self.radii = {k: ensure_tensor(v).to(dev) for k, v in (state.get("radii") or {}).items()}
         self.dtype = state.get("dtype", torch.float64)
         return self
 
@@ -121,9 +120,8 @@ class AudioMetricsData:
         other.n = self.n
         other.mean, other.cov = self.mean.to(device), self.cov.to(device)
         if self.embeddings is not None:
-            other._append(ops.as_matrix(self.embeddings.to(device)))
+            other._append(ops.as_rows(self.embeddings.to(device)))
         other.radii = {key: r.to(device) for key, r in self.radii.items()}
-        other._fed_f64 = self._fed_f64
         return other
 
     def add(self, embeddings):
@@ -140,7 +138,8 @@ class AudioMetricsData:
         n = e.shape[0]
         if n == 0:
             raise ValueError("cannot add an empty batch of embeddings")
-        if n <= ops.stats_push_max_rows() and self._push(e):
+        f32_store = self._buf is None or self._buf.dtype == torch.float32      # (a float64 store takes the general path)
+        if n <= ops.stats_push_max_rows() and f32_store and self._push(e):
             return
         e = ops.as_matrix(e)
         mean, cov = ops.stats(e)          # n == 1 -> zero covariance (data.py:40-42)
@@ -149,8 +148,8 @@ class AudioMetricsData:
             self._update_embeddings(e)
 
     def _add_f64(self, embeddings):
-        """add() of float64 rows: statistics in f64 from the f64 values, as the reference computes them (data.py:39-44);
-        stored rows are kept as f32 for the kernel-distance / PRDC kernels (one RuntimeWarning per process)."""
+        """add() of float64 rows: statistics in f64 from the f64 values and rows stored as float64, as the reference does
+        (data.py:39-44, 68-72): the k-NN radii, membership counts and kernel distance of such a set run in f64 too."""
         e = ensure_tensor(embeddings)
         if e.dim() != 2:
             raise ValueError(f"embeddings must have shape [n, d], got {tuple(e.shape)}")
@@ -163,9 +162,8 @@ class AudioMetricsData:
             raise ValueError("cannot add an empty batch of embeddings")
         mean, cov = ops.stats_f64(e)
         self._update_stats(mean, cov, n)
-        self._fed_f64 = True
         if self.store_embeddings:
-            self._update_embeddings(e)                      # narrowed (as_matrix warns once)
+            self._update_embeddings(e)
 
     def _push(self, e):
         """The one-launch form of add().  False (nothing done) when the running state is not in the plain (D,), (D, D) f64
@@ -199,15 +197,11 @@ class AudioMetricsData:
         return True
 
     def recompute_stats(self):
-        """One-shot statistics of the stored rows (data.py:49-58); a no-op without stored rows."""
+        """One-shot statistics of the stored rows, in their dtype (data.py:49-58); a no-op without stored rows."""
         rows = self.embeddings
         if rows is None:
             return
         self.n = int(rows.shape[0])
-        if getattr(self, "_fed_f64", False) and self.mean is not None and self.n >= 2:
-            # the stored rows are an f32 copy of float64 inputs; the accumulated statistics - Chan-merged in f64 from the
-            # f64 values - describe the same rows and are the closer ones to what the reference recomputes from its f64 matrix
-            return
         self.mean, self.cov = ops.stats(rows)
         if self.n < 2:
             # reference quirk kept on purpose: a (1, 1) zero matrix, not (D, D) (data.py:56)
@@ -217,7 +211,7 @@ class AudioMetricsData:
         """The PreparedSet of the stored rows (norms, maxima, scaled f16 copy), computed once per content: the k-NN sweep
         and the membership counts of an evaluate() share it.  None without stored rows."""
         rows = self.embeddings
-        if rows is None:
+        if rows is None or rows.dtype == torch.float64:          # (the f64 kernels take the rows as they are)
             return None
         rows = ops.as_matrix(rows)
         # valid for exactly the content it was computed from: every append / load / move bumps _content_version, and a
@@ -245,13 +239,16 @@ class AudioMetricsData:
     def _update_embeddings(self, embeddings):
         self._append(self._to_device_matrix(embeddings))
 
-    def _reserve(self, rows, d, device):
-        """Capacity for `rows` stored rows: amortised doubling of the HBM buffer (the reference re-concatenates the whole
-        matrix per batch, data.py:68-72)."""
+    def _reserve(self, rows, d, device, dtype=torch.float32):
+        """Capacity for `rows` stored rows of `dtype`: amortised doubling of the HBM buffer (the reference re-concatenates the
+        whole matrix per batch, data.py:68-72).  A float32 store that receives float64 rows becomes float64, as torch.cat's
+        type promotion makes the reference's."""
         held = 0 if self.embeddings is None else self.embeddings.shape[0]
-        if self._buf is None or self._buf.shape[0] < rows or self._buf.device != device:
+        if self._buf is not None and self._buf.dtype != dtype and self._buf.dtype == torch.float64:
+            dtype = torch.float64
+        if self._buf is None or self._buf.shape[0] < rows or self._buf.device != device or self._buf.dtype != dtype:
             cap = max(rows, 2 * (0 if self._buf is None else self._buf.shape[0]), 1024)
-            buf = torch.empty((cap, _ld_for(d)), dtype=torch.float32, device=device)
+            buf = torch.empty((cap, _ld_for(d)), dtype=dtype, device=device)
             if held:
                 buf[:held, :d] = self.embeddings
             self._buf = buf
@@ -259,7 +256,7 @@ class AudioMetricsData:
     def _append(self, e):
         n_new, d = e.shape
         n_old = 0 if self.embeddings is None else self.embeddings.shape[0]
-        self._reserve(n_old + n_new, d, e.device)
+        self._reserve(n_old + n_new, d, e.device, e.dtype if e.dtype == torch.float64 else torch.float32)
         self._buf[n_old:n_old + n_new, :d] = e
         self.embeddings = self._buf[:n_old + n_new, :d]
 
@@ -291,7 +288,6 @@ class AudioMetricsData:
             elif self.store_embeddings != other.store_embeddings:
                 raise AssertionError("cannot merge a set that stores its embeddings with one that does not")
             self._update_stats(other.mean.clone(), other.cov.clone(), other.n)
-            self._fed_f64 = self._fed_f64 or getattr(other, "_fed_f64", False)
             if self.store_embeddings:
                 self._update_embeddings(other.embeddings)
         return self

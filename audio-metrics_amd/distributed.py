@@ -215,13 +215,19 @@ def local_rows(data, group=None):
         dev = torch.device("cuda", torch.cuda.current_device())
     else:
         dev = torch.device("cpu")
-    t = torch.tensor([0 if rows is None else rows.shape[1], 0 if stores else 1], dtype=torch.int64, device=dev)
+    is64 = rows is not None and rows.dtype == torch.float64
+    t = torch.tensor([0 if rows is None else rows.shape[1], 0 if stores else 1, 1 if is64 else 0], dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    width, someone_keeps_none = (int(v) for v in t.cpu().tolist())
+    width, someone_keeps_none, someone_is64 = (int(v) for v in t.cpu().tolist())
     if someone_keeps_none:
         raise ValueError("the metric needs the stored embeddings of a set that kept none")
+    # the dtype is agreed on like the width: the shards travel through one all-gather (float64 anywhere -> float64 everywhere,
+    # torch.cat's promotion of the reference's single store, data.py:68-72)
+    dtype = torch.float64 if someone_is64 else torch.float32
     if rows is None:
-        rows = torch.empty((0, width), dtype=torch.float32, device=dev)
+        rows = torch.empty((0, width), dtype=dtype, device=dev)
+    elif rows.dtype != dtype:
+        rows = rows.to(dtype)
     return rows
 
 
@@ -340,7 +346,8 @@ def sharded_radii(local, full, counts, k, ops, world, rank, group, prepared=None
     n, d = full.shape
     lo = sum(counts[:rank])
     hi = lo + counts[rank]
-    if not _alone(world) and min(counts) > 0 and hasattr(ops, "knn_sym_part") and ops.knn_sym_eligible(n, d, k):
+    if not _alone(world) and min(counts) > 0 and hasattr(ops, "knn_sym_part") and full.dtype != torch.float64 \
+            and ops.knn_sym_eligible(n, d, k):
         extra = {} if prepared is None else {"prepared": prepared}
         bounds = _all_gather_rows(ops.knn_bounds(full, k, lo, counts[rank], **extra), counts, world, group)
         if after_first_exchange is not None:
@@ -357,7 +364,7 @@ def sharded_radii(local, full, counts, k, ops, world, rank, group, prepared=None
     elif local.shape[0] > 0:
         r_local = ops.knn_radii(local, k, columns=full)
     else:
-        r_local = torch.empty(0, dtype=torch.float32, device=full.device)
+        r_local = torch.empty(0, dtype=torch.float64 if full.dtype == torch.float64 else torch.float32, device=full.device)
     return r_local, _all_gather_rows(r_local, counts, world, group)
 
 
@@ -426,6 +433,9 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
         from . import hip_ops as ops
     world, rank = _world(group)
     dev = ref_local.device
+    if ref_local.dtype == torch.float64 or cand_local.dtype == torch.float64:
+        # one dtype for both sets, as numpy / torch promote (kd.py:115); the float32 one-call chain does not apply
+        ref_local, cand_local, fused = ref_local.to(torch.float64), cand_local.to(torch.float64), False
     if _alone(world) and fused and hasattr(ops, "evaluate"):
         return evaluate_single(ref_local, cand_local, metrics, nearest_k, ops, kid_subsets, kid_subset_size, rng_seed)
     if shard_counts is not None:

@@ -160,22 +160,8 @@ def _same_device(*tensors):
     return dev
 
 
-_NARROWING_WARNED = False
-
-
-def _warn_narrowing():
-    """Once per process: the reference keeps float64 embeddings as they are (data.py:39-44, 68-72; its own test embedder and
-    the output of its PCA projection are float64).  Here an add() computes the STATISTICS of float64 rows in f64 too
-    (am_stats_f64), but rows that are stored - for the kernel distance and PRDC, whose kernels are f32 - are kept as
-    float32: real embedders (CLAP, VGGish) produce float32, so only synthetic float64 inputs and PCA-projected sets see
-    the narrowing (~6e-8 relative per element)."""
-    global _NARROWING_WARNED
-    if not _NARROWING_WARNED:
-        _NARROWING_WARNED = True
-        import warnings
-        warnings.warn("audio_metrics_amd: float64 embeddings are stored as float32 for the kernel-distance / PRDC kernels "
-                      "(statistics, FAD and APA are computed from the float64 values; the reference keeps float64 throughout)",
-                      RuntimeWarning, stacklevel=3)
+def is_f64(t):
+    return torch.is_tensor(t) and t.dtype == torch.float64
 
 
 def as_matrix(e, name="embeddings"):
@@ -185,8 +171,6 @@ def as_matrix(e, name="embeddings"):
     if e.dim() != 2:
         raise ValueError(f"{name} must be 2-D, got shape {tuple(e.shape)}")
     if e.dtype != torch.float32:
-        if e.dtype == torch.float64:
-            _warn_narrowing()
         e = e.to(torch.float32)
     n, d = e.shape
     ok = e.stride(1) == 1 and e.stride(0) % 4 == 0 and e.stride(0) >= d and e.data_ptr() % 16 == 0
@@ -196,6 +180,29 @@ def as_matrix(e, name="embeddings"):
         buf[:, :d] = e
         e = buf[:, :d]
     return e
+
+
+def as_matrix64(e, name="embeddings"):
+    """(N, D) f64 device matrix with unit column stride (the f64 kernels need no alignment: any row stride >= D)."""
+    _require_cuda(e, name)
+    if e.dim() != 2:
+        raise ValueError(f"{name} must be 2-D, got shape {tuple(e.shape)}")
+    if e.dtype != torch.float64:
+        e = e.to(torch.float64)
+    n, d = e.shape
+    if n > 0 and (e.stride(1) != 1 or (n > 1 and e.stride(0) < d)):
+        e = e.contiguous()
+    return e
+
+
+def as_rows(e, name="embeddings"):
+    """The matrix form the kernels take, in the dtype the reference computes in (data.py:39-44, prdc.py:12, kd.py:115):
+    float64 rows stay float64 (the *_f64 entry points), everything else is float32."""
+    return as_matrix64(e, name) if is_f64(e) else as_matrix(e, name)
+
+
+def _ld64(e):
+    return e.stride(0) if e.shape[0] > 1 else e.shape[1]
 
 
 def _ld(e):
@@ -214,7 +221,9 @@ def _f64(t, name):
 
 # ------------------------------------------------------------------ statistics
 def stats(e):
-    """mean f64[D], unbiased covariance f64[D, D] of the rows of e (data.py:37-58)."""
+    """mean f64[D], unbiased covariance f64[D, D] of the rows of e (data.py:37-58), computed in the dtype of e."""
+    if is_f64(e):
+        return stats_f64(e)
     lib = _lib.load()
     e = as_matrix(e)
     n, d = e.shape
@@ -246,6 +255,14 @@ def stats_f64(e):
 
 def colsum(e):
     lib = _lib.load()
+    if is_f64(e):
+        e = as_matrix64(e)
+        n, d = e.shape
+        out = torch.empty(d, dtype=torch.float64, device=e.device)
+        nb = lib.am_stats_f64_workspace_bytes(n, d)
+        ws = _workspace(nb, e.device)
+        _call(lib, "am_colsum_f64", e.device, _ptr(e), n, d, _ld64(e), _ptr(out), _ptr(ws), nb)
+        return out
     e = as_matrix(e)
     n, d = e.shape
     out = torch.empty(d, dtype=torch.float64, device=e.device)
@@ -258,8 +275,16 @@ def colsum(e):
 def scatter(e, mean):
     """sum_n (x_n - mean)(x_n - mean)^T, not divided (multi-GPU building block)."""
     lib = _lib.load()
-    e = as_matrix(e)
     mean = _f64(mean, "mean")
+    if is_f64(e):
+        e = as_matrix64(e)
+        n, d = e.shape
+        out = torch.empty((d, d), dtype=torch.float64, device=e.device)
+        nb = lib.am_stats_f64_workspace_bytes(n, d)
+        ws = _workspace(nb, e.device)
+        _call(lib, "am_scatter_f64", e.device, _ptr(e), n, d, _ld64(e), _ptr(mean), _ptr(out), _ptr(ws), nb)
+        return out
+    e = as_matrix(e)
     n, d = e.shape
     out = torch.empty((d, d), dtype=torch.float64, device=e.device)
     nb = lib.am_stats_workspace_bytes(n, d)
@@ -330,7 +355,7 @@ def eigh_descending(a, max_sweeps=40):
 def project(x, mean, components):
     """(x - mean) @ components.T as f64 [N, p] (IncrementalPCA.transform)."""
     lib = _lib.load()
-    x = as_matrix(x)
+    x = as_rows(x)
     mean, components = _f64(mean, "mean"), _f64(components, "components")
     n, d = x.shape
     p = components.shape[0]
@@ -338,7 +363,9 @@ def project(x, mean, components):
         raise ValueError(f"projection shapes do not match: x {tuple(x.shape)}, mean {tuple(mean.shape)}, components {tuple(components.shape)}")
     _same_device(x, mean, components)
     out = torch.empty((n, p), dtype=torch.float64, device=x.device)
-    if n > 0:
+    if n > 0 and is_f64(x):
+        _call(lib, "am_project_rows_f64", x.device, _ptr(x), n, _ld64(x), d, _ptr(mean), _ptr(components), p, _ptr(out))
+    elif n > 0:
         _call(lib, "am_project_f64", x.device, _ptr(x), n, _ld(x), d, _ptr(mean), _ptr(components), p, _ptr(out))
     return out
 
@@ -424,11 +451,20 @@ def apa_scalar(d_y_x, d_y_xp, d_x_xp):
 
 # ------------------------------------------------------------------ kernel distance
 def kd_poly(x, y, idx1, idx2, gamma, coef0, degree):
-    """Per-subset unbiased MMD^2 (f64[S] device tensor).  idx1/idx2: int64 [S, m]."""
+    """Per-subset unbiased MMD^2 (f64[S] device tensor).  idx1/idx2: int64 [S, m].  float64 features (either side: numpy's
+    matmul promotes, kd.py:115) run every product and sum in f64 (am_kd_poly_f64)."""
     lib = _lib.load()
-    x, y = as_matrix(x, "features_1"), as_matrix(y, "features_2")
     idx1, idx2 = _index_table(idx1, "idx1"), _index_table(idx2, "idx2")
     s, m = idx1.shape
+    if is_f64(x) or is_f64(y):
+        x, y = as_matrix64(x, "features_1"), as_matrix64(y, "features_2")
+        out = torch.empty(s, dtype=torch.float64, device=x.device)
+        nb = lib.am_kd_f64_workspace_bytes(s, m)
+        ws = _workspace(nb, x.device)
+        _call(lib, "am_kd_poly_f64", x.device, _ptr(x), x.shape[0], _ld64(x), _ptr(y), y.shape[0], _ld64(y), x.shape[1],
+              _ptr(idx1), _ptr(idx2), s, m, float(gamma), float(coef0), int(degree), _ptr(out), _ptr(ws), nb)
+        return out
+    x, y = as_matrix(x, "features_1"), as_matrix(y, "features_2")
     out = torch.empty(s, dtype=torch.float64, device=x.device)
     nb = lib.am_kd_poly_workspace_bytes(s, m, x.shape[1])
     ws = _workspace(nb, x.device)
@@ -441,9 +477,17 @@ def kd_poly(x, y, idx1, idx2, gamma, coef0, degree):
 def kd_rbf(x, y, idx1, idx2, sigma):
     """Per-subset unbiased MMD^2 with the RBF kernel exp(-|x-y|^2 / (2 sigma^2)) (f64[S] device tensor)."""
     lib = _lib.load()
-    x, y = as_matrix(x, "features_1"), as_matrix(y, "features_2")
     idx1, idx2 = _index_table(idx1, "idx1"), _index_table(idx2, "idx2")
     s, m = idx1.shape
+    if is_f64(x) or is_f64(y):
+        x, y = as_matrix64(x, "features_1"), as_matrix64(y, "features_2")
+        out = torch.empty(s, dtype=torch.float64, device=x.device)
+        nb = lib.am_kd_f64_workspace_bytes(s, m)
+        ws = _workspace(nb, x.device)
+        _call(lib, "am_kd_rbf_f64", x.device, _ptr(x), x.shape[0], _ld64(x), _ptr(y), y.shape[0], _ld64(y), x.shape[1], _ptr(idx1),
+              _ptr(idx2), s, m, float(sigma), _ptr(out), _ptr(ws), nb)
+        return out
+    x, y = as_matrix(x, "features_1"), as_matrix(y, "features_2")
     out = torch.empty(s, dtype=torch.float64, device=x.device)
     nb = lib.am_kd_rbf_workspace_bytes(s, m)
     ws = _workspace(nb, x.device)
@@ -474,6 +518,9 @@ class PreparedSet:
 
 
 def prepare(x):
+    """PreparedSet of a float32 set; None for float64 rows (the f64 kernels derive nothing ahead of their tile loop)."""
+    if is_f64(x):
+        return None
     lib = _lib.load()
     x = as_matrix(x)
     n, d = x.shape
@@ -487,8 +534,20 @@ def prepare(x):
 
 def knn_radii(x, k, columns=None, prepared=None):
     """(k+1)-th smallest distance from each row of x to the rows of `columns`
-    (default: x itself) - prdc.py:4-14.  `prepared`: the PreparedSet of x (self-distance form only)."""
+    (default: x itself) - prdc.py:4-14, in the dtype of the rows (float64 rows: float64 radii, am_knn_radii_f64).
+    `prepared`: the PreparedSet of x (self-distance form of float32 sets only)."""
     lib = _lib.load()
+    if is_f64(x) or is_f64(columns):
+        x = as_matrix64(x)
+        y = x if columns is None else as_matrix64(columns, "columns")
+        n, d = x.shape
+        if y.shape[1] != d:
+            raise ValueError("feature dimensions differ")
+        out = torch.empty(n, dtype=torch.float64, device=x.device)
+        nb = lib.am_knn_f64_workspace_bytes(n, y.shape[0], d, int(k))
+        ws = _workspace(nb, x.device)
+        _call(lib, "am_knn_radii_f64", x.device, _ptr(x), n, _ld64(x), _ptr(y), y.shape[0], _ld64(y), d, int(k), _ptr(out), _ptr(ws), nb)
+        return out
     x = as_matrix(x)
     y = x if columns is None else as_matrix(columns, "columns")
     n, d = x.shape
@@ -517,7 +576,10 @@ def prdc_path(n_ref, n_cand, d):
     return int(_lib.load().am_prdc_path(int(n_ref), int(n_cand), int(d)))
 
 
-def knn_sym_eligible(n, d, k):
+def knn_sym_eligible(n, d, k, dtype=None):
+    """The partitioned symmetric sweep is a float32 form (float64 sets: row shards through knn_radii)."""
+    if dtype == torch.float64:
+        return False
     return bool(_lib.load().am_knn_sym_eligible(int(n), int(d), int(k)))
 
 
@@ -574,11 +636,28 @@ def knn_lists_finish(lists, x_full, k):
 
 def prdc_counts(ref, cand, r_ref, r_cand, want_min=False, prepared_ref=None, prepared_cand=None):
     """col_count i32[Nc], row_any u8[Nr], row_cover u8[Nr] (prdc.py:34-48); with want_min=True also the row
-    minimum f32[Nr] (not needed by any metric; costs extra)."""
+    minimum f32[Nr] (not needed by any metric; costs extra).  float64 rows (either set): distances, radii and the comparisons
+    in f64 (am_prdc_counts_f64; the row minimum is then f64 too)."""
     lib = _lib.load()
-    ref, cand = as_matrix(ref, "reference"), as_matrix(cand, "candidate")
     _require_cuda(r_ref, "r_ref")
     _require_cuda(r_cand, "r_cand")
+    if is_f64(ref) or is_f64(cand):
+        ref, cand = as_matrix64(ref, "reference"), as_matrix64(cand, "candidate")
+        r_ref, r_cand = r_ref.to(torch.float64).contiguous(), r_cand.to(torch.float64).contiguous()
+        nr, d = ref.shape
+        nc = cand.shape[0]
+        if r_ref.numel() != nr or r_cand.numel() != nc or cand.shape[1] != d:
+            raise ValueError("radius / embedding shapes do not match")
+        col = torch.empty(nc, dtype=torch.int32, device=ref.device)
+        rany = torch.empty(nr, dtype=torch.uint8, device=ref.device)
+        rcov = torch.empty(nr, dtype=torch.uint8, device=ref.device)
+        rmin = torch.empty(nr, dtype=torch.float64, device=ref.device) if want_min else None
+        nb = lib.am_prdc_f64_workspace_bytes(nr, nc, d)
+        ws = _workspace(nb, ref.device)
+        _call(lib, "am_prdc_counts_f64", ref.device, _ptr(ref), nr, _ld64(ref), _ptr(cand), nc, _ld64(cand), d, _ptr(r_ref), _ptr(r_cand),
+              _ptr(col), _ptr(rany), _ptr(rcov), _ptr(rmin) if want_min else ctypes.c_void_p(None), _ptr(ws), nb)
+        return (col, rany, rcov, rmin) if want_min else (col, rany, rcov)
+    ref, cand = as_matrix(ref, "reference"), as_matrix(cand, "candidate")
     r_ref = r_ref.to(torch.float32).contiguous()
     r_cand = r_cand.to(torch.float32).contiguous()
     nr, d = ref.shape
@@ -654,6 +733,8 @@ def evaluate(ref, cand, what, nearest_k=5, idx_cand=None, idx_ref=None, gamma=No
     are) and mean_out, cov_out, radii_out (device tensors the chain writes its own results to, so that the caller keeps
     them).  Returns the raw host record: (head f64[16], mmds f64[S] or None)."""
     lib = _lib.load()
+    if is_f64(ref) or is_f64(cand):
+        raise ValueError("am_evaluate_f32 is the float32 chain; float64 sets run entry point by entry point (evaluate_sharded)")
     ref, cand = as_matrix(ref, "reference"), as_matrix(cand, "candidate")
     dev = _same_device(ref, cand)
     n_ref, d = ref.shape

@@ -39,7 +39,7 @@ class IncrementalPCA:
             x = x.to(self._device)
         elif self._device is None:
             self._device = x.device
-        return ops.as_matrix(x)
+        return ops.as_rows(x)                # float64 rows (a float64 embedder) are fitted and projected in f64, as scikit-learn does
 
     def partial_fit(self, X, y=None, check_input=True, batch_stats=None):
         """scikit-learn's incremental update from one batch.  batch_stats = (n, mean f64[D], cov f64[D, D]) of the batch when

@@ -75,6 +75,12 @@ size_t am_stats_f64_workspace_bytes(int64_t N, int D);
 int am_stats_f64(const double* X, int64_t N, int D, int64_t ld,
                  double* mean, double* cov,
                  void* ws, size_t ws_bytes, am_stream_t stream);
+/* the two halves of am_stats_f64 (column sums; centred scatter, NOT divided) for a multi-GPU caller, as am_colsum_f32 /
+ * am_scatter_f32; same workspace query.  D <= 8192. */
+int am_colsum_f64(const double* X, int64_t N, int D, int64_t ld,
+                  double* colsum, void* ws, size_t ws_bytes, am_stream_t stream);
+int am_scatter_f64(const double* X, int64_t N, int D, int64_t ld, const double* mean,
+                   double* scatter, void* ws, size_t ws_bytes, am_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * A3  Chan / pairwise merge of two (n, mean, cov) triples in f64
@@ -285,6 +291,39 @@ int am_prdc_reduce(const int32_t* col_count, int64_t Nc,
                    int64_t* out4, am_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * float64 rows: A6-A10 in the dtype of the embeddings.
+ *   The reference computes every stage in the dtype of the rows it is given - torch.cdist / kthvalue (prdc.py:12-13,34),
+ *   the comparisons against the radii (prdc.py:36-47), np.matmul and the kernel sums (kd.py:112-116, 56-81) - and float64
+ *   rows are what its PCA projection hands on (projection.py:20-21: scikit-learn's float64 product; audio_metrics.py:163-182,
+ *   the path of every reference test and of examples/2_musdb.py) and what its test embedder yields.  These entry points are
+ *   the f64 forms of am_knn_radii_f32 / am_prdc_counts_f32 / am_kd_poly_f32 / am_kd_rbf_f32: same arguments with double
+ *   rows, double radii and a double row minimum, every product and sum in f64 on the f64 matrix cores
+ *   (v_mfma_f64_16x16x4_f64, csrc/pairwise_f64.hip):  d2 = max(fma(-2, <x, y>, |x|^2 + |y|^2), 0), radius = sqrt_rn of the
+ *   (k+1)-th smallest d2, membership  sqrt_rn(d2) < r  decided exactly through d2 < T(r).  Rows need no alignment
+ *   (ld >= D, in elements).  Any 1 <= k < M (k > 31: distance blocks + a radix select, a correctness path).
+ * ------------------------------------------------------------------------- */
+size_t am_knn_f64_workspace_bytes(int64_t N, int64_t M, int D, int k);
+int am_knn_radii_f64(const double* X, int64_t N, int64_t ldx,
+                     const double* Y, int64_t M, int64_t ldy, int D, int k,
+                     double* out_r, void* ws, size_t ws_bytes, am_stream_t stream);
+size_t am_prdc_f64_workspace_bytes(int64_t Nr, int64_t Nc, int D);
+int am_prdc_counts_f64(const double* R, int64_t Nr, int64_t ldr,
+                       const double* C, int64_t Nc, int64_t ldc, int D,
+                       const double* r_ref, const double* r_cand,
+                       int32_t* out_col_count, uint8_t* out_row_any, uint8_t* out_row_cover, double* out_row_min,
+                       void* ws, size_t ws_bytes, am_stream_t stream);
+size_t am_kd_f64_workspace_bytes(int S, int m);
+int am_kd_poly_f64(const double* X, int64_t N1, int64_t ldx,
+                   const double* Y, int64_t N2, int64_t ldy, int D,
+                   const int64_t* idx1, const int64_t* idx2, int S, int m,
+                   double gamma, double coef0, int degree,
+                   double* out_mmd, void* ws, size_t ws_bytes, am_stream_t stream);
+int am_kd_rbf_f64(const double* X, int64_t N1, int64_t ldx,
+                  const double* Y, int64_t N2, int64_t ldy, int D,
+                  const int64_t* idx1, const int64_t* idx2, int S, int m, double sigma,
+                  double* out_mmd, void* ws, size_t ws_bytes, am_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * N1  PCA projection support                   reference: projection.py:6-46 (scikit-learn IncrementalPCA),
  *                                                           audio_metrics.py:163-209
  *   am_eigh_sym_f64  eigen-decomposition of a symmetric POSITIVE SEMI-DEFINITE D x D matrix (the Gram matrix of the
@@ -294,13 +333,16 @@ int am_prdc_reduce(const int32_t* col_count, int64_t Nc,
  *                    sweeps (12, then 6 at a time: normally once per solve - the kernels of a sweep return at once when
  *                    the sweep before it applied no rotation; fitting happens once per reference set, not per evaluate).  AM_ERR_NO_CONVERGENCE after max_sweeps (<= 0: 40).
  *   am_project_f64   out[N][p] (f64) = (X[n][:] - mean[:]) . components[j][:]  - IncrementalPCA.transform - on the f64
- *                    matrix cores; X is the N x D f32 embedding matrix, mean f64[D], components f64[p][D].
+ *                    matrix cores; X is the N x D f32 embedding matrix (am_project_rows_f64: f64), mean f64[D], components f64[p][D].
  * ------------------------------------------------------------------------- */
 size_t am_eigh_workspace_bytes(int D);
 int am_eigh_sym_f64(const double* A, int D, double* evals, double* evecs, int max_sweeps,
                     void* ws, size_t ws_bytes, am_stream_t stream);
 int am_project_f64(const float* X, int64_t N, int64_t ld, int D, const double* mean, const double* components, int p,
                    double* out, am_stream_t stream);
+/* the same for float64 rows (a float64 embedder in front of the projection: scikit-learn then multiplies in f64 too) */
+int am_project_rows_f64(const double* X, int64_t N, int64_t ld, int D, const double* mean, const double* components, int p,
+                        double* out, am_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * A13  one call = one evaluate()                reference: audio_metrics.py:254-274

@@ -98,6 +98,36 @@ PRDC_LARGE_CASES = {
     "unit_40000_512_k10": ("unit", 144, 40000, 40000, 512, 10),
 }
 
+# float64 rows (round 5): what the reference's PCA projection hands to KD / PRDC (projection.py:20-21) and what a float64
+# embedder yields.  The inputs are NOT cast to float32.
+def randn64(seed, n, d, scale=1.0, shift=0.0):
+    return np.random.default_rng(seed).standard_normal((n, d)) * scale + shift
+
+
+def decaying64(seed, n, d, decades=1.0, scale=1.0, shift=0.0):
+    x = np.random.default_rng(seed).standard_normal((n, d)) * scale + shift
+    return x * np.logspace(0.0, -decades, d)
+
+
+def pair64(kind, seed, n_ref, n_cand, d):
+    if kind == "randn":
+        return randn64(seed, n_ref, d), randn64(seed + 1, n_cand, d, 1.05, 0.05)
+    if kind == "decay":
+        return decaying64(seed, n_ref, d, 1.0, 1.0, 0.3), decaying64(seed + 1, n_cand, d, 1.0, 1.1, 0.35)
+    raise ValueError(kind)
+
+
+F64_CASES = {
+    # name: (kind, seed, n_ref, n_cand, d of the rows fed in, n_pca or 0, k)
+    "direct_2000_24_k5": ("randn", 201, 2000, 2000, 24, 0, 5),
+    "direct_300_500_9_k3": ("randn", 202, 300, 500, 9, 0, 3),          # odd width, unequal sizes
+    "direct_1500_40_k40": ("randn", 203, 1500, 1400, 40, 0, 40),      # k + 1 > 32: the select path
+    "direct_2100_130_k10": ("decay", 204, 2100, 2050, 130, 0, 10),    # more than eight 16-element slabs, a ragged last one
+    "pca8_20000_k5": ("decay", 205, 20000, 20000, 96, 8, 5),          # the reference's own projection (n_pca = 8), 20 000 rows
+    "pca64_20000_k10": ("decay", 206, 20000, 20000, 96, 64, 10),
+}
+
+
 # The headline benchmark's inputs (bench.py): numpy-seeded so that the CPU oracle can reproduce them.
 BENCH_SEED = 2026
 

@@ -368,6 +368,63 @@ def gen_pca():
     print("pca singular values", out["fit1/singular_values_"], out["fit2/singular_values_"])
 
 
+def gen_f64():
+    """float64 rows through the reference's own functions: AudioMetricsData.add / get_radii, prdc, kernel_distance - and, for
+    the pca cases, its IncrementalPCA wrapper in front (projection.py:6-46, audio_metrics.py:163-209: fit on the reference
+    set, transform both).  Every stage then runs in f64 (data.py:39-44, prdc.py:12-13,34-48, kd.py:112-116)."""
+    import time
+    r_proj = importlib.import_module("audio_metrics.projection")
+    out = {"versions": VERSIONS + f"; sklearn {__import__('sklearn').__version__}"}
+    for name, (kind, seed, nr, nc, d, n_pca, k) in gi.F64_CASES.items():
+        t0 = time.time()
+        ref, cand = gi.pair64(kind, seed, nr, nc, d)
+        assert ref.dtype == np.float64
+        if n_pca:
+            pca = r_proj.IncrementalPCA(n_components=n_pca)
+            pca.partial_fit(ref.copy())
+            out[f"{name}/components"] = np.asarray(pca.components_, dtype=np.float64)
+            out[f"{name}/pca_mean"] = np.asarray(pca.mean_, dtype=np.float64)
+            ref, cand = pca.transform(ref).numpy(), pca.transform(cand).numpy()
+            assert ref.dtype == np.float64 and ref.shape == (nr, n_pca)
+            out[f"{name}/proj_ref_head"] = ref[:64].copy()               # (spot check of the projection itself)
+        a, b = amd(ref), amd(cand)
+        assert a.embeddings.dtype == torch.float64
+        out[f"{name}/mean_ref"] = a.mean.numpy()
+        out[f"{name}/cov_ref"] = a.cov.numpy()
+        res = r_prdc.prdc(a, b, k)
+        for key, v in res.items():
+            out[f"{name}/{key}"] = v
+        r_ref, r_cand = a.radii[f"radii_{k}"], b.radii[f"radii_{k}"]
+        assert r_ref.dtype == torch.float64
+        out[f"{name}/r_ref"] = r_ref.numpy()
+        out[f"{name}/r_cand"] = r_cand.numpy()
+        dist = torch.cdist(a.embeddings, b.embeddings)
+        out[f"{name}/col_count"] = (dist < r_ref[:, None]).sum(dim=0).numpy().astype(np.int32)
+        out[f"{name}/row_any"] = (dist < r_cand[None, :]).any(dim=1).numpy()
+        out[f"{name}/row_cover"] = (dist.min(dim=1)[0] < r_ref).numpy()
+        out[f"{name}/row_min_head"] = dist.min(dim=1)[0][:256].numpy()
+        del dist
+        # kernel distance with the candidate as features_1 (audio_metrics.py:260), per-subset values replayed with the
+        # reference's own functions
+        kd = r_kd.kernel_distance(b, a)
+        out[f"{name}/kd_mean"], out[f"{name}/kd_std"] = kd["kernel_distance_mean"], kd["kernel_distance_std"]
+        m = 1000 if 1000 < min(nr, nc) else max(1, min(nr, nc) // 2)
+        rng = np.random.default_rng(1234)
+        mmds = np.zeros(100)
+        for i in range(100):
+            i1 = rng.choice(nc, m, replace=False)
+            i2 = rng.choice(nr, m, replace=False)
+            mmds[i] = r_kd.kernel_mmd2(cand[i1], ref[i2], r_kd.polynomial_kernel)
+        assert float(np.mean(mmds)) == kd["kernel_distance_mean"]
+        out[f"{name}/mmds"] = mmds
+        if nr <= 3000:
+            rr = r_kd.kid_features_to_metric(cand, ref, kernel_type="rbf", kid_sigma=3.0)
+            out[f"{name}/rbf_mean"], out[f"{name}/rbf_std"] = rr["kernel_distance_mean"], rr["kernel_distance_std"]
+        out[f"{name}/fad"] = r_fad.frechet_distance(b, a)
+        print("f64", name, res, kd, f"{time.time() - t0:.0f}s", flush=True)
+    np.savez_compressed(os.path.join(HERE, "f64.npz"), **out)
+
+
 # (seed of the global generator or None, explicit seed or None, items, buffer_size, min_age) per case
 STREAM_CASES = {
     "global_small": (11, None, 40, 8, 0),
