@@ -82,6 +82,7 @@ SIGNATURES = {
     "am_kernel_clock_read": (c_int, [c_int, _P, _P]),
     "am_knn_path": (c_int, [c_int64, c_int64, c_int, c_int, c_int]),
     "am_prdc_path": (c_int, [c_int64, c_int64, c_int]),
+    "am_filter_engine": (c_int, [c_int]),
     "am_filter_stats_enable": (c_int, [_P]),
 }
 

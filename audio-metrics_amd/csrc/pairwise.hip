@@ -1385,6 +1385,14 @@ extern "C" int am_prdc_path(int64_t Nr, int64_t Nc, int D) {
     return plan_cross_fast(Nr, Nc).wide ? 3 : 2;
 }
 
+// which of the two 256-row engines multiplies the tiles of a path-3 filter pass for rows of D elements (benchmark support:
+// the kernel name a profile shows): 0 wide_engine.h (knn_wide_kernel / cross_wide_kernel), 1 pstat_engine.h
+// (knn_pstat_kernel / cross_pstat_kernel)
+extern "C" int am_filter_engine(int D) {
+    if (D < 1) return 0;
+    return wide_stationary((int)(half_ld(D) / 2)) ? 1 : 0;
+}
+
 // ---- partitioned symmetric k-NN (multi-GPU; every rank holds the full set) --------------------------
 extern "C" int am_knn_sym_eligible(int64_t N, int D, int k) {
     if (N < 1 || D < 1 || k < 1 || k > AM_MAX_K) return 0;

@@ -117,7 +117,9 @@ __global__ void __launch_bounds__(256) max_bits_kernel(const float* __restrict__
 // ---- optional filter statistics (am_filter_stats_enable): how much work the filter passes left for the exact kernels.
 // int64 slots: 0 k-NN calls, 1 entries queued by the sweep, 2 of those through the spill queue, 3 pairs evaluated exactly,
 // 4 rows recomputed by the exact fix-up kernel; 5 membership calls, 6 pairs queued, 7 of those through the overflow queue,
-// 8 calls handed to the exact kernel (both queues overflowed or the operands could not be scaled).
+// 8 calls handed to the exact kernel (both queues overflowed or the operands could not be scaled);
+// 9 the largest |f16 value - exact value| / (fast_c (|x|^2 + G)) over every pair the k-NN verification evaluated, as f32 bits
+// (the MEASURED form of the bound of item 1 above: must stay <= 1), 10 the number of pairs it was measured on.
 constexpr int FILTER_STATS_SLOTS = 16;
 static long long* g_filter_stats = nullptr;                 // caller-owned device buffer, nullptr = off
 static int g_filter_stats_device = -1;
@@ -1086,9 +1088,9 @@ template <int KCAP>
 __global__ void __launch_bounds__(256) knn_fast_prune_kernel(const float* __restrict__ fval, const unsigned* __restrict__ fidx,
                                                              const int* __restrict__ cnt, int cap, int64_t N, int k1,
                                                              const float* __restrict__ xnorm, const unsigned* __restrict__ maxn,
-                                                             uint2* __restrict__ pairs, int pair_cap, int* __restrict__ pair_count,
-                                                             int* __restrict__ cnt2, int partitioned, float fc,
-                                                             int* __restrict__ gate) {
+                                                             uint2* __restrict__ pairs, float* __restrict__ pair_val, int pair_cap,
+                                                             int* __restrict__ pair_count, int* __restrict__ cnt2, int partitioned,
+                                                             float fc, int* __restrict__ gate) {
     if (gate != nullptr && gate[0] != 0) return;          // (gate: data-dependent fallback, see knn_fast_predict_kernel)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -1138,7 +1140,10 @@ __global__ void __launch_bounds__(256) knn_fast_prune_kernel(const float* __rest
     }
     const unsigned* fi = fidx + i * (int64_t)cap;
     for (int s = 0; s < c; ++s)
-        if (fv[s] <= thr) pairs[at++] = make_uint2((unsigned)i, fi[s]);
+        if (fv[s] <= thr) {
+            pair_val[at] = fv[s];                              // the f16 value travels with the pair: the verification measures the bound on it
+            pairs[at++] = make_uint2((unsigned)i, fi[s]);
+        }
 }
 
 // One pair per lane, 64 pairs per wave at a time (wave_pair_dot): the exact engine's fmaf chain (t(a,b) == t(b,a) bit for
@@ -1153,9 +1158,17 @@ __global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __res
                                                               const float* __restrict__ xnorm, int D,
                                                               const uint2* __restrict__ pairs, const int* __restrict__ pair_count,
                                                               int pair_cap, float* __restrict__ cand, int* __restrict__ cnt2,
-                                                              int cap, const int* __restrict__ skip) {
+                                                              int cap, const int* __restrict__ skip, const float* __restrict__ pair_val,
+                                                              float fc, const unsigned* __restrict__ maxn,
+                                                              unsigned long long* __restrict__ bound_slots) {
     extern __shared__ __attribute__((aligned(16))) float vlds[];
     if (skip != nullptr && *skip != 0) return;
+    // bound_slots (am_filter_stats_enable): the verification holds BOTH values of every surviving pair - the f16 matrix-core
+    // value `a` the filter decided on and the exact f32 value `t` - so the error bound the filter rests on,
+    // |a - t| <= fast_c(D) (|x|^2 + G) with x the smaller-normed row of the pair, is MEASURED here instead of assumed:
+    // slot 0 = max of |a - t| / bound as f32 bits (<= 1 or the filter is unsound), slot 1 = pairs measured
+    float worst = 0.f;
+    unsigned long long measured = 0ull;
     const int n = min(*pair_count, pair_cap);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* tile = vlds + wave * 128 * VERIFY_LD;                     // rows 0..63: first rows of the pairs, 64..127: second rows
@@ -1165,7 +1178,28 @@ __global__ void __launch_bounds__(256) knn_fast_verify_kernel(const float* __res
         const bool hole = p.x == FAST_HOLE;
         if (hole) p = make_uint2(0u, 0u);
         const float acc = wave_pair_dot(X, ld, X, ld, p.x, p.y, D, tile, lane);
-        if (!hole) knn_file(cand, cnt2, cap, p.x, clamp0(fmaf(-2.f, acc, xnorm[p.x] + xnorm[p.y])));
+        if (!hole) {
+            const float nx = xnorm[p.x], ny = xnorm[p.y];
+            const float t = fmaf(-2.f, acc, nx + ny);
+            knn_file(cand, cnt2, cap, p.x, clamp0(t));
+            if (bound_slots != nullptr) {
+                const float bound = fc * (fminf(nx, ny) + __uint_as_float(maxn[0]));
+                const float ratio = fabsf(pair_val[e] - t) / bound;
+                if (ratio == ratio) worst = fmaxf(worst, ratio);   // (0 / 0 of an all-zero set: no statement)
+                ++measured;
+            }
+        }
+    }
+    if (bound_slots != nullptr) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            worst = fmaxf(worst, __shfl_xor(worst, off));
+            measured += __shfl_xor(measured, off);
+        }
+        if (lane == 0 && measured != 0ull) {
+            atomicMax(bound_slots, (unsigned long long)__float_as_uint(worst));      // worst >= 0: bit order = value order
+            atomicAdd(bound_slots + 1, measured);
+        }
     }
 }
 
@@ -1533,7 +1567,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     const int64_t pair_cap64 = std::min<int64_t>((int64_t)nwg * p.qcap, (int64_t)1 << 30);   // (the pair list reuses the region memory)
     const int pair_cap = (int)pair_cap64;
     hipLaunchKernelGGL(knn_fast_prune_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.cand, f.fidx, b.cnt, p.cap,
-                       N, k1, b.xn, maxn, b.wgq, pair_cap, f.pair_count, f.cnt2, out_lists != nullptr ? 1 : 0, fast_c(D), gate);
+                       N, k1, b.xn, maxn, b.wgq, f.wgv, pair_cap, f.pair_count, f.cnt2, out_lists != nullptr ? 1 : 0, fast_c(D), gate);
     if (gate != nullptr)                                 // check B: did the prune step leave a verifiable amount of work?
         hipLaunchKernelGGL(knn_fast_decide_kernel, dim3(1), dim3(64), 0, st, gate, N, k1, 1, f.pair_count, maxn, b.ov_count);
     AM_LAUNCH_CHECK();
@@ -1541,8 +1575,12 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     {
         AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_fast_verify_kernel), (int)VERIFY_LDS_BYTES));
     }
-    hipLaunchKernelGGL(knn_fast_verify_kernel, dim3(2048), dim3(256), VERIFY_LDS_BYTES, st, X, ld, b.xn, D, b.wgq, f.pair_count,
-                       pair_cap, b.cand, f.cnt2, p.cap, skip_verify);
+    {
+        long long* stats = filter_stats_for_current_device();      // (the approximate values of the pairs: f.wgv, free since the scatter)
+        hipLaunchKernelGGL(knn_fast_verify_kernel, dim3(2048), dim3(256), VERIFY_LDS_BYTES, st, X, ld, b.xn, D, b.wgq, f.pair_count,
+                           pair_cap, b.cand, f.cnt2, p.cap, skip_verify, (const float*)f.wgv, fast_c(D), (const unsigned*)maxn,
+                           stats != nullptr ? reinterpret_cast<unsigned long long*>(stats) + 9 : nullptr);
+    }
     clock_end(AM_KERNEL_KNN_VERIFY, st);
     AM_LAUNCH_CHECK();
     hipLaunchKernelGGL(knn_fast_select_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.cand, f.cnt2, p.cap, N, k1,

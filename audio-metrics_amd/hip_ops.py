@@ -100,7 +100,7 @@ def kernel_clock_read(kernel):
 
 
 FILTER_STATS_NAMES = ("knn_calls", "knn_queued", "knn_spilled", "knn_verified_pairs", "knn_fallback_rows",
-                      "prdc_calls", "prdc_queued", "prdc_overflow_queue", "prdc_fallback_calls")
+                      "prdc_calls", "prdc_queued", "prdc_overflow_queue", "prdc_fallback_calls", "bound_ratio_max", "bound_pairs")
 _FILTER_STATS = {}
 
 
@@ -122,7 +122,11 @@ def filter_stats_read(device):
     buf = _FILTER_STATS[torch.device(device).index]
     values = buf.cpu().tolist()
     buf.zero_()
-    return dict(zip(FILTER_STATS_NAMES, values))
+    out = dict(zip(FILTER_STATS_NAMES, values))
+    # slot 9 holds the bit pattern of a float: the largest measured |f16 value - exact value| / (fast_c (|x|^2 + G))
+    import struct
+    out["bound_ratio_max"] = struct.unpack("<f", struct.pack("<I", int(out["bound_ratio_max"]) & 0xffffffff))[0]
+    return out
 
 
 def _call(lib, name, device, *args):
@@ -574,6 +578,11 @@ def knn_path(n, m, d, k, self_distance=True):
 def prdc_path(n_ref, n_cand, d):
     """0 exact kernel, 2 / 3 f16 filter + exact verification (128 / 256-row engine)."""
     return int(_lib.load().am_prdc_path(int(n_ref), int(n_cand), int(d)))
+
+
+def filter_engine(d):
+    """Tile engine of the path-3 filter kernels for rows of d elements: 1 operand-stationary (pstat), 0 streamed (wide)."""
+    return int(_lib.load().am_filter_engine(int(d)))
 
 
 def knn_sym_eligible(n, d, k, dtype=None):

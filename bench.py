@@ -415,8 +415,9 @@ def main():
         cross_entry = entry("am_prdc_counts_prepared_f32", "am_prdc_counts_f32")
         knn_path = ops.knn_path(n, n, d, k) if (world == 1 or part_form) else 0
         cross_path = ops.prdc_path(rows_local, n, d)
-        knn_kernel = {0: "knn_partial_kernel", 1: "knn_sym_kernel", 2: "knn_fast_kernel", 3: "knn_wide_kernel"}[knn_path]
-        cross_kernel = {0: "prdc_cross_kernel", 2: "cross_fast_kernel", 3: "cross_wide_kernel"}[cross_path]
+        engine = "pstat" if ops.filter_engine(d) == 1 else "wide"       # path 3: operand-stationary or streamed tile engine
+        knn_kernel = {0: "knn_partial_kernel", 1: "knn_sym_kernel", 2: "knn_fast_kernel", 3: f"knn_{engine}_kernel"}[knn_path]
+        cross_kernel = {0: "prdc_cross_kernel", 2: "cross_fast_kernel", 3: f"cross_{engine}_kernel"}[cross_path]
         peak_of = {0: F32_MFMA_PEAK_TFLOPS, 1: F32_MFMA_PEAK_TFLOPS, 2: F16_MFMA_PEAK_TFLOPS, 3: F16_MFMA_PEAK_TFLOPS}
         mfma_of = {0: "v_mfma_f32_32x32x2_f32", 1: "v_mfma_f32_32x32x2_f32", 2: "v_mfma_f32_32x32x16_f16",
                    3: "v_mfma_f32_32x32x16_f16"}
@@ -555,7 +556,8 @@ def main():
 
 
 def per_step(stats, steps):
-    return {key: value / steps for key, value in stats.items()}
+    """Counters per step; the MEASURED error-bound ratio (a maximum, not a count) is passed through."""
+    return {key: (value if key == "bound_ratio_max" else value / steps) for key, value in stats.items()}
 
 
 def run_e2e(args, am, dev, world, rank, fence, n_ranks_seen=1):

@@ -400,6 +400,10 @@ int am_kernel_clock_enable(int on);
 int am_kernel_clock_read(int kernel, int64_t* launches, double* total_ms);
 int am_knn_path(int64_t N, int64_t M, int D, int k, int self);
 int am_prdc_path(int64_t Nr, int64_t Nc, int D);
+/* form 3 has two tile engines, chosen by the row length alone: 1 = operand-stationary (csrc/pstat_engine.h: the workgroup's
+ * 256-row block held in registers, kernels knn_pstat_kernel / cross_pstat_kernel; rows of up to 512 elements),
+ * 0 = both operands streamed through LDS (csrc/wide_engine.h: knn_wide_kernel / cross_wide_kernel) */
+int am_filter_engine(int D);
 
 /* ---- optional filter statistics (benchmark support) -------------------------------------------------
  * What the f16 filter passes leave for the exact kernels is data dependent.  A caller hands the library a
@@ -410,6 +414,9 @@ int am_prdc_path(int64_t Nr, int64_t Nc, int D);
  *   [3] pairs evaluated exactly (after pruning)           [4] rows recomputed by the exact fix-up kernel
  *   [5] membership calls     [6] pairs queued            [7] of those via the overflow queue
  *   [8] membership calls handed to the exact kernel (queues overflowed / operands not scalable)
+ *   [9] the error bound of the f16 filter, MEASURED: max over every pair the k-NN verification evaluated of
+ *       |f16 matrix-core value - exact f32 value| / (fast_c(D) (|x|^2 + G)), as the bit pattern of a float in the low half
+ *       (the filter is sound while this stays <= 1; csrc/pairwise_fast.h derives the bound)     [10] pairs it was measured on
  * The caller reads and clears the buffer itself. */
 #define AM_FILTER_STATS_SLOTS 16
 int am_filter_stats_enable(int64_t* device_slots);

@@ -73,6 +73,16 @@ def test_evaluate_matches_reference(am, golden, tag, metrics, n_pca):
             assert d.n == int(g[f"{tag}/{attr}/n"])
             np.testing.assert_allclose(d.mean.cpu().numpy(), g[f"{tag}/{attr}/mean"], rtol=1e-5, atol=1e-7)
             np.testing.assert_allclose(d.cov.cpu().numpy(), g[f"{tag}/{attr}/cov"], rtol=1e-4, atol=1e-8)
+    if tag == "pca":
+        # behind the projection every row is float64 (projection.py:20-21), and since round 5 it stays float64 through the
+        # k-NN radii, the membership counts and the kernel distance: the four PRDC values are the reference's to the digit
+        shadows = [v for k, v in vars(m).items() if isinstance(v, am.AudioMetricsData) and v.embeddings is not None
+                   and v.embeddings.shape[1] == n_pca]
+        assert shadows and all(s.embeddings.dtype == torch.float64 for s in shadows)
+        assert all(r.dtype == torch.float64 for s in shadows for r in s.radii.values())
+        for key in ("precision", "recall", "density", "coverage"):
+            assert res[key] == float(g[f"{tag}/{key}"]), (key, res[key], float(g[f"{tag}/{key}"]))
+        assert abs(res["kernel_distance_mean"] - float(g[f"{tag}/kernel_distance_mean"])) <= 1e-9
     # a second evaluate() reuses the cached reference side (radii, d_x_xp) and gives the same values
     res2 = m(cand)
     for key in res:

@@ -135,3 +135,28 @@ def test_apa(golden):
         cand = gi.randn(53 + i, 1200, d, sc, sh)
         a, b, c = (_feed(v, [len(v)], False) for v in (cand, ref, anti))
         assert abs(oracle.apa(a, b, c) - float(g[f"three_set_{i}/apa"])) <= 1e-7
+
+
+# ---- float64 rows (round 5): the oracle's torch / numpy calls keep the dtype they are given, as the reference's do
+@pytest.mark.parametrize("name", list(gi.F64_CASES))
+def test_f64_rows(golden, name):
+    g = golden("f64")
+    kind, seed, nr, nc, d, n_pca, k = gi.F64_CASES[name]
+    ref, cand = gi.pair64(kind, seed, nr, nc, d)
+    assert ref.dtype == np.float64
+    if n_pca:                               # project with the REFERENCE's fitted components (IncrementalPCA.transform in f64)
+        comp, mean = g[f"{name}/components"], g[f"{name}/pca_mean"]
+        ref, cand = (ref - mean) @ comp.T, (cand - mean) @ comp.T
+        np.testing.assert_allclose(ref[:64], g[f"{name}/proj_ref_head"], rtol=0, atol=1e-12)
+    a, b = _feed(ref, [nr]), _feed(cand, [nc])
+    assert a.embeddings.dtype == torch.float64
+    np.testing.assert_allclose(a.mean.numpy(), g[f"{name}/mean_ref"], rtol=0, atol=1e-12)
+    res = oracle.prdc(a, b, k)
+    assert a.radii[f"radii_{k}"].dtype == torch.float64
+    np.testing.assert_allclose(a.radii[f"radii_{k}"].numpy(), g[f"{name}/r_ref"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(b.radii[f"radii_{k}"].numpy(), g[f"{name}/r_cand"], rtol=1e-9, atol=1e-9)
+    for key in ("precision", "recall", "density", "coverage"):
+        assert abs(res[key] - float(g[f"{name}/{key}"])) <= (0.0 if not n_pca else 1.0 / min(nr, nc)) + 1e-12, key
+    kd, mmds = oracle.kid_from_features(cand, ref, return_all=True)
+    np.testing.assert_allclose(mmds, g[f"{name}/mmds"], rtol=0, atol=1e-10)
+    assert abs(kd["kernel_distance_mean"] - float(g[f"{name}/kd_mean"])) <= 1e-10
