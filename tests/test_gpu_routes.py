@@ -1,0 +1,178 @@
+"""A seeded slice of the fuzzers inside the driver-run suite.
+
+tools/fuzz_filter.py / fuzz_part.py found the real defects of rounds 1-4 but are builder-run.  Here 20 k-NN / membership
+cases and 8 partitioned ones run in ONE process with the SHIPPED library, with fixed seeds chosen (tools/route_probe.py)
+so that every data-dependent route of csrc/pairwise_fast.h is taken by at least two cases - and the route is ASSERTED
+through am_filter_stats next to the bits:
+
+  plain      f16 sweep -> scatter -> prune -> exact verification -> selection, no fallback
+  check A    the sample pass says the f16 values cannot separate the rows' neighbours: the exact general kernel takes the call
+  marking    a block of identical rows is taken out of the sweep and recomputed by the batched fix-up
+  scale      operands that cannot be scaled into f16: exact kernels
+  budget     membership filter: overflow queue past its budget -> the exact membership kernel takes the call
+  overflow   membership filter: entries beyond a region go through the overflow queue and are still verified
+  partition  am_knn_bounds / am_knn_sym_part / am_knn_lists_finish against the one-GPU entry point
+
+Exact values without a second library: the k-NN radii of the general entry point (columns = a COPY of the set:
+am_knn_path == 0) and membership counts over reference-row chunks small enough for am_prdc_path == 0 are the exact f32
+kernels' bits.  Every case also carries the MEASURED error bound of the filter (am_filter_stats slot 9): the largest
+|f16 matrix-core value - exact f32 value| / (fast_c(D) (|x|^2 + G)) over all verified pairs must stay <= 1 - the one
+hardware assumption in csrc/pairwise_fast.h (how v_mfma_f32_32x32x16_f16 rounds its accumulation) as an observation."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def probe():
+    import audio_metrics_amd
+    audio_metrics_amd._lib.load()
+    import route_probe
+    route_probe.ops.filter_stats_enable("cuda:0", True)
+    yield route_probe
+    route_probe.ops.filter_stats_enable("cuda:0", False)
+
+
+def sets_of(probe, fam, n, n2, d, seed):
+    if fam == "shared":
+        return probe.shared_clusters(n, d, seed, 1), probe.shared_clusters(n2, d, seed, 2)
+    if fam == "cancel":                     # halves that cancel: <x, y> ~ 0 while sum |x_k y_k| = |x||y| (the bound's worst case)
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        out = []
+        for rows in (n, n2):
+            h = torch.randn(rows, d // 2, generator=g, device="cuda")
+            sign = (torch.arange(rows, device="cuda") % 2 * 2 - 1).to(h.dtype)[:, None]
+            out.append(torch.cat([h, sign * h + 1e-3 * torch.randn(rows, d // 2, generator=g, device="cuda")], dim=1))
+        return out
+    if fam == "subnormal":                  # a few large elements per row, the rest 2^-30 of them: flushed by the f16 copy
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        out = []
+        for rows in (n, n2):
+            x = torch.randn(rows, d, generator=g, device="cuda") * 2.0 ** -30
+            idx = torch.randint(0, d, (rows, 4), generator=g, device="cuda")
+            x.scatter_(1, idx, torch.randn(rows, 4, generator=g, device="cuda"))
+            out.append(x)
+        return out
+    if fam == "manifold":                   # a 24-dimensional set embedded in D dimensions plus noise (randn in D = 4096 has no
+        g = torch.Generator(device="cuda").manual_seed(seed)      # nearest neighbours to speak of: every distance is the same)
+        basis = torch.randn(24, d, generator=g, device="cuda") / 24 ** 0.5
+        return [torch.randn(rows, 24, generator=g, device="cuda") @ basis + 0.02 * torch.randn(rows, d, generator=g, device="cuda")
+                for rows in (n, n2)]
+    return probe.make(fam, n, d, seed), probe.make(fam, n2, d, seed + 100)
+
+
+# name: (family, rows, candidate rows, dim, k, seed, expected k-NN route, expected membership route)
+CASES = {
+    "randn_20k_128": ("randn", 20000, 20000, 128, 5, 1, "plain", "plain"),
+    "randn_8200_512": ("randn", 8200, 8200, 512, 10, 10, "plain", "plain"),
+    "randn_12001_320": ("randn", 12001, 7000, 320, 3, 21, "plain", "plain"),
+    "unit_33k_192": ("unit", 33000, 9000, 192, 10, 2, "plain", "plain"),
+    "unit_20k_512": ("unit", 20000, 20000, 512, 5, 22, "plain", "plain"),
+    "cancel_16k_256": ("cancel", 16000, 16000, 256, 5, 23, "plain", None),
+    "subnormal_16k_128": ("subnormal", 16000, 16000, 128, 5, 24, None, None),
+    "randn_6200_4096": ("randn", 6200, 6200, 4096, 5, 25, "check A", None),       # concentration of measure: nothing to separate
+    "manifold_6200_4096": ("manifold", 6200, 6200, 4096, 5, 28, None, None),
+    "clustered_20k_512": ("clustered", 20000, 20000, 512, 5, 3, "check A", "budget"),
+    "shared_20k_512": ("shared", 20000, 20000, 512, 5, 4, "check A", "budget"),
+    "lowrank_20k_257": ("lowrank", 20000, 20000, 257, 5, 9, "check A", None),
+    "hub_30k_128": ("hub", 30000, 30000, 128, 3, 6, "check A", "overflow"),
+    "sparse_16400_64": ("sparse", 16400, 16400, 64, 5, 11, "check A", "budget"),
+    "silence_40k_256": ("silence", 40000, 3001, 256, 5, 5, "marking", "plain"),
+    "silence_20k_512": ("silence", 20000, 20000, 512, 10, 26, "marking", None),
+    "scales_34567_130": ("scales", 34567, 4938, 130, 1, 8, "check A", "budget"),
+    "tiny_20k_96": ("tiny", 20000, 20000, 96, 5, 12, "scale", "scale"),
+    "huge_16400_64": ("huge", 16400, 16400, 64, 5, 27, None, None),
+    "dups_12k_67": ("dups", 12000, 12000, 67, 8, 7, "plain", "plain"),
+    "randn_40k_64_min": ("randn", 40000, 40000, 64, 5, 29, "plain", "plain"),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_route_and_bits(probe, name):
+    fam, n, n2, d, k, seed, knn_route, cross_route = CASES[name]
+    ops = probe.ops
+    x, y = sets_of(probe, fam, n, n2, d, seed)
+    assert ops.knn_path(n, n, d, k) == 3                                       # the production filter form, by shape
+    if ops.prdc_path(n, n2, d) != 3:                                           # (D = 4096: the membership filter's verification tile does not fit)
+        cross_route = None
+    ops.filter_stats_read("cuda:0")
+    r = ops.knn_radii(x, k)
+    s = ops.filter_stats_read("cuda:0")
+    assert torch.equal(r.view(torch.int32), probe.exact_radii(x, k).view(torch.int32)), "radii differ from the exact kernel's"
+    # the filter's error bound, measured on every pair the verification evaluated
+    if s["bound_pairs"] > 0:
+        assert 0.0 <= s["bound_ratio_max"] <= 1.0, s
+        print(f"{name}: |a - t| / bound <= {s['bound_ratio_max']:.3f} over {s['bound_pairs']} pairs")
+    if knn_route == "plain":
+        assert s["knn_fallback_rows"] == 0 and s["knn_verified_pairs"] > 0 and s["bound_pairs"] == s["knn_verified_pairs"], s
+    elif knn_route in ("check A", "scale"):
+        assert s["knn_fallback_rows"] == n, s                               # the exact general kernel took every row
+        if knn_route == "check A":
+            assert s["knn_queued"] == 0, s                                  # ... before the sweep queued anything
+    elif knn_route == "marking":
+        assert 32 <= s["knn_fallback_rows"] < n // 8 and s["knn_verified_pairs"] > 0, s    # the identical block: batched fix-up
+    r2 = ops.knn_radii(y, k)
+    ops.filter_stats_read("cuda:0")
+    want_min = seed % 2 == 1
+    got = ops.prdc_counts(x, y, r, r2, want_min=want_min)
+    s = ops.filter_stats_read("cuda:0")
+    want = probe.exact_counts(x, y, r, r2, want_min)
+    for a, b in zip(got, want):
+        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
+    assert s["prdc_calls"] == (1 if ops.prdc_path(n, n2, d) == 3 else 0)
+    if cross_route == "plain":
+        assert s["prdc_fallback_calls"] == 0 and s["prdc_overflow_queue"] == 0, s
+    elif cross_route == "overflow":
+        assert s["prdc_fallback_calls"] == 0 and s["prdc_overflow_queue"] > 0, s
+    elif cross_route in ("budget", "scale"):
+        assert s["prdc_fallback_calls"] == 1, s
+        if cross_route == "budget":
+            assert s["prdc_overflow_queue"] > 0, s
+
+
+@pytest.mark.parametrize("fam,rows,dim,k,world,seed", [
+    ("randn", 20011, 128, 5, 2, 31), ("unit", 33000, 256, 10, 3, 32), ("randn", 9000, 512, 1, 8, 33), ("scales", 40000, 136, 3, 4, 34),
+    ("silence", 33000, 128, 5, 2, 35), ("dups", 20011, 200, 5, 3, 36), ("clustered", 9000, 256, 5, 4, 37), ("hub", 20011, 128, 3, 8, 38)])
+def test_partitioned_route(probe, fam, rows, dim, k, world, seed):
+    """tools/fuzz_part.py, eight seeded cases: the partitioned k-NN (bounds per rank, each rank's share of the symmetric sweep,
+    the merge of the all-gathered lists incl. its flagged-row routes) against the one-GPU entry point, bit for bit."""
+    ops = probe.ops
+    x = probe.make(fam, rows, dim, seed)
+    assert ops.knn_sym_eligible(rows, dim, k)
+    want = ops.knn_radii(x, k)
+    shards = [(rows * p // world, rows * (p + 1) // world) for p in range(world)]
+    bounds = torch.cat([ops.knn_bounds(x, k, lo, hi - lo) for lo, hi in shards])
+    lists = torch.stack([ops.knn_sym_part(x, k, p, world, bounds) for p in range(world)])
+    got = ops.knn_lists_finish(lists, x, k)
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    assert torch.equal(want.view(torch.int32), probe.exact_radii(x, k).view(torch.int32))
+
+
+def test_measured_bound_is_reported_per_family(probe):
+    """The slack of the bound on the families VERDICT r4 item 4 names, in one place: cancelling halves, four decades of row
+    norms, D = 4096, rows whose small elements the f16 copy flushes.  (`scales` as a whole goes to the exact kernel - check A -
+    so its decades are taken one SET at a time here: a set scaled by 1e-2 and one by 1e2.)"""
+    ops = probe.ops
+    worst = {}
+    g = torch.Generator(device="cuda").manual_seed(41)
+    base = torch.randn(16000, 256, generator=g, device="cuda")
+    fams = {"cancel": sets_of(probe, "cancel", 16000, 8, 256, 42)[0], "scaled_down": base * 1e-2, "scaled_up": base * 1e2,
+            "d4096": sets_of(probe, "manifold", 6200, 8, 4096, 45)[0], "subnormal": sets_of(probe, "subnormal", 16000, 8, 128, 43)[0],
+            "unit": probe.make("unit", 20000, 512, 44)}
+    for name, x in fams.items():
+        ops.filter_stats_read("cuda:0")
+        ops.knn_radii(x, 5)
+        s = ops.filter_stats_read("cuda:0")
+        if s["bound_pairs"]:
+            worst[name] = s["bound_ratio_max"]
+            assert s["bound_ratio_max"] <= 1.0, (name, s)
+    print("measured |a - t| / (fast_c (|x|^2 + G)) per family:", {k: round(v, 3) for k, v in worst.items()})
+    assert len(worst) >= 4, worst                 # most of the families reach the verification (the rest fall back: no statement)
