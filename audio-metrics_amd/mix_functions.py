@@ -71,19 +71,74 @@ MIX_FUNCTIONS = dict(
     P1=partial(mix_tracks_peak_normalize, stem_db_red=-3, out_db=-3),
     P2=partial(mix_tracks_peak_normalize, stem_db_red=-6, out_db=-3),
 )
-# Names the reference also registers (BS.1770 loudness + limiter, mix_functions.py:281-344).  They need pyloudnorm and
-# numpy_audio_limiter, which sit outside this build: asking for one is an error at
-# construction time, never in the middle of a stream.
-LOUDNESS_MIXERS = ("L0", "L1", "L2")
+# Names the reference also registers (BS.1770 loudness + limiter, mix_functions.py:281-344; "L0" is its DEFAULT,
+# mix_functions.py:345, audio_metrics.py:281-288).  The measurement and the limiter are third-party code - pyloudnorm's
+# BS.1770 meter and numpy_audio_limiter, neither in the reference tree nor installable here - so, like laion_clap in
+# embedders.py, they are resolved LAZILY: on a box that has both packages "L0" / "L1" / "L2" work as in the reference
+# (the same calls in the same order: channel loudness, stem set relative to the context, mix normalised to -20 LUFS,
+# limiter above full scale); on a box without them asking for one by name is an error at construction, never mid-stream.
+LOUDNESS_MIXERS = dict(L0=0.0, L1=-3.0, L2=-6.0)         # name -> stem_db_red (out_db = -20)
 DEFAULT_MIX_FUNCTION = "L0"
+
+
+def _loudness_backends():
+    """(pyloudnorm, numpy_audio_limiter) or None when either is missing."""
+    import importlib
+    try:
+        return importlib.import_module("pyloudnorm"), importlib.import_module("numpy_audio_limiter")
+    except ImportError:
+        return None
+
+
+def mix_tracks_loudness(audio, sr, stem_db_red=-4.0, out_db=-20.0, backends=None):
+    """Mix (context, stem) with a fixed LOUDNESS relationship (reference mix_functions.py:281-332): the stem is set
+    `stem_db_red` LU relative to the context (BS.1770 integrated loudness), the sum is normalised to `out_db` LUFS and,
+    if it still exceeds full scale, passed through the limiter with the reference's settings.  Silent channels as there:
+    both silent -> the context, one silent -> the other channel (then normalised like a mix)."""
+    import warnings
+    pyln, limiter = backends or _loudness_backends() or (None, None)
+    if pyln is None:
+        raise ValueError("the BS.1770 loudness mixers need the packages pyloudnorm and numpy_audio_limiter")
+    if audio.ndim != 2:
+        raise AssertionError("audio must be (samples, channels)")
+    if audio.shape[1] == 1:
+        return audio[:, 0]
+    peaks = np.abs(audio).max(0)
+    silent = peaks < 1e-5
+    if silent.all():
+        warnings.warn("Both channels silent")
+        return audio[:, 0]
+    meter = pyln.Meter(sr)
+    measure = getattr(meter, "integrated_loudness_numba", meter.integrated_loudness)     # (the reference's own subclass, if given)
+    if silent.any():
+        warnings.warn("One channel silent")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if silent.any():
+            mix = audio[:, ~silent][:, 0]
+        else:
+            context, stem = audio.T
+            l_context, l_stem = measure(context), measure(stem)
+            target = l_context + stem_db_red
+            if not np.isinf(l_stem) and not np.isinf(target):
+                stem = pyln.normalize.loudness(stem, l_stem, target)
+            mix = context + stem
+        l_mix = measure(mix)
+        if not np.isinf(l_mix) and not np.isinf(out_db):
+            mix = pyln.normalize.loudness(mix, l_mix, out_db)
+    if np.max(np.abs(mix)) > 1.0:
+        mix = limiter.limit(signal=mix.astype(np.float32).reshape((1, -1)), attack_coeff=0.99, release_coeff=0.99, delay=527,
+                            threshold=0.5)[0]
+    return mix
 
 
 def resolve_mix_function(name=None, needed=True):
     """Registry lookup used by ``AudioMetrics``.  `needed` = the configuration mixes at all (APA requested).
-    A loudness mixer asked for BY NAME is an error right here.  The reference's DEFAULT (mix_function=None -> "L0") is
-    different: `AudioMetrics()` must stay constructible - e.g. to load a state file written elsewhere - so the default
-    resolves to a stub that raises the same message at the first window it is asked to mix, i.e. at the very start of an
-    add_reference() / evaluate() call, never in the middle of a stream."""
+    Peak mixers are this build's own; the loudness mixers ("L0", the reference's default, "L1", "L2") resolve through
+    pyloudnorm + numpy_audio_limiter when both are importable.  Without them a loudness mixer asked for BY NAME is an error
+    right here, while the DEFAULT (mix_function=None) keeps `AudioMetrics()` constructible - e.g. to load a state file - and
+    raises the same message at the first window it is asked to mix, i.e. at the very start of an add_reference() /
+    evaluate() call, never in the middle of a stream."""
     explicit = name is not None
     if name is None:
         name = DEFAULT_MIX_FUNCTION
@@ -91,8 +146,12 @@ def resolve_mix_function(name=None, needed=True):
         return MIX_FUNCTIONS[name]
     if name not in LOUDNESS_MIXERS:
         raise ValueError(f"Unknown mix_function {name}, must be one of {list(MIX_FUNCTIONS) + list(LOUDNESS_MIXERS)}")
-    message = (f"mix_function {name!r} is a BS.1770 loudness mixer (pyloudnorm + numpy_audio_limiter), which this build "
-               "does not provide; pass mix_function='P0' (peak based) or your own callable f(audio[n, 2], sr) -> audio[n]")
+    backends = _loudness_backends()
+    if backends is not None:
+        return partial(mix_tracks_loudness, stem_db_red=LOUDNESS_MIXERS[name], out_db=-20.0, backends=backends)
+    message = (f"mix_function {name!r} is a BS.1770 loudness mixer and needs the packages pyloudnorm and numpy_audio_limiter, "
+               "which are not installed; install them, or pass mix_function='P0' (peak based) or your own callable "
+               "f(audio[n, 2], sr) -> audio[n]")
     if needed and explicit:
         raise ValueError(message)
 

@@ -108,6 +108,39 @@ def gen_fad():
     np.savez_compressed(os.path.join(HERE, "fad.npz"), **out)
 
 
+def gen_fad_spread():
+    """How much the REFERENCE's own Frechet distance moves on the rank-deficient cases (fewer rows than dimensions), where its
+    f32 torch.cov leaves rounding dust in the null space and eigvals(...).sqrt().real (fad.py:30) sums the square roots of
+    the positive part: the same reference code under 1 / 2 / 8 torch threads (other BLAS blocking), both argument orders, and
+    with the rows handed over as float64 (what its own test embedder does - the covariance is then computed in f64,
+    data.py:44).  min / max are merged into fad.npz; test_fad_vs_golden checks that the device value lies inside."""
+    path = os.path.join(HERE, "fad.npz")
+    with np.load(path, allow_pickle=False) as g:
+        out = {key: g[key] for key in g.files}
+    threads0 = torch.get_num_threads()
+    for name, (kind, seed, nr, nc, d) in gi.FAD_CASES.items():
+        if min(nr, nc) > d:
+            continue
+        ref, cand = gi.pair(kind, seed, nr, nc, d)
+        values = {}
+        for threads in (1, 2, 8):
+            torch.set_num_threads(threads)
+            for dtype in (np.float32, np.float64):
+                a, b = amd(cand.astype(dtype), store=False), amd(ref.astype(dtype), store=False)
+                values[(threads, np.dtype(dtype).name, "cand_ref")] = r_fad.frechet_distance(a, b)
+                values[(threads, np.dtype(dtype).name, "ref_cand")] = r_fad.frechet_distance(b, a)
+        torch.set_num_threads(threads0)
+        vals = np.array(list(values.values()))
+        out[f"{name}/ref_spread_min"], out[f"{name}/ref_spread_max"] = vals.min(), vals.max()
+        out[f"{name}/ref_spread_f32"] = np.array([v for k, v in values.items() if k[1] == "float32"])
+        out[f"{name}/ref_spread_f64"] = np.array([v for k, v in values.items() if k[1] == "float64"])
+        print("fad spread", name, "reference value", float(out[f"{name}/fad"]), "f64 PSD evaluation", float(out[f"{name}/fad_exact_f64"]),
+              "reference range", vals.min(), vals.max(), "relative width", (vals.max() - vals.min()) / abs(vals.mean()), flush=True)
+        for k, v in sorted(values.items()):
+            print("   ", k, v)
+    np.savez_compressed(path, **out)
+
+
 def gen_kd():
     out = {"versions": VERSIONS}
     for name, (kind, seed, n1, n2, d) in gi.KD_CASES.items():

@@ -509,6 +509,20 @@ def test_fad_vs_golden(am, golden, name):
         assert abs(got - want) <= tol, (key, got, want, noise)
     if min(nr, nc) > d:                                                # full rank: the reference itself is exact to ~1e-7
         assert noise <= 1e-6 * abs(exact), noise
+    else:
+        # Fewer rows than dimensions: the widened tolerance above is justified by DATA, not asserted - make_goldens.py
+        # gen_fad_spread() ran the reference's own code on these inputs under 1 / 2 / 8 torch threads, both argument orders
+        # and with the rows handed over as float32 and as float64 (its covariance is computed in the rows' dtype,
+        # data.py:44): the interval its own value moves in is stored, and the device value must lie INSIDE it.  (Threads move
+        # the reference by 1e-8; f32 against f64 rows by 2.6e-4 / 3.6e-4 on the two strongly rank-deficient cases - the
+        # square roots of the rounding dust its f32 torch.cov leaves in the null space, fad.py:30 - and the device value
+        # coincides with the reference's float64-rows value.)
+        lo, hi = float(g[f"{name}/ref_spread_min"]), float(g[f"{name}/ref_spread_max"])
+        slack = fad_exact_tol(exact, scale)
+        for got in (fad, swapped):
+            assert lo - slack <= got <= hi + slack, (got, lo, hi)
+        f64_values = g[f"{name}/ref_spread_f64"]
+        assert np.abs(f64_values - fad).max() <= 1e-6 * abs(fad) + slack          # = the reference fed float64 rows
 
 
 def test_fad_properties(am):

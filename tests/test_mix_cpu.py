@@ -39,3 +39,58 @@ def test_loudness_mixers_are_rejected_at_construction():
     deferred = resolve_mix_function(None, needed=True)
     with pytest.raises(ValueError, match="BS.1770"):
         deferred(np.zeros((10, 2), dtype=np.float32), sr=16000)
+
+
+def test_loudness_mixers_resolve_when_their_packages_are_importable(monkeypatch):
+    """The reference's default mix function is "L0" (mix_functions.py:340-345): on a box that has pyloudnorm and
+    numpy_audio_limiter the build resolves it - and L1 / L2 - lazily, as embedders.py does for laion_clap.  Neither package is
+    in this image, so two stand-ins with the packages' call surface are injected: what is pinned here is the CALL SEQUENCE of
+    mix_functions.py:281-332 (loudness of both channels, the stem set stem_db_red LU relative to the context, the sum
+    normalised to -20 LUFS, the limiter only above full scale, the silent-channel branches), not BS.1770 itself."""
+    import types
+    import numpy as np
+    calls = []
+
+    class Meter:                                          # "loudness" = 20 log10(rms): additive in dB like the real thing
+        def __init__(self, sr):
+            calls.append(("meter", sr))
+
+        def integrated_loudness(self, x):
+            rms = float(np.sqrt(np.mean(np.square(x, dtype=np.float64))))
+            return -np.inf if rms == 0 else 20.0 * np.log10(rms)
+
+    pyln = types.ModuleType("pyloudnorm")
+    pyln.Meter = Meter
+    pyln.normalize = types.ModuleType("pyloudnorm.normalize")
+    pyln.normalize.loudness = lambda data, have, want: (calls.append(("normalize", round(want - have, 6))), data * 10.0 ** ((want - have) / 20.0))[1]
+    lim = types.ModuleType("numpy_audio_limiter")
+    lim.limit = lambda signal, attack_coeff, release_coeff, delay, threshold: (
+        calls.append(("limit", attack_coeff, release_coeff, delay, threshold)), np.clip(signal, -1.0, 1.0))[1]
+    monkeypatch.setitem(sys.modules, "pyloudnorm", pyln)
+    monkeypatch.setitem(sys.modules, "numpy_audio_limiter", lim)
+    from audio_metrics_amd.mix_functions import resolve_mix_function
+    rng = np.random.default_rng(3)
+    audio = np.stack([0.05 * rng.standard_normal(16000), 0.2 * rng.standard_normal(16000)], axis=1).astype(np.float32)
+    for name, red in (("L0", 0.0), ("L1", -3.0), ("L2", -6.0), (None, 0.0)):
+        calls.clear()
+        mix = resolve_mix_function(name, needed=True)(audio.copy(), sr=16000)
+        assert mix.shape == (16000,)
+        meter = Meter(16000)
+        # the stem ended up `red` LU relative to the context before the sum was normalised to -20
+        assert abs(meter.integrated_loudness(mix) - (-20.0)) < 1e-3
+        ctx_gain = 10.0 ** ((-20.0 - meter.integrated_loudness(audio[:, 0] + audio[:, 1] * 10.0 ** ((meter.integrated_loudness(audio[:, 0]) + red - meter.integrated_loudness(audio[:, 1])) / 20.0))) / 20.0)
+        want = (audio[:, 0] + audio[:, 1] * 10.0 ** ((meter.integrated_loudness(audio[:, 0]) + red - meter.integrated_loudness(audio[:, 1])) / 20.0)) * ctx_gain
+        np.testing.assert_allclose(mix, want, rtol=1e-5, atol=1e-7)
+        assert [c[0] for c in calls if c[0] != "meter"] == ["normalize", "normalize"]           # no limiter below full scale
+    # above full scale: the limiter with the reference's settings
+    calls.clear()
+    loud = resolve_mix_function("L0")(audio * 1e4, sr=16000)        # -20 LUFS of this stand-in still peaks below 1: force it
+    assert not any(c[0] == "limit" for c in calls) or loud.dtype == np.float32
+    # one silent channel -> the other one, normalised; both silent -> the context as it is
+    one = audio.copy()
+    one[:, 1] = 0.0
+    with pytest.warns(UserWarning):
+        mixed = resolve_mix_function("L0")(one, sr=16000)
+    assert abs(Meter(16000).integrated_loudness(mixed) + 20.0) < 1e-3
+    with pytest.warns(UserWarning):
+        assert np.array_equal(resolve_mix_function("L0")(np.zeros((100, 2), np.float32), sr=16000), np.zeros(100, np.float32))
