@@ -54,14 +54,75 @@ def _alone(world):
         return False
     return world == 1
 
+# ---- optional exchange log (bench.py --gpus N): what every collective of an evaluate moved and how long the COMPUTE stream
+# stood still for it.  Off by default (no events, no host clocks).  exchange_log_begin() ... exchange_log_end() around one
+# evaluate_sharded() returns a list of records {name, kind, bytes, exposed_ms, host_ms}:
+#   exposed_ms  HIP events on the compute stream right before / behind the point where it waits for the collective - the time
+#               the exchange is NOT hidden under kernels (for a blocking backend - gloo - the host time is the whole story)
+#   host_ms     wall time the issuing call and the wait kept the host
+# The first real multi-GPU run then says by itself which exchange is exposed and by how much.
+_EXCHANGE_LOG = None
+
+
+def exchange_log_begin():
+    global _EXCHANGE_LOG
+    _EXCHANGE_LOG = []
+
+
+def exchange_log_end():
+    """The records of the evaluate since exchange_log_begin(); synchronises the device once to read the event pairs."""
+    global _EXCHANGE_LOG
+    log, _EXCHANGE_LOG = _EXCHANGE_LOG or [], None
+    if any(r.get("_events") for r in log) and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    out = []
+    for r in log:
+        ev = r.pop("_events", None)
+        r["exposed_ms"] = float(ev[0].elapsed_time(ev[1])) if ev else r["host_ms"]
+        out.append(r)
+    return out
+
+
+class _Exchange:
+    """Context manager around the point where the current stream waits for a collective (or issues a blocking one)."""
+
+    def __init__(self, name, kind, tensor, world):
+        self.on = _EXCHANGE_LOG is not None
+        if not self.on:
+            return
+        import time
+        self.t0 = time.perf_counter()
+        self.rec = {"name": name, "kind": kind, "bytes": int(tensor.numel() * tensor.element_size() * (world if kind == "all_gather" else 1))}
+        self.cuda = tensor.is_cuda
+        if self.cuda:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(tensor.device))
+            self.dev = tensor.device
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if not self.on or exc[0] is not None:
+            return False
+        import time
+        if self.cuda:
+            self.e1.record(torch.cuda.current_stream(self.dev))
+            self.rec["_events"] = (self.e0, self.e1)
+        self.rec["host_ms"] = (time.perf_counter() - self.t0) * 1e3
+        _EXCHANGE_LOG.append(self.rec)
+        return False
+
+
 def shard_bounds(n, world, rank):
     """Contiguous row range [lo, hi) of `rank` (rows_g = [g*N/G, (g+1)*N/G))."""
     return n * rank // world, n * (rank + 1) // world
 
 
-def _all_reduce(t, world, group):
+def _all_reduce(t, world, group, name="all_reduce"):
     if not _alone(world):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        with _Exchange(name, "all_reduce", t, world):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
@@ -148,8 +209,8 @@ def _all_gather_into(out, local, world, group, async_op=False):
 class _Gathered:
     """Row shards of unequal length being concatenated: start() issues the collective, rows() waits and trims."""
 
-    def __init__(self, local, counts, world, group, async_op=True):
-        self.counts, self.world, self.local = counts, world, local
+    def __init__(self, local, counts, world, group, async_op=True, name="all_gather"):
+        self.counts, self.world, self.local, self.name = counts, world, local, name
         self.work = None
         self._rows = None
         self.alone = _alone(world)
@@ -163,7 +224,11 @@ class _Gathered:
             pad = torch.zeros((cmax, *width), dtype=local.dtype, device=local.device)
             pad[:local.shape[0]] = local
         self.out = torch.empty((world * cmax, *width), dtype=local.dtype, device=local.device)
-        self.work = _all_gather_into(self.out, pad, world, group, async_op=async_op)
+        if async_op:
+            self.work = _all_gather_into(self.out, pad, world, group, async_op=True)
+        else:
+            with _Exchange(name, "all_gather", pad, world):
+                self.work = _all_gather_into(self.out, pad, world, group, async_op=False)
         self._pad = pad                                   # stays alive until the collective has run
 
     def rows(self):
@@ -172,7 +237,8 @@ class _Gathered:
         if self._rows is not None:
             return self._rows
         if self.work is not None:
-            self.work.wait()
+            with _Exchange(self.name, "all_gather", self._pad, self.world):      # (the wait: what of the gather is not hidden)
+                self.work.wait()
             self.work = None
         cmax = max(self.counts)
         if all(c == cmax for c in self.counts):
@@ -182,8 +248,8 @@ class _Gathered:
         return self._rows
 
 
-def _all_gather_rows(local, counts, world, group):
-    return _Gathered(local, counts, world, group, async_op=False).rows()
+def _all_gather_rows(local, counts, world, group, name="all_gather"):
+    return _Gathered(local, counts, world, group, async_op=False, name=name).rows()
 
 
 def global_count(n_local, device, group=None):
@@ -240,7 +306,7 @@ def global_means_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group):
         return ops.colsum(x) if x.shape[0] > 0 else torch.zeros(d, dtype=torch.float64, device=dev)
 
     sums = torch.stack((colsum(ref_local), colsum(cand_local)))                 # [2, D]
-    _all_reduce(sums, world, group)
+    _all_reduce(sums, world, group, "column_sums")
     return sums[0] / float(n_ref), sums[1] / float(n_cand)
 
 
@@ -253,7 +319,7 @@ def global_covariances_pair(ref_local, cand_local, mean_r, mean_c, n_ref, n_cand
         return ops.scatter(x, mean) if x.shape[0] > 0 else torch.zeros((d, d), dtype=torch.float64, device=dev)
 
     sc = torch.stack((scatter(ref_local, mean_r), scatter(cand_local, mean_c)))  # [2, D, D]
-    _all_reduce(sc, world, group)
+    _all_reduce(sc, world, group, "scatters")
     return sc[0] / float(max(n_ref - 1, 1)), sc[1] / float(max(n_cand - 1, 1))
 
 
@@ -349,12 +415,13 @@ def sharded_radii(local, full, counts, k, ops, world, rank, group, prepared=None
     if not _alone(world) and min(counts) > 0 and hasattr(ops, "knn_sym_part") and full.dtype != torch.float64 \
             and ops.knn_sym_eligible(n, d, k):
         extra = {} if prepared is None else {"prepared": prepared}
-        bounds = _all_gather_rows(ops.knn_bounds(full, k, lo, counts[rank], **extra), counts, world, group)
+        bounds = _all_gather_rows(ops.knn_bounds(full, k, lo, counts[rank], **extra), counts, world, group, "knn_bounds")
         if after_first_exchange is not None:
             after_first_exchange()
         lists = ops.knn_sym_part(full, k, rank, world, bounds, **extra)
         all_lists = torch.empty((world, *lists.shape), dtype=lists.dtype, device=lists.device)
-        _all_gather_into(all_lists.view(-1), lists.view(-1), world, group)
+        with _Exchange("knn_lists", "all_gather", lists, world):
+            _all_gather_into(all_lists.view(-1), lists.view(-1), world, group)
         r_full = ops.knn_lists_finish(all_lists, full, k)
         return r_full[lo:hi], r_full
     if after_first_exchange is not None:
@@ -365,7 +432,7 @@ def sharded_radii(local, full, counts, k, ops, world, rank, group, prepared=None
         r_local = ops.knn_radii(local, k, columns=full)
     else:
         r_local = torch.empty(0, dtype=torch.float64 if full.dtype == torch.float64 else torch.float32, device=full.device)
-    return r_local, _all_gather_rows(r_local, counts, world, group)
+    return r_local, _all_gather_rows(r_local, counts, world, group, "radii")
 
 
 def result_from_record(head, mmds, metrics, n_ref, n_cand, nearest_k):
@@ -473,12 +540,12 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
     ref_g = cand_g = bulk = None
     if need_full:
         bulk = None if _alone(world) else _bulk_group(group)
-        ref_g = _Gathered(ref_local, ref_counts, world, bulk if bulk is not None else group)
+        ref_g = _Gathered(ref_local, ref_counts, world, bulk if bulk is not None else group, name="reference_rows")
 
     def start_cand():
         nonlocal cand_g
         if cand_g is None:
-            cand_g = _Gathered(cand_local, cand_counts, world, bulk if bulk is not None else group)
+            cand_g = _Gathered(cand_local, cand_counts, world, bulk if bulk is not None else group, name="candidate_rows")
         return cand_g
 
     if need_full and (bulk is not None or "prdc" not in metrics):
@@ -516,7 +583,7 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
             local_tot = ops.prdc_reduce(col, rany, rcov)
             packed[:n_cand] = col
             packed[n_cand:] = torch.stack((local_tot[1], local_tot[3])).to(torch.int32)
-        _all_reduce(packed, world, group)
+        _all_reduce(packed, world, group, "membership_counts")
         none = torch.zeros(0, dtype=torch.uint8, device=dev)
         tot = ops.prdc_reduce(packed[:n_cand], none, none)                     # [#cols with count > 0, 0, sum of counts, 0]
         prdc_pending = (tot, packed[n_cand:], k)
@@ -534,7 +601,7 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
             part = ops.kd_poly(cand_full, ref_full, upload(idx1[rank::world], dev), upload(idx2[rank::world], dev),
                                1.0 / d, KID_COEF0, KID_DEGREE)
             mmds[rank::world] = part
-        _all_reduce(mmds, world, group)
+        _all_reduce(mmds, world, group, "kd_subsets")
         kd_pending = mmds
 
     # ONE read-back for everything that is already on the device: per-subset MMD^2 values, PRDC totals (the Frechet record

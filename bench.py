@@ -374,6 +374,42 @@ def main():
     fence()
     unfused_ms = (time.perf_counter() - t0) / probe_steps * 1e3
 
+    # ---- several ranks: what every collective of one step moved and how long the compute stream stood still for it
+    # (distributed.exchange_log_*), and the bandwidth of ONE all-gather of a whole set with nothing else running - the
+    # number that tells a mesh (every peer's share over its own xGMI link at once) from a ring (one link's worth), which is
+    # what decides whether the two 205 MB gathers hide under the sweeps at 8 ranks (tools/scale_model.py predicts both)
+    exchange = None
+    if world > 1:
+        from audio_metrics_amd import distributed as dmod
+        fence()
+        dmod.exchange_log_begin()
+        evaluate_sharded(ref_l, cand_l, metrics=("fad", "kd", "prdc"), nearest_k=k, shard_counts=shard_counts)
+        records = dmod.exchange_log_end()
+        fence()
+        gathered = torch.empty((n, d), dtype=ref_l.dtype, device=dev)
+        equal = all(c == shard_counts[0][0] for c in shard_counts[0])
+        gather_ms = None
+        if equal:                                            # (unequal shards travel padded: measured inside the step only)
+            for _ in range(2):
+                fence()
+                t1 = time.perf_counter()
+                dmod._all_gather_into(gathered, ref_l.contiguous(), world, None)
+                fence()
+                gather_ms = (time.perf_counter() - t1) * 1e3
+        t = torch.tensor([sum(r["exposed_ms"] for r in records), gather_ms or 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        received = (world - 1) / world * n * d * ref_l.element_size()
+        exchange = {"collectives": records, "exchange_exposed_ms": float(t[0].item()),
+                    "gather_ms": float(t[1].item()) if gather_ms else None,
+                    "gather_GBps": (received / (float(t[1].item()) * 1e-3) / 1e9) if gather_ms else None,
+                    "gather_note": f"one all-gather of a whole {n} x {d} set alone on the fabric (max over ranks): bytes a rank "
+                                   "RECEIVES / time.  7 peers x ~76 GB/s per direction: ~370 GB/s if RCCL drives every link at once "
+                                   "(mesh), ~60 GB/s through one link (ring)",
+                    "exposed_note": "per collective of one step on rank 0: HIP events on the compute stream around the point where "
+                                    "it waits for the exchange (exposed_ms; gloo: host time), bytes; exchange_exposed_ms = their "
+                                    "sum, max over ranks",
+                    "backend": backend}
+
     # ---- other workloads SURVEY 8(d) asks for beside the headline one (never `value`): the filter kernels' speed depends
     # on how many pairs their error bound cannot decide, i.e. on the data and on k
     variants = {}
@@ -544,6 +580,9 @@ def main():
             "result_check": check_against_fixture(result, args.data, n, d, k),
             "variants": variants,
         }
+        if exchange is not None:
+            out["exchange"] = exchange
+        out["scale_model"] = scale_model_prediction(world, n, d, k, out["ms_per_step"])
         if world == 1:
             out["warm"] = warm_evaluate(am, ref, cand, k, max(1, min(args.steps, 3)))
             out["first_call"] = first_call(step, fence)
@@ -553,6 +592,30 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def scale_model_prediction(world, n, d, k, measured_ms):
+    """tools/scale_model.py's prediction for this rank count (one GPU emulating a rank's compute segments, the collectives
+    simulated under two fabric assumptions) beside the measured step: one run of the driver's scaling bench then says which
+    assumption holds.  None when no prediction for this workload is committed."""
+    path = os.path.join(ROOT, "profiles", "scale_model.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if [table.get("rows"), table.get("dim"), table.get("nearest_k")] != [n, d, k]:
+        return None
+    row = table.get("worlds", {}).get(str(world))
+    if row is None:
+        return None
+    mesh, ring = row.get("f32_first/mesh", {}), row.get("f32_first/ring", {})
+    return {"source": "profiles/scale_model.json (tools/scale_model.py on ONE GPU, library sources " + str(table.get("library", "?"))[:12] + ")",
+            "predicted_ms_mesh": mesh.get("step_ms"), "predicted_ms_ring": ring.get("step_ms"),
+            "predicted_exposed_ms_mesh": mesh.get("exposed_ms"), "predicted_exposed_ms_ring": ring.get("exposed_ms"),
+            "measured_ms": measured_ms,
+            "note": "mesh: every peer's share over its own xGMI link at once at 70 % of 76.5 GB/s; ring: the same volumes through "
+                    "one link per direction at 80 %; compute segments timed on one GPU, collectives simulated in issue order"}
 
 
 def per_step(stats, steps):

@@ -256,6 +256,17 @@ def test_bench_multi_rank_launch(ranks, rows, dim, plain):
         assert out2["result"][key] == out1["result"][key], key
     assert abs(out2["result"]["fad"] - out1["result"]["fad"]) <= 1e-5 * abs(out1["result"]["fad"])
     assert abs(out2["result"]["kernel_distance_mean"] - out1["result"]["kernel_distance_mean"]) <= 1e-9
+    # the first real multi-GPU run explains itself: per-collective exposed time and volume, the
+    # all-gather bandwidth measured alone, the scale model's prediction for this rank count where one is committed
+    ex = out2["exchange"]
+    names = [r["name"] for r in ex["collectives"]]
+    for must in ("column_sums", "scatters", "reference_rows", "candidate_rows", "radii", "membership_counts", "kd_subsets"):
+        assert must in names, names
+    assert all(r["bytes"] > 0 and r["exposed_ms"] >= 0.0 and r["kind"] in ("all_reduce", "all_gather") for r in ex["collectives"])
+    assert ex["exchange_exposed_ms"] >= 0.0 and ex["backend"] == "gloo"
+    if rows % ranks == 0:
+        assert ex["gather_GBps"] > 0.0 and ex["gather_ms"] > 0.0
+    assert "exchange" not in out1 and "scale_model" in out2          # (None unless profiles/scale_model.json covers this workload)
 
 
 def test_overlapped_frechet_solve_gives_the_same_result():

@@ -20,7 +20,8 @@ Orders compared:
   * `f16_first` (not built): the prepared f16 copies + norms (N x D x 2) first, so that the filter
     sweeps start after half the bytes; the f32 rows - needed only by the exact verification and the kernel distance - behind.
 
-    python tools/scale_model.py > profiles/r4/scale_model.json        (on the GPU box; AB_ROWS=1000000 for configs[3])
+    python tools/scale_model.py > profiles/scale_model.json        (on the GPU box; AB_ROWS=1000000 for configs[3]);
+    bench.py --gpus N prints this file's prediction for N beside its measured step (`scale_model` in the line)
 """
 import json
 import os
@@ -197,6 +198,7 @@ def main():
     out = {"workload": f"bench.py: FAD+KD+PRDC(k={k}) cold evaluate of 2 x {n} x {d} ({os.environ.get('AB_DATA', 'randn')})", "measured_on": "ONE MI355X (rank 0 emulated)",
            "assumptions": {"xgmi_link_GBps_per_direction": LINK / 1e9, "links_per_gpu": 7, "collective_latency_us": LAT * 1e6,
                            "mesh": "all links at once at 70 % of the link rate", "ring": "one link per direction at 80 %"},
+           "rows": n, "dim": d, "nearest_k": k, "data": os.environ.get("AB_DATA", "randn"),
            "library": library_stamp(), "worlds": {}}
     for world in [int(w) for w in os.environ.get("AB_WORLDS", "1,2,4,8").split(",")]:
         seg = measure(n, d, k, world, dev)
