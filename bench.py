@@ -164,17 +164,37 @@ def launch_ranks(n_ranks):
     GPU, let the child write rank 0's JSON line to our stdout, and exit with its code.  (A child, never an exec: replacing
     a process that has initialised the GPU takes the box down on this pool; this one has not - `import torch` does not -
     but a child is right either way.)  The reference's multi-GPU entry needs no launcher either (util/gpu_parallel.py:79-118)."""
-    import socket
+    import signal
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC is the only form the host driver supports
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n_ranks, 1))))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-    return subprocess.run(cmd, env=env).returncode
+    # --standalone: torchrun runs its own c10d rendezvous on a port IT binds (a port found here by bind-then-close could be
+    # taken by somebody else before the child binds it again)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n_ranks), os.path.abspath(__file__), *sys.argv[1:]]
+    # the child gets its own session: a SIGTERM / SIGINT that ends THIS process (tools/run_round_checks.sh wraps every call in
+    # `timeout`) is passed on to the whole group - torchrun and its N ranks - instead of leaving them on the GPU until the
+    # collective timeout
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def pass_on(signum, frame):
+        try:
+            os.killpg(child.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+        try:
+            child.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        sys.exit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, pass_on)
+    return child.wait()
 
 
 def library_stamp():

@@ -155,8 +155,12 @@ double am_apa_f64(double d_y_x, double d_y_xp, double d_x_xp);
  *     m >= 512, 128 <= D <= 8192, degree == 3: split-f16 form - every gathered row as two f16 planes, three f16 MFMA
  *       stages per 64-element slab on the 256 x 256 engine, error of a dot product <= ~3 * 2^-22 |x||y|;
  *     everything else (and the RBF kernel): f32 MFMA on the 128 x 128 engine.
- *   am_kd_poly_workspace_bytes(S, m, D) is right for every shape.  am_kd_workspace_bytes(S, m) predates the split form
- *   and covers the f32 form only: am_kd_poly_f32 answers a too-small workspace with AM_ERR_WORKSPACE. */
+ *   am_kd_poly_workspace_bytes(S, m, D) is right for every shape.
+ *   DEPRECATED: am_kd_workspace_bytes(S, m) predates the split form and covers the f32 form only.  A caller that still sizes
+ *   with it gets AM_ERR_WORKSPACE from am_kd_poly_f32 at the shapes of the split form (m >= 512, 128 <= D <= 8192,
+ *   degree 3) - am_last_error() names the size am_kd_poly_workspace_bytes would have given - and never a silently different
+ *   kernel: the form, and with it the bits, depend on the shapes alone.  Kept for the RBF entry point's callers of round 2;
+ *   new code uses am_kd_poly_workspace_bytes / am_kd_rbf_workspace_bytes. */
 size_t am_kd_workspace_bytes(int S, int m);
 size_t am_kd_poly_workspace_bytes(int S, int m, int D);
 int am_kd_poly_f32(const float* X, int64_t N1, int64_t ldx,

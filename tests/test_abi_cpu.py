@@ -47,6 +47,25 @@ def test_host_side_entry_points():
     assert lib.am_prdc_workspace_bytes(1000, 2000, 128) > 0
 
 
+def test_deprecated_kd_workspace_query_is_answered_with_an_error_code():
+    """a workspace sized with the D-less am_kd_workspace_bytes (deprecated) is too small for the split-f16 form
+    that m >= 512, 128 <= D <= 8192, degree 3 take.  The entry point must answer AM_ERR_WORKSPACE - before any device work:
+    the check is host arithmetic on the sizes, so it runs here - and say which size it wanted; at shapes of the f32 form the
+    old query is still sufficient."""
+    import ctypes
+    import audio_metrics_amd as am
+    lib = am._lib.load()
+    S, m, D, n = 4, 1000, 512, 5000
+    old, new = lib.am_kd_workspace_bytes(S, m), lib.am_kd_poly_workspace_bytes(S, m, D)
+    assert 0 < old < new
+    assert lib.am_kd_poly_workspace_bytes(S, 200, D) == lib.am_kd_workspace_bytes(S, 200)        # small subsets: the f32 form
+    fake = ctypes.c_void_p(0x10000)                                   # 16-byte aligned, never dereferenced: the call stops at the size check
+    rc = lib.am_kd_poly_f32(fake, n, D, fake, n, D, D, fake, fake, S, m, 1.0 / D, 1.0, 3, fake, fake, old, None)
+    assert rc == -4 and lib.am_status_string(rc).decode() == "workspace too small"
+    msg = lib.am_last_error().decode()
+    assert str(new) in msg and "am_kd_poly_workspace_bytes" in msg, msg
+
+
 def test_no_cpu_fallback():
     import audio_metrics_amd as am
     with pytest.raises(am._lib.HipLibraryError):
