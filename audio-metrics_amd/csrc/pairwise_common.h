@@ -296,6 +296,9 @@ struct KnnFastEpilogue {
                             wq += __popcll(sel);
                             const unsigned j = jbase + mt * 32 + g4 * 8 + e;
                             // filed under its own row, or (mirrored only) under row j
+#ifdef AM_DEV_KNOBS
+                            if (TBX == WIDE_TILE_ROWS && (g_wide_dbg & 32)) continue;     // timing experiment: entries found, not stored
+#endif
                             if (own || mir) store_entry(slot, own ? prow[nt] : j, own ? j : prow[nt], own && mir, u);
                         }
                     }
@@ -306,6 +309,9 @@ struct KnnFastEpilogue {
                 // nearest neighbours practically never share a tile, and sixteen conditional insertions per tile were
                 // a large part of the epilogue while the bounds are loose.
                 const float vmin = tmin <= pl ? fmaxf(tmin, 0.f) : INFINITY;
+#ifdef AM_DEV_KNOBS
+                if (TBX == WIDE_TILE_ROWS && (g_wide_dbg & 64)) continue;                 // timing experiment: no lane-local lists
+#endif
                 if (__any(vmin < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], vmin);
             }
         }

@@ -117,8 +117,10 @@ def check_against_fixture(result, kind, n, d, k):
     kernel_distance outputs on these inputs, the four PRDC values come from oracle.prdc_blocked (row blocks of the
     reference's torch calls - its N x N formulation needs 164 GB at 100k rows)."""
     path = os.path.join(ROOT, "tests", "golden", "bench_prdc.npz")
+    if d != 512:
+        kind = f"{kind}_d{d}"                       # the narrower sets' keys carry the width (make_goldens.py gen_bench)
     tag = f"{kind}_k{k}"
-    if not (os.path.exists(path) and n == 100000 and d == 512):
+    if not (os.path.exists(path) and n == 100000):
         return None
     g = np.load(path, allow_pickle=False)
     diffs, ok = {}, True
@@ -443,6 +445,19 @@ def main():
         variants["stream_add_32"] = {"store": stream_add(am, ref, 32, True), "no_store": stream_add(am, ref, 32, False),
                                      "reference_cpu_embeddings_per_s": {"no_store": 24400, "store": [700, 1800]},
                                      "what": "AudioMetricsData.add() fed 32-row device batches of the reference set"}
+        if d == 512:
+            # VGGish's width (reference embedders/vggish.py:5-33: 128-d; BASELINE configs[0]'s shape) at the headline row count:
+            # the tile kernels' MFMA work shrinks with D, their epilogues do not
+            vr, vc = (torch.as_tensor(a).to(dev) for a in gi.bench_pair("randn", n, 128))
+            ops.filter_stats_read(dev)
+            dt, vres = timed_steps(lambda: evaluate_sharded(vr, vc, metrics=("fad", "kd", "prdc"), nearest_k=k), fence, 5, 2)
+            stats = ops.filter_stats_read(dev)
+            variants["vggish_128"] = {"ms_per_step": dt / 5 * 1e3, "embeddings_per_s": 5 * 2 * n / dt,
+                                      "workload": f"FAD+KD+PRDC(k={k}) cold evaluate() of 2x{n}x128 randn sets (VGGish width)",
+                                      "filter": per_step(stats, 7), "result": vres,
+                                      "knn_path": ops.knn_path(n, n, 128, k), "prdc_path": ops.prdc_path(n, n, 128),
+                                      "result_check": check_against_fixture(vres, "randn", n, 128, k)}
+            del vr, vc
         for name, kind, vk in (("clap_shaped_k5", "clap", 5), ("randn_k10", "randn", 10), ("clap_shaped_k10", "clap", 10)):
             if (kind, vk) == (args.data, k):
                 continue

@@ -232,8 +232,12 @@ def gen_bench():
     if os.path.exists(path):
         with np.load(path, allow_pickle=False) as g:
             out.update({key: g[key] for key in g.files})
-    for kind in ("randn", "clap"):
-        ref, cand = gi.bench_pair(kind, 100000, 512)
+    # (kind, width): 512 = the CLAP-shaped headline sets; 128 = VGGish's width (reference embedders/vggish.py:5-33,
+    # BASELINE configs[0]'s shape) at the same 100 000 rows - the bench variant `vggish_128`.  Keys of the narrower sets
+    # carry the width: "randn_d128/fad", "randn_d128_k5/precision".
+    for kind_name, kind, width in (("randn", "randn", 512), ("clap", "clap", 512), ("randn_d128", "randn", 128)):
+        ref, cand = gi.bench_pair(kind, 100000, width)
+        kind = kind_name
         if f"{kind}/fad" not in out:
             t0 = time.time()
             a, b = amd(cand, store=True), amd(ref, store=True)
@@ -244,7 +248,7 @@ def gen_bench():
             print("bench", kind, "fad", out[f"{kind}/fad"], kd, f"{time.time() - t0:.0f}s", flush=True)
             del a, b
             np.savez_compressed(path, **out)
-        for k in (5, 10):
+        for k in ((5, 10) if width == 512 else (5,)):
             if f"{kind}_k{k}/precision" in out:
                 continue
             t0 = time.time()

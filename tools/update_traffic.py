@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """profiles/traffic.json from the PMC summaries of one profile directory.
 
-    tools/update_traffic.py profiles/r4 [--stamp <sources_sha256>]
+    tools/update_traffic.py profiles/r5 [--table profiles/traffic.json] [--stamp <sources_sha256>]
 
 Reads <dir>/pmc_fetch.summary.txt (FETCH_SIZE, KiB) and <dir>/pmc_write.summary.txt (WRITE_SIZE, KiB; TCC_HIT_sum,
 TCC_MISS_sum) - the files tools/profile_bench.sh + tools/rocpd_summary.py write - and records, per kernel,
 HBM-side bytes per launch = FETCH_SIZE x 1024 x 2 (gfx950 wide-read under-count, MI355X_MICROARCH.md HBM section) +
 WRITE_SIZE x 1024, the L2 hit rate, the profile directory and the sha256 of the sources the profiled library was built
 from (<dir>/library.stamp.json, copied there by profile_bench.sh; --stamp overrides).  bench.py reports roofline.traffic
-only when that hash equals the loaded library's.  Kernels of other profiles keep their earlier records."""
+only when that hash equals the loaded library's.
+ONE stamp per table (round 5): a table that already holds records of ANOTHER library is not merged into - its records are
+dropped (and listed) and the table starts again from this profile, so that no line of traffic.json can belong to a library
+other than the one named in the same directory's library.stamp.json."""
 import json
 import os
 import re
@@ -35,18 +38,28 @@ def main():
         i = args.index("--stamp")
         stamp = args[i + 1]
         del args[i:i + 2]
+    table_arg = None
+    if "--table" in args:
+        i = args.index("--table")
+        table_arg = args[i + 1]
+        del args[i:i + 2]
     prof = args[0].rstrip("/")
     if stamp is None:
         with open(os.path.join(prof, "library.stamp.json")) as f:
             stamp = json.load(f)["sources_sha256"]
     fetch = counters(os.path.join(prof, "pmc_fetch.summary.txt"))
     write = counters(os.path.join(prof, "pmc_write.summary.txt"))
-    table_path = os.path.join(ROOT, "profiles", "traffic.json")
+    table_path = table_arg or os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(table_path) as f:
             table = json.load(f)
     except (OSError, ValueError):
         table = {}
+    stale = {name: rec for name, rec in table.get("kernels", {}).items() if rec.get("sources_sha256") != stamp}
+    if stale:
+        print(f"dropping {len(stale)} record(s) of other libraries: " + ", ".join(f"{n} ({r.get('sources_sha256', '?')[:12]})" for n, r in sorted(stale.items())))
+        table["kernels"] = {name: rec for name, rec in table.get("kernels", {}).items() if name not in stale}
+    table["sources_sha256"] = stamp
     kernels = table.setdefault("kernels", {})
     for name in sorted(set(fetch) & set(write)):
         if "FETCH_SIZE" not in fetch[name] or "WRITE_SIZE" not in write[name]:
