@@ -107,12 +107,10 @@ __device__ __forceinline__ void pstat_pipeline(const float* __restrict__ Q, int6
 
     // ---- Q slabs: piece p = 8 rows x 128 B; wave w fetches pieces 2 w, 2 w + 1 (rows 16 w .. 16 w + 15 of the half tile)
     const int lr = L.lane >> 3, slot8 = L.lane & 7;
-    unsigned voq[2];                                  // even / odd piece: the swizzle of a row depends on (row >> 1) & 7
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-        const int row = par * 8 + lr;
-        voq[par] = (unsigned)(((int64_t)row * ldq + (slot8 ^ ((row >> 1) & 7)) * 4) * 4);
-    }
+    // even piece (rows lr of the wave's sixteen); the odd piece's rows lie 8 further down and their swizzle (row >> 1) & 7
+    // differs in bit 2 of the chunk index = bit 6 of the byte offset (rows are multiples of 128 B): one register, one XOR
+    const unsigned voq0 = (unsigned)(((int64_t)lr * ldq + (slot8 ^ ((lr >> 1) & 7)) * 4) * 4);
+    const unsigned odd_soff = (unsigned)((int64_t)8 * ldq * 4);
     const unsigned wave_soff = (unsigned)((int64_t)wave * 16 * ldq * 4), half_soff = (unsigned)((int64_t)PQ_ROWS * ldq * 4);
     const int64_t q_tiles_total = (nq + WTB - 1) / WTB;
     auto qtile_of = [&](int t) -> int64_t { return t < ntiles ? tmap(t) : q_tiles_total; };   // past the end: empty descriptor
@@ -120,7 +118,7 @@ __device__ __forceinline__ void pstat_pipeline(const float* __restrict__ Q, int6
     TileRsrc qrs = make_wide_rsrc(Q, ldq, nq, qtile_of(0) * WTB);
     auto fetch_stage = [&](int i) {                   // piece i of the stage under the fetch cursor
         float* dst = lds + fslot * PSTAGE_WORDS + (wave * 2 + i) * 8 * WROW;
-        lds_direct_b128(qrs, dst, voq[i], (unsigned)(fk * 128) + (fh ? half_soff : 0u) + wave_soff);
+        lds_direct_b128(qrs, dst, i == 0 ? voq0 : (voq0 ^ 64u), (unsigned)(fk * 128) + (fh ? half_soff : 0u) + wave_soff + (i == 0 ? 0u : odd_soff));
     };
     auto advance_fetch = [&]() {
         fslot = (fslot + 1) & (PRING - 1);

@@ -342,6 +342,9 @@ knn_wide_body(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float*
         region = __builtin_amdgcn_readfirstlane(*slot);
     }
     const float nmax = __uint_as_float(maxn[0]);
+    // 2 fc through the exponent field: an integer add on the scalar unit (a float multiply of a wave-uniform value lands in a
+    // vector register, and the k <= 10 instantiation at 512 columns has none to spare)
+    const float fc2 = __uint_as_float(__float_as_uint(fc) + (1u << 23));
     KnnWideEpilogue<KCAP, Lane> epi(L);
     epi.qnorm = xnorm;
     epi.thr = thr;
@@ -370,8 +373,8 @@ knn_wide_body(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float*
         const int64_t i = sw.pb * WTB + L.prow(nt);
         epi.prow[nt] = (unsigned)i;
         epi.xn[nt] = i < N ? xnorm[i] : INFINITY;
-        epi.e2c = 2.f * fc;
-        epi.e2n = 2.f * fc * nmax;
+        epi.e2c = fc2;
+        epi.e2n = fc2 * nmax;
         epi.flt[nt] = i < N ? __hip_atomic_load(thr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) epi.best[nt][s] = s < KCAP - k1 ? -INFINITY : INFINITY;
@@ -421,7 +424,7 @@ knn_wide_body(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float*
 #pragma unroll
             for (int s = 0; s < KCAP; ++s) __hip_atomic_store(out + s, m[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float kthv = m[KCAP - 1];
-            const float bound = kthv + 2.f * fc * (xnorm[i] + nmax);
+            const float bound = kthv + fc2 * (xnorm[i] + nmax);
             // (a row taken out of the sweep keeps its -inf: knn_fast_mask_flat_kernel; nobody else writes thr[i])
             if (epi_row_in_sweep(thr, i)) atomicMin(reinterpret_cast<unsigned*>(thr) + i, __float_as_uint(bound));
         }

@@ -44,6 +44,36 @@ def test_wide_kernels_stay_within_the_register_file():
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_operand_stationary_kernels_do_not_spill():
+    """pairwise_pstat.hip (round 5): 32 instantiations - membership filter and k-NN sweep for 1 .. 8 slabs of 64 f16 per row,
+    with / without the row minimum, lists of 6 / 11 - at two waves per SIMD.  At 512 columns 96 registers hold P fragments, 64
+    accumulators, 16 Q fragments: the epilogues have ~70 left, and the k <= 10 sweep used every one of them (the seventh and
+    eighth slab of the P rows live in LDS for exactly that reason).  None may touch scratch."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("am_build", os.path.join(ROOT, "audio-metrics_amd", "_build.py"))
+    build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(build)
+    r = subprocess.run([hipcc, *build.HIPCC_FLAGS, "--cuda-device-only", "-c", "pairwise_pstat.hip", "-o", os.devnull,
+                        "-Rpass-analysis=kernel-resource-usage"], cwd=CSRC, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    name, usage = None, {}
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+        for key, label in (("VGPRs", "VGPRs"), ("ScratchSize \\[bytes/lane\\]", "scratch"), ("Occupancy \\[waves/SIMD\\]", "occupancy")):
+            m = re.search(r"remark:\s+%s: (\d+)" % key, line)
+            if m and name:
+                usage[name][label] = int(m.group(1))
+    kernels = {n: u for n, u in usage.items() if "pstat_kernel" in n}
+    assert len(kernels) == 32, sorted(usage)
+    for n, u in kernels.items():
+        assert u["VGPRs"] <= 256 and u["occupancy"] >= 2 and u["scratch"] == 0, (n, u)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
 def test_kernel_distance_on_the_wide_engine_does_not_spill():
     """kd_wide_kernel: 128 accumulators + an f64 epilogue.  With a run-time power loop per accumulator element the register
     allocator spilled accumulators inside the MAIN loop (684 bytes per lane); the degree-3 form must stay at zero scratch."""
