@@ -34,4 +34,6 @@ if ! cmp -s "$STAMP" "$OUT/library.stamp.json"; then
     exit 1
 fi
 python3 tools/update_traffic.py "$OUT" --table "$OUT/traffic.json"
+# the raw rocprofv3 databases (tens of MB per pass) stay on the box: gpurun copies back at most 64 MiB in all
+rm -rf "$OUT/trace" "$OUT/pmc_sq" "$OUT/pmc_fetch" "$OUT/pmc_write"
 ls -la "$OUT"
