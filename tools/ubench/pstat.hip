@@ -29,7 +29,10 @@ __device__ __forceinline__ void wait_vm() {
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
-template <int NW, int LAG, int ROT>
+// ABL (ablation bits, timing only - results are meaningless with any of 1 / 2 / 4 set): 1 no LDS-DMA, 2 no fragment reads behind
+// the first, 4 no barrier, 8 waves 4-7 issue their pieces one k-step behind waves 0-3, 16 s_setprio 1 around the MFMAs,
+// 32 a barrier every SECOND stage only
+template <int NW, int LAG, int ROT, int ABL = 0>
 __global__ void __launch_bounds__(NW * 64, 1) pstat(const float* __restrict__ src, int64_t src_rows, int ld_words, int tiles,
                                                       float* __restrict__ out) {
     constexpr int NP = 8 / NW;                        // 32-row P tiles per wave: 2 (four waves) or 1 (eight waves)
@@ -66,6 +69,7 @@ __global__ void __launch_bounds__(NW * 64, 1) pstat(const float* __restrict__ sr
     const unsigned nb = (unsigned)nblk, blk_bytes = (unsigned)(512 * ld_words * 4);
     unsigned blk_cur = (unsigned)(((int64_t)blockIdx.x * 7) % nblk), blk_next = blk_cur;
     auto piece = [&](int ring_slot, bool next_tile, int kslab, int i) {
+        if (ABL & 1) return;
         const int p = wave * PIECES + i;
         float* dst = lds + ring_slot * STAGE_WORDS + p * 8 * WROW;
         const unsigned so = (next_tile ? blk_next : blk_cur) * blk_bytes + (unsigned)(kslab * 128) + (unsigned)((p & ~1) * 8 * ld_words * 4);
@@ -110,6 +114,7 @@ __global__ void __launch_bounds__(NW * 64, 1) pstat(const float* __restrict__ sr
         blk_next = blk_cur + 13 >= nb ? blk_cur + 13 - nb : blk_cur + 13;
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) {
+            if (ABL & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (ROT) {
@@ -120,10 +125,15 @@ __global__ void __launch_bounds__(NW * 64, 1) pstat(const float* __restrict__ sr
                         for (int n = 0; n < NP; ++n)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, qa[m]),
                                                                                  __builtin_bit_cast(f16x8, pf[n][s8 * 4 + c]), acc[m][n], 0, 0, 0);
-                        if (c < 3) qa[m] = qfrag1(s8 % RING, c + 1, m);
-                        else if (LAG == 2) qa[m] = qfrag1((s8 + 1) % RING, 0, m);
+                        if (!(ABL & 2)) {
+                            if (c < 3) qa[m] = qfrag1(s8 % RING, c + 1, m);
+                            else if (LAG == 2) qa[m] = qfrag1((s8 + 1) % RING, 0, m);
+                        }
                         if (PIECES == 4 && m == 1) piece((s8 + DEPTH) % RING, s8 + DEPTH >= 8, (s8 + DEPTH) & 7, c);
-                        if (PIECES == 2 && m == 1 && (c & 1) == 0) piece((s8 + DEPTH) % RING, s8 + DEPTH >= 8, (s8 + DEPTH) & 7, c >> 1);
+                        if (PIECES == 2 && !(ABL & 8) && m == 1 && (c & 1) == 0) piece((s8 + DEPTH) % RING, s8 + DEPTH >= 8, (s8 + DEPTH) & 7, c >> 1);
+                        if (PIECES == 2 && (ABL & 8) && m == 1) {
+                            if (wave < 4 ? (c & 1) == 0 : (c & 1) == 1) piece((s8 + DEPTH) % RING, s8 + DEPTH >= 8, (s8 + DEPTH) & 7, c >> 1);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     continue;
@@ -144,9 +154,10 @@ __global__ void __launch_bounds__(NW * 64, 1) pstat(const float* __restrict__ sr
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (ABL & 16) __builtin_amdgcn_s_setprio(0);
             // stage g + LAG has landed (this wave's pieces); the barrier publishes it
             wait_vm<(DEPTH - LAG) * PIECES>();
-            __builtin_amdgcn_s_barrier();
+            if (!(ABL & 4) && (!(ABL & 32) || (s8 & 1))) __builtin_amdgcn_s_barrier();
             if (LAG == 1) {
                 qfrags(qa, (s8 + 1) % RING, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -164,21 +175,21 @@ __global__ void __launch_bounds__(NW * 64, 1) pstat(const float* __restrict__ sr
     if (sink == 12345.678f) out[0] = sink;
 }
 
-template <int NW, int LAG, int ROT>
+template <int NW, int LAG, int ROT, int ABL = 0>
 static void run(const float* src, int64_t rows, int ld_words, float* out, int src_mb) {
     const int tiles = 1024;                          // 8192 stages of 16 KB = 4096 units of 8.4 MFLOP per CU
     const size_t lds_bytes = 4 * STAGE_WORDS * 4;
-    hipFuncSetAttribute((const void*)pstat<NW, LAG, ROT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipFuncSetAttribute((const void*)pstat<NW, LAG, ROT, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((pstat<NW, LAG, ROT>), dim3(256), dim3(NW * 64), lds_bytes, 0, src, rows, ld_words, 16, out);
+    hipLaunchKernelGGL((pstat<NW, LAG, ROT, ABL>), dim3(256), dim3(NW * 64), lds_bytes, 0, src, rows, ld_words, 16, out);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((pstat<NW, LAG, ROT>), dim3(256), dim3(NW * 64), lds_bytes, 0, src, rows, ld_words, tiles, out);
+    hipLaunchKernelGGL((pstat<NW, LAG, ROT, ABL>), dim3(256), dim3(NW * 64), lds_bytes, 0, src, rows, ld_words, tiles, out);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / (tiles * 4);        // per 8.4 MFLOP per CU (two 16-KB stages)
-    printf("src %3d MB  waves %d lag %d rot %d: %.3f us per 8.4 MFLOP/CU -> %.0f TFLOP/s of 2500 (%.2f)   [%s]\n", src_mb, NW, LAG, ROT, us,
+    printf("src %3d MB  waves %d lag %d rot %d abl %2d: %.3f us per 8.4 MFLOP/CU -> %.0f TFLOP/s of 2500 (%.2f)   [%s]\n", src_mb, NW, LAG, ROT, ABL, us,
            2.0 * 256 * 256 * 64 * 256 / us * 1e-6, 2.0 * 256 * 256 * 64 * 256 / us * 1e-6 / 2500.0, hipGetErrorString(hipGetLastError()));
 }
 
@@ -200,11 +211,19 @@ int main() {
             (void)hipMemcpy(src, hsrc, rows * 1024, hipMemcpyHostToDevice);
             free(hsrc);
         }
-        run<4, 2, 0>(src, rows, ld_words, out, src_mb);
         run<4, 2, 1>(src, rows, ld_words, out, src_mb);
         run<8, 1, 0>(src, rows, ld_words, out, src_mb);
         run<8, 2, 0>(src, rows, ld_words, out, src_mb);
         run<8, 2, 1>(src, rows, ld_words, out, src_mb);
+        run<8, 2, 1, 1>(src, rows, ld_words, out, src_mb);
+        run<8, 2, 1, 2>(src, rows, ld_words, out, src_mb);
+        run<8, 2, 1, 3>(src, rows, ld_words, out, src_mb);
+        run<8, 2, 1, 4>(src, rows, ld_words, out, src_mb);
+        run<8, 2, 1, 7>(src, rows, ld_words, out, src_mb);
+        run<8, 2, 1, 8>(src, rows, ld_words, out, src_mb);
+        run<8, 2, 1, 16>(src, rows, ld_words, out, src_mb);
+        run<8, 2, 1, 24>(src, rows, ld_words, out, src_mb);
+        run<8, 2, 1, 32>(src, rows, ld_words, out, src_mb);
         (void)hipFree(src); (void)hipFree(out);
     }
     return 0;
