@@ -538,6 +538,11 @@ def main():
             "matrix cores with a proven error bound and queue the few pairs the bound cannot decide; those are "
             "re-evaluated with the exact f32 fmaf chain (verify kernels, listed under other_kernels), so the outputs are "
             "bit-identical to the exact f32 kernels'.")
+        if knn_path == 3 or cross_path == 3:
+            # measured, not a target: a loop of nothing but this MFMA on random operands (tools/ubench/pstat.hip, ablation 7)
+            main["sustained_mfma_only"] = {"tflops": 1720.0, "frac_of_peak": 0.69, "source": "profiles/r5/ubench_pstat_abl.txt",
+                                           "note": "what the f16 matrix pipe sustains on this pool at the clock its power draw allows; "
+                                                   "frac above is priced against the nominal peak, not against this"}
         verify = {}
         for name, label in (("knn_verify", "knn_fast_verify_kernel"), ("cross_verify", "cross_verify_kernel")):
             launches, total = clocks[name]
@@ -570,6 +575,7 @@ def main():
             "unit": "embeddings/s",
             "n_gpus": world,
             "n_ranks_seen": n_ranks_seen,
+            "library_sources_sha256": library_stamp(),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
