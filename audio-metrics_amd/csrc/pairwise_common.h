@@ -162,6 +162,15 @@ template <int KCAP, class Lane = LaneInfo, int TBX = TB, int MT = 2>
 struct KnnFastEpilogue {
     static constexpr int NWAVES = TBX == WIDE_TILE_ROWS ? 8 : 4;   // waves per workgroup
     static constexpr int NT = Lane::NT;                             // 32-row P tiles per wave
+    // ACC_INIT (pstat_engine.h): the accumulators start at c0_j = |x_j|^2 / dsc (dsc = -2 / scales: c0_j = -|x_j|^2 / 2 in the
+    // units of the scaled dot product), so an element holds a' = <x_i, x_j>' + c0_j and the approximate squared distance is
+    // dsc a' + |x_i|^2 - a DEcreasing function of a', exact up to the scaling by a power of two.  The tests of the fast path
+    // then run on the accumulator itself:
+    //   own row     min_j (dsc a'_j + |x_i|^2) <= bound_i        <=>  fma(dsc, max_j a'_j, |x_i|^2) <= bound_i      (max3 only)
+    //   column j    dsc a'_j + |x_i|^2 <= thr_j                    <=>  a'_j - thr_j / dsc >= -|x_i|^2 / dsc          (sub, max3)
+    // two vector passes per accumulator element instead of three (fma with the column norm, subtract, two half min3).
+    // Error bound: c0_j is one more term of the matrix core's accumulation (pairwise_fast.h, fast_c: D + 1 terms).
+    static constexpr bool ACC_INIT = Lane::ACC_INIT;
     const float* qnorm;
     const float* thr;
     int64_t n, pblock;
@@ -181,6 +190,8 @@ struct KnnFastEpilogue {
     int* cnt;
     int cap;
     float dsc;                  // -2 / (operand scale)^2
+    float idsc;                 // 1 / dsc (a power of two: exact)
+    float xs[NT];               // ACC_INIT: -|x_i|^2 / dsc, what a column-direction margin is compared with
     unsigned prow[NT];           // (row indices fit 32 bits: the filter path is limited to < 2^31 rows)
     float xn[NT], flt[NT];        // xn = +inf for rows past the end: every approximate value is +inf and passes no test
     float e2c, e2n;             // 2 E_i = e2c * |x_i|^2 + e2n  (recomputed per tile group: two registers less than keeping it)
@@ -227,9 +238,22 @@ struct KnnFastEpilogue {
     }
     __device__ __forceinline__ void aux_commit(int t) {
         if (L.tid < TBX) {
-            aux[(t & 1) * 2 * TBX + L.tid] = aux_n;
-            aux[(t & 1) * 2 * TBX + TBX + L.tid] = aux_t;
+            // ACC_INIT: both in the units of the accumulator (+-inf keep their meaning: a column past the end starts at -inf
+            // and can never be the maximum; its bound -inf becomes +inf and no margin reaches it)
+            aux[(t & 1) * 2 * TBX + L.tid] = ACC_INIT ? aux_n * idsc : aux_n;
+            aux[(t & 1) * 2 * TBX + TBX + L.tid] = ACC_INIT ? aux_t * idsc : aux_t;
         }
+    }
+    // start value of accumulator tile mt of the half tile L.wm: register 4 g + e <-> column mt * 32 + g * 8 + h * 4 + e
+    __device__ __forceinline__ f32x16 acc_init(int t, int mt) const {
+        const float* a = aux + (t & 1) * 2 * TBX + L.wm * (MT * 32) + L.h * 4 + mt * 32;
+        f32x16 c;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a + g4 * 8);
+            c[g4 * 4 + 0] = v.x; c[g4 * 4 + 1] = v.y; c[g4 * 4 + 2] = v.z; c[g4 * 4 + 3] = v.w;
+        }
+        return c;
     }
     __device__ __forceinline__ void finish(int t, int64_t qtile, f32x16 (&acc)[MT][NT]) {
         const float* a = aux + (t & 1) * 2 * TBX + L.wm * (MT * 32) + L.h * 4;
@@ -240,6 +264,66 @@ struct KnnFastEpilogue {
         }
 #endif
         const unsigned jbase = (unsigned)(qtile * TBX) + L.wm * (MT * 32) + L.h * 4;
+        if constexpr (ACC_INIT) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 tqs[4];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) tqs[g4] = *reinterpret_cast<const f32x4*>(a + TBX + mt * 32 + g4 * 8);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float amax4[4], wmax4[4];
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        float am = -INFINITY, wm = -INFINITY;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            am = fmaxf(am, acc[mt][nt][g4 * 4 + e]);
+                            wm = fmaxf(wm, acc[mt][nt][g4 * 4 + e] - tqs[g4][e]);
+                        }
+                        amax4[g4] = am;
+                        wmax4[g4] = wm;
+                    }
+                    const float amax = fmaxf(fmaxf(amax4[0], amax4[1]), fmaxf(amax4[2], amax4[3]));
+                    const float wmax = fmaxf(fmaxf(wmax4[0], wmax4[1]), fmaxf(wmax4[2], wmax4[3]));
+                    const float tmin = fmaf(dsc, amax, xn[nt]);         // the smallest approximate value of the tile's 16 elements
+                    const float pl = fminf(flt[nt], best[nt][KCAP - 1] + fmaf(e2c, xn[nt], e2n));
+                    if (!__any(tmin <= pl || (mirror && wmax >= xs[nt]))) continue;          // gate 1 (see below)
+#ifdef AM_DEV_KNOBS
+                    if constexpr (TBX == WIDE_TILE_ROWS) {
+                        if (g_wide_dbg & 16) continue;
+                    }
+#endif
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        if (!__any(fmaf(dsc, amax4[g4], xn[nt]) <= pl || (mirror && wmax4[g4] >= xs[nt]))) continue;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int reg = g4 * 4 + e;
+                            const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt]);
+                            const bool own = u <= pl, mir = mirror && acc[mt][nt][reg] - tqs[g4][e] >= xs[nt];
+                            const unsigned long long sel = __ballot(own || mir);
+                            if (sel != 0ull) {
+                                const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(sel >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sel, 0u));
+                                const int slot = wq + below;
+                                wq += __popcll(sel);
+                                const unsigned j = jbase + mt * 32 + g4 * 8 + e;
+#ifdef AM_DEV_KNOBS
+                                if (TBX == WIDE_TILE_ROWS && (g_wide_dbg & 32)) continue;
+#endif
+                                if (own || mir) store_entry(slot, own ? prow[nt] : j, own ? j : prow[nt], own && mir, u);
+                            }
+                        }
+                    }
+                    const float vmin = tmin <= pl ? fmaxf(tmin, 0.f) : INFINITY;
+#ifdef AM_DEV_KNOBS
+                    if (TBX == WIDE_TILE_ROWS && (g_wide_dbg & 64)) continue;
+#endif
+                    if (__any(vmin < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], vmin);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             f32x4 yn[4], tq[4];

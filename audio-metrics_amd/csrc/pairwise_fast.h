@@ -20,7 +20,14 @@
 //      D 2^-24 S) satisfies
 //          |a - t| <= fast_c(D) (|x|^2 + G),     fast_c(D) = 2^-10 + 2^-19 + 2^-25 sqrt(D) + D 2^-21 ,
 //      for D <= 4096 (wider inputs take the exact kernels); 2^-19 covers the roundings of a, t, the thresholds
-//      below and of the f32 norms the bound itself is computed from.  At D = 512 fast_c = 1.2224e-3.
+//      below and of the f32 norms the bound itself is computed from.  At D = 512 fast_c = 1.2229e-3.
+//      The operand-stationary engine (pstat_engine.h) starts every accumulator at c0 = -|y|^2 / 2 (in the units of the scaled
+//      dot product, an exact scaling) instead of adding |y|^2 afterwards: c0 is then one more term of the matrix core's
+//      accumulation, whose partial sums are bounded by |c0| + S, so its part of the bound on a = -2 acc + |x|^2 becomes
+//      (D + 1) 2^-21 (|y|^2 / 2 + S) <= (D + 1) 2^-21 (|x|^2 / 2 + |y|^2) <= (D + 1) 2^-21 (|x|^2 + G): the same form with D + 1
+//      for D (fast_c below counts D + 1 terms for both engines); that a no longer adds |x|^2 + |y|^2 with the exact value's
+//      rounding of the sum is a difference of 2^-24 (|x|^2 + |y|^2), inside the 2^-19 term.  am_filter_stats slot 9 MEASURES
+//      |a - t| / (fast_c (|x|^2 + G)) on every verified pair (tests/test_gpu_routes.py).
 //   2. A pair is QUEUED when a <= threshold + eps, which every pair with t <(=) threshold satisfies.
 //   3. Queued pairs are evaluated with the engine's fmaf order (the chain oracle/exact_c reproduces), and the
 //      reductions of the exact kernels are applied to those values.  Queue overflow falls back to the exact
@@ -44,7 +51,7 @@ static inline int half_drop_bits() {
 }
 static inline float fast_c(int D) {
     const int n = half_drop_bits();
-    const float rest = 1.9073486328125e-06f + 2.98023223876953125e-08f * sqrtf((float)D) + (float)D * 4.76837158203125e-07f;
+    const float rest = 1.9073486328125e-06f + 2.98023223876953125e-08f * sqrtf((float)D) + (float)(D + 1) * 4.76837158203125e-07f;
     if (n == 0) return 0.0009765625f + rest;
     const float u = ldexpf(1.f, -(11 - n)) + ldexpf(1.f, -11);
     return 2.f * u + u * u + rest;

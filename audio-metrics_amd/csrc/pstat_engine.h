@@ -49,6 +49,13 @@ constexpr int pstat_lds_words(int kslabs) { return PRING * PSTAGE_WORDS + pstat_
 struct PLane {
     static constexpr int NT = 1;
     static constexpr int LISTS = 2;                   // partial per-row lists after the sweep: the two lane halves
+    // The accumulators of a unit do not start at zero but at a per-COLUMN value the epilogue supplies (acc_init): the k-NN
+    // sweep and the membership filter start them at -|y_j|^2 / 2 in the units of the scaled dot product, so that what comes out
+    // is <x, y_j> - |y_j|^2 / 2 and the epilogue's fast path needs no fma per element to add the column norm.  The vector ALU
+    // and the matrix pipe of a SIMD do not overlap here (profiles/r5/wide_bench_nomargin.txt: one vector pass per accumulator
+    // element = 0.15 ms per sweep at 100 000 rows, at D = 128 and at D = 512 alike), and the start values are the same LDS
+    // reads the epilogue did anyway.
+    static constexpr bool ACC_INIT = true;
     int tid, lane, wave, wm, r, h;
     __device__ __forceinline__ PLane() {
         tid = threadIdx.x;
@@ -72,6 +79,7 @@ __device__ __forceinline__ void pstat_wait() {        // vmcnt(N) and lgkmcnt(0)
 // local tile t multiplies; P block = rows prow0 .. prow0 + 255.  Epi:
 //   aux_issue(t, qtile) / aux_commit(t)   per-TILE side data through LDS (as in wide_engine.h)
 //   finish(t, qtile, acc[4][1])           once per HALF tile, L.wm telling which
+//   acc_init(t, m)  (Epi::ACC_INIT)       start value of accumulator tile m (32 Q rows) of the half tile L.wm of local tile t
 template <int KSLABS, class TileMap, class Epi>
 __device__ __forceinline__ void pstat_pipeline(const float* __restrict__ Q, int64_t nq, int64_t ldq, const TileMap& tmap,
                                                const float* __restrict__ P, int64_t np, int64_t ldp, int64_t prow0, int ntiles,
@@ -164,6 +172,11 @@ __device__ __forceinline__ void pstat_pipeline(const float* __restrict__ Q, int6
     int slot = 0;                                     // ring slot of the stage being multiplied
 #pragma unroll
     for (int m = 0; m < 4; ++m) q[m] = qfrag(0, 0, m);
+    if constexpr (Epi::ACC_INIT) {
+        L.wm = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][0] = epi.acc_init(0, m);
+    }
     const int units = 2 * ntiles;
     for (int u = 0; u < units; ++u) {
         const int t = u >> 1;
@@ -183,7 +196,7 @@ __device__ __forceinline__ void pstat_pipeline(const float* __restrict__ Q, int6
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, q[m]), __builtin_bit_cast(f16x8, pfrag),
-                                                                         (ks == 0 && c == 0) ? zero : acc[m][0], 0, 0, 0);
+                                                                         (!Epi::ACC_INIT && ks == 0 && c == 0) ? zero : acc[m][0], 0, 0, 0);
                     if (c < 3) q[m] = qfrag(slot, c + 1, m);
                     else if (!last_stage) q[m] = qfrag(next_slot, 0, m);     // published by the barrier of the stage before
                     if (m == 1 && (c & 1) == 0) fetch_stage(c >> 1);
@@ -203,6 +216,15 @@ __device__ __forceinline__ void pstat_pipeline(const float* __restrict__ Q, int6
             if (last_stage) {                         // a unit's first fragments are read behind its predecessor's epilogue:
 #pragma unroll                                        // no fragment register is live across the epilogue
                 for (int m = 0; m < 4; ++m) q[m] = qfrag(slot, 0, m);
+                // ... and, ACC_INIT, its accumulators' start values (side data of a new tile: committed before the barrier above).
+                // Reading them a unit earlier, in front of the barrier, was measured: the same time (profiles/r5/wide_bench_accinit_ab.txt).
+                if constexpr (Epi::ACC_INIT) {
+                    if (u + 1 < units) {
+                        L.wm = second ? 0 : 1;
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc[m][0] = epi.acc_init((u + 1) >> 1, m);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -48,6 +48,7 @@ constexpr int ENGINE_THREADS = 256;
 
 struct LaneInfo {
     static constexpr int NT = 2;                 // 32-row P tiles per wave (pstat_engine.h: 1)
+    static constexpr bool ACC_INIT = false;      // accumulators start at zero (pstat_engine.h: at the epilogue's per-column start value)
     int tid, lane, wm, wn, r, h;
     __device__ __forceinline__ LaneInfo() {
         tid = threadIdx.x;

@@ -40,6 +40,7 @@ constexpr int WENGINE_LDS_WORDS = 2 * WSTAGE_WORDS;   // two stages, 128 KB
 struct WLane {
     static constexpr int NT = 2;                      // 32-row P tiles per wave
     static constexpr int LISTS = 4;                   // partial per-row lists after a sweep: Q half x lane half
+    static constexpr bool ACC_INIT = false;
     int tid, lane, wave, wm, wn, r, h;
     __device__ __forceinline__ WLane() {
         tid = threadIdx.x;

@@ -19,6 +19,12 @@ template <class Eng> constexpr size_t wide_cross_lds_bytes() { return (Eng::LDS_
 template <class Lane>
 struct CrossWideEpilogue {
     static constexpr int NT = Lane::NT;
+    // ACC_INIT (pstat_engine.h; the scheme of KnnFastEpilogue): accumulators start at |c_j|^2 / dsc, an element holds
+    // a' = <r_i, c_j>' + |c_j|^2 / dsc and the approximate squared distance is dsc a' + |r_i|^2.  Row direction (thresholds of
+    // the lane's own row): fma(dsc, max_j a'_j, |r_i|^2) against them; "any" direction (column thresholds T'_j + E'_j):
+    // a'_j - (T'_j + E'_j) / dsc >= -|r_i|^2 / dsc.  aux[0] and aux[1] are then in accumulator units, aux[2] (certain witness)
+    // stays a squared distance.
+    static constexpr bool ACC_INIT = Lane::ACC_INIT;
     const float* qnorm;
     const float* qthr;
     int64_t nq;
@@ -32,9 +38,9 @@ struct CrossWideEpilogue {
     int* ov_count;
     int ovcap;
     int* fail;
-    float dsc;
+    float dsc, idsc;
     int64_t prow[NT];
-    float xn[NT], thi[NT], tlo[NT], e2[NT], m[NT];
+    float xn[NT], xs[NT], thi[NT], tlo[NT], e2[NT], m[NT];
     bool rowok[NT], anyf[NT], covf[NT];
     float aux_n, aux_hi;
     const Lane& L;
@@ -65,13 +71,23 @@ struct CrossWideEpilogue {
             float* d = aux + (t & 1) * 3 * WTB + L.tid;
             const bool in = aux_hi > -INFINITY;               // thresholds are >= 0; -inf marks a column past the end
             const float e = fmaf(fc, aux_n, rnmax_c);
-            d[0] = aux_n;
-            d[WTB] = in ? aux_hi + e : -INFINITY;
+            d[0] = ACC_INIT ? aux_n * idsc : aux_n;                      // (past the end: +inf -> -inf, never the maximum)
+            d[WTB] = in ? (ACC_INIT ? (aux_hi + e) * idsc : aux_hi + e) : (ACC_INIT ? INFINITY : -INFINITY);
             d[2 * WTB] = in ? aux_hi - e : -INFINITY;
         }
     }
     // NEED_ANY = false: every row of this block already has its "any" witness - the column-threshold test (one subtraction
     // and half a min3 per accumulator element, and the threshold loads) is not compiled in
+    __device__ __forceinline__ f32x16 acc_init(int t, int mt) const {
+        const float* a = aux + (t & 1) * 3 * WTB + L.wm * 128 + L.h * 4 + mt * 32;
+        f32x16 c;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a + g4 * 8);
+            c[g4 * 4 + 0] = v.x; c[g4 * 4 + 1] = v.y; c[g4 * 4 + 2] = v.z; c[g4 * 4 + 3] = v.w;
+        }
+        return c;
+    }
     template <bool WANT_MIN, bool NEED_ANY>
     __device__ __forceinline__ void finish_impl(int t, int64_t qtile, f32x16 (&acc)[4][NT]) {
         const float* a = aux + (t & 1) * 3 * WTB + L.wm * 128 + L.h * 4;
@@ -79,6 +95,82 @@ struct CrossWideEpilogue {
 #ifdef AM_DEV_KNOBS
         if (g_wide_dbg & 2) return;                            // timing experiment: MFMA pipeline only
 #endif
+        if constexpr (ACC_INIT) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                f32x4 ths[4];
+                if constexpr (NEED_ANY) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) ths[g4] = *reinterpret_cast<const f32x4*>(a + WTB + mt * 32 + g4 * 8);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float amax4[4], wmax4[4];
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        float am = -INFINITY, wmx = -INFINITY;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            am = fmaxf(am, acc[mt][nt][g4 * 4 + e]);
+                            if constexpr (NEED_ANY) wmx = fmaxf(wmx, acc[mt][nt][g4 * 4 + e] - ths[g4][e]);
+                        }
+                        amax4[g4] = am;
+                        wmax4[g4] = wmx;
+                    }
+                    const float tmin = fmaf(dsc, fmaxf(fmaxf(amax4[0], amax4[1]), fmaxf(amax4[2], amax4[3])), xn[nt]);
+                    if constexpr (WANT_MIN) m[nt] = fminf(m[nt], fmaxf(tmin, 0.f));
+                    const float prow_thr = WANT_MIN ? fmaxf(thi[nt], m[nt] + e2[nt]) : thi[nt];
+                    {
+                        bool hit = rowok[nt] && tmin <= prow_thr;
+                        if constexpr (NEED_ANY)
+                            hit = hit || (rowok[nt] && !anyf[nt] && fmaxf(fmaxf(wmax4[0], wmax4[1]), fmaxf(wmax4[2], wmax4[3])) >= xs[nt]);
+                        if (!__any(hit)) continue;
+#ifdef AM_DEV_KNOBS
+                        if (g_wide_dbg & 16) continue;
+#endif
+                    }
+                    const float* alo = a + 2 * WTB + mt * 32;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const bool row_hit = __any(rowok[nt] && fmaf(dsc, amax4[g4], xn[nt]) <= prow_thr);
+                        bool any_hit = false;
+                        if constexpr (NEED_ANY) any_hit = __any(rowok[nt] && !anyf[nt] && wmax4[g4] >= xs[nt]);
+#ifdef AM_DEV_KNOBS
+                        if (g_wide_dbg & 8) any_hit = false;
+#endif
+                        if (!(row_hit || any_hit)) continue;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int reg = g4 * 4 + e;
+                            const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt]);
+                            const int64_t j = jbase + mt * 32 + g4 * 8 + e;
+                            bool sure = false, want = false;
+                            if (row_hit) {
+                                sure = rowok[nt] && u < tlo[nt];
+                                const unsigned long long mask = __ballot(sure);
+                                if (mask != 0ull && L.lane == 0) {
+                                    const int lo = __popcll(mask & 0xffffffffull);
+                                    const int hi = __popcll(mask >> 32);
+                                    if (lo) atomicAdd(col_count + j - L.h * 4, lo);
+                                    if (hi) atomicAdd(col_count + j - L.h * 4 + 4, hi);
+                                }
+                                covf[nt] = covf[nt] || sure;
+                                want = rowok[nt] && !sure && u <= thi[nt];
+                                if constexpr (WANT_MIN) want = want || (rowok[nt] && u <= m[nt] + e2[nt]);
+                            }
+                            if constexpr (NEED_ANY) {
+                                if (rowok[nt] && !anyf[nt] && acc[mt][nt][reg] - ths[g4][e] >= xs[nt]) {
+                                    if (u < alo[g4 * 8 + e]) anyf[nt] = true;       // certain witness
+                                    else want = true;                               // ambiguous "any"
+                                }
+                            }
+                            if (want) push(prow[nt], (unsigned)j | (sure ? FAST_COUNTED : 0u));
+                        }
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             f32x4 yn[4], th[4];
@@ -174,6 +266,8 @@ struct CrossWideShim {
     __device__ __forceinline__ void aux_issue(int t, int64_t q) { e.aux_issue(t, q); }
     __device__ __forceinline__ void aux_commit(int t) { e.aux_commit(t); }
     __device__ __forceinline__ void finish(int t, int64_t q, f32x16 (&acc)[4][Lane::NT]) { e.template finish_impl<WANT_MIN, NEED_ANY>(t, q, acc); }
+    static constexpr bool ACC_INIT = Lane::ACC_INIT;
+    __device__ __forceinline__ f32x16 acc_init(int t, int mt) const { return e.acc_init(t, mt); }
 };
 
 struct WideTiles {
@@ -250,7 +344,11 @@ cross_wide_body(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const flo
     epi.ovcap = ovcap;
     epi.fail = fail;
     epi.dsc = half_unscale(maxn[2], maxn[3]);
-    if (blockIdx.x == 0 && L.tid == 0 && !(half_scale_ok(maxn[2]) && half_scale_ok(maxn[3]))) *fail = 1;
+    epi.idsc = 1.f / epi.dsc;
+    // (ACC_INIT: norms and thresholds travel in accumulator units, |.| <= a few G / |dsc| - two sets whose magnitudes lie so far
+    // apart that this leaves f32 go to the exact kernel like operands that cannot be scaled)
+    const bool units_ok = !Lane::ACC_INIT || gmax * -epi.idsc < 1.0e36f;
+    if (blockIdx.x == 0 && L.tid == 0 && !(half_scale_ok(maxn[2]) && half_scale_ok(maxn[3]) && units_ok)) *fail = 1;
     const int64_t prow0 = w.rb * WTB;
 #pragma unroll
     for (int nt = 0; nt < Lane::NT; ++nt) {
@@ -259,6 +357,7 @@ cross_wide_body(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const flo
         epi.prow[nt] = i;
         epi.rowok[nt] = ok;
         epi.xn[nt] = ok ? rnorm[i] : 0.f;
+        epi.xs[nt] = -epi.xn[nt] * epi.idsc;
         const float e = fc * ((ok ? rnorm[i] : 0.f) + gmax);
         epi.thi[nt] = ok ? rthr[i] + e : -INFINITY;
         epi.tlo[nt] = ok ? rthr[i] - e : -INFINITY;
@@ -368,11 +467,13 @@ knn_wide_body(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float*
     epi.cnt = cnt;
     epi.cap = cap;
     epi.dsc = half_unscale(maxn[2], maxn[2]);
+    epi.idsc = 1.f / epi.dsc;
 #pragma unroll
     for (int nt = 0; nt < Lane::NT; ++nt) {
         const int64_t i = sw.pb * WTB + L.prow(nt);
         epi.prow[nt] = (unsigned)i;
         epi.xn[nt] = i < N ? xnorm[i] : INFINITY;
+        epi.xs[nt] = -epi.xn[nt] * epi.idsc;
         epi.e2c = fc2;
         epi.e2n = fc2 * nmax;
         epi.flt[nt] = i < N ? __hip_atomic_load(thr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;

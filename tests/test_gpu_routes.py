@@ -176,3 +176,27 @@ def test_measured_bound_is_reported_per_family(probe):
             assert s["bound_ratio_max"] <= 1.0, (name, s)
     print("measured |a - t| / (fast_c (|x|^2 + G)) per family:", {k: round(v, 3) for k, v in worst.items()})
     assert len(worst) >= 4, worst                 # most of the families reach the verification (the rest fall back: no statement)
+
+
+@pytest.mark.parametrize("scale_ref,scale_cand,route", [(1e-3, 1e3, "filter"), (1e3, 1e-3, "filter"), (1e-15, 1e15, "exact"), (1e14, 1e-14, "exact")])
+def test_sets_of_very_different_magnitude(probe, scale_ref, scale_cand, route):
+    """The membership filter on the operand-stationary engine starts its accumulators at -|c_j|^2 / 2 in the units of the SCALED
+    dot product (csrc/pstat_engine.h, ACC_INIT): with a reference and a candidate set whose magnitudes lie far apart that start
+    value dwarfs the products (six decades: still the filter, every pair decided by the norms - the bound must hold), and past
+    ~1e36 in those units it would leave f32, so such a call is handed to the exact kernel like operands that cannot be scaled."""
+    ops = probe.ops
+    g = torch.Generator(device="cuda").manual_seed(51)
+    x = torch.randn(20000, 128, generator=g, device="cuda") * scale_ref
+    y = torch.randn(20000, 128, generator=g, device="cuda") * scale_cand
+    r, r2 = ops.knn_radii(x, 5), ops.knn_radii(y, 5)
+    assert ops.prdc_path(20000, 20000, 128) == 3 and ops.filter_engine(128) == 1
+    ops.filter_stats_read("cuda:0")
+    got = ops.prdc_counts(x, y, r, r2)
+    s = ops.filter_stats_read("cuda:0")
+    want = probe.exact_counts(x, y, r, r2, False)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert s["prdc_calls"] == 1 and s["prdc_fallback_calls"] == (1 if route == "exact" else 0), s
+    # the larger set's rows lie far outside every ball of the smaller one; the smaller set's rows all sit at the origin of the larger
+    # one's scale: inside a candidate's ball exactly when that candidate's radius exceeds its own norm
+    print(f"{scale_ref:g} / {scale_cand:g}: column counts {int(got[0].sum())}, rows with a witness {int(got[1].sum())}, route {route}")
