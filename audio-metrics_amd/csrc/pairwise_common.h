@@ -148,6 +148,14 @@ constexpr int FAST_ROW_OVERFLOW = 0x40000000;                                 //
                                                                               // later +1's of the scatter cannot wrap it
 constexpr unsigned FAST_HOLE = 0xffffffffu;                                  // pair-list slot left unwritten (list full)
 
+// Wave-wide float compares as LANE MASKS in scalar registers (v_cmp_*_f32 sN, a, b).  `__any(a <= b || ...)` materialises the
+// bool as 0 / 1 in a vector register and compares that again (v_cndmask, v_and, v_cmp_ne: five vector instructions per gate in
+// the filter epilogues, where every vector pass is paid in full - pstat_engine.h); masks combine on the scalar unit and a gate
+// is `mask == 0`.
+__device__ __forceinline__ unsigned long long lanes_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 5); }   // ordered <=
+__device__ __forceinline__ unsigned long long lanes_ge(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 3); }   // ordered >=
+__device__ __forceinline__ unsigned long long lanes_lt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 4); }   // ordered <
+
 // Lane / TBX / MT: geometry of the engine underneath - LaneInfo, 128, 2 (tile_engine.h) or WLane, 256, 4 (wide_engine.h)
 //
 // Queue protocol (round 3).  A workgroup's region of `qcap` entries is NWAVES private sub-regions of wcap = qcap / (2 NWAVES)
@@ -265,6 +273,9 @@ struct KnnFastEpilogue {
 #endif
         const unsigned jbase = (unsigned)(qtile * TBX) + L.wm * (MT * 32) + L.h * 4;
         if constexpr (ACC_INIT) {
+            float xsm[NT];                                    // the diagonal tile holds both directions itself: no column-direction hit
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) xsm[nt] = mirror ? xs[nt] : INFINITY;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 f32x4 tqs[4];
@@ -288,7 +299,7 @@ struct KnnFastEpilogue {
                     const float wmax = fmaxf(fmaxf(wmax4[0], wmax4[1]), fmaxf(wmax4[2], wmax4[3]));
                     const float tmin = fmaf(dsc, amax, xn[nt]);         // the smallest approximate value of the tile's 16 elements
                     const float pl = fminf(flt[nt], best[nt][KCAP - 1] + fmaf(e2c, xn[nt], e2n));
-                    if (!__any(tmin <= pl || (mirror && wmax >= xs[nt]))) continue;          // gate 1 (see below)
+                    if ((lanes_le(tmin, pl) | lanes_ge(wmax, xsm[nt])) == 0ull) continue;    // gate 1 (see below)
 #ifdef AM_DEV_KNOBS
                     if constexpr (TBX == WIDE_TILE_ROWS) {
                         if (g_wide_dbg & 16) continue;
@@ -296,14 +307,15 @@ struct KnnFastEpilogue {
 #endif
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        if (!__any(fmaf(dsc, amax4[g4], xn[nt]) <= pl || (mirror && wmax4[g4] >= xs[nt]))) continue;
+                        if ((lanes_le(fmaf(dsc, amax4[g4], xn[nt]), pl) | lanes_ge(wmax4[g4], xsm[nt])) == 0ull) continue;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int reg = g4 * 4 + e;
                             const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt]);
-                            const bool own = u <= pl, mir = mirror && acc[mt][nt][reg] - tqs[g4][e] >= xs[nt];
-                            const unsigned long long sel = __ballot(own || mir);
+                            const float w = acc[mt][nt][reg] - tqs[g4][e];
+                            const unsigned long long sel = lanes_le(u, pl) | lanes_ge(w, xsm[nt]);
                             if (sel != 0ull) {
+                                const bool own = u <= pl, mir = w >= xsm[nt];
                                 const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(sel >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sel, 0u));
                                 const int slot = wq + below;
                                 wq += __popcll(sel);
@@ -319,7 +331,7 @@ struct KnnFastEpilogue {
 #ifdef AM_DEV_KNOBS
                     if (TBX == WIDE_TILE_ROWS && (g_wide_dbg & 64)) continue;
 #endif
-                    if (__any(vmin < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], vmin);
+                    if (lanes_lt(vmin, best[nt][KCAP - 1]) != 0ull) list_insert<KCAP>(best[nt], vmin);
                 }
             }
             return;

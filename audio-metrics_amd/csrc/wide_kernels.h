@@ -40,7 +40,7 @@ struct CrossWideEpilogue {
     int* fail;
     float dsc, idsc;
     int64_t prow[NT];
-    float xn[NT], xs[NT], thi[NT], tlo[NT], e2[NT], m[NT];
+    float xn[NT], xs[NT], xsn[NT], thi[NT], tlo[NT], e2[NT], m[NT];   // xsn (ACC_INIT): xs while the row still lacks its witness, +inf after
     bool rowok[NT], anyf[NT], covf[NT];
     float aux_n, aux_hi;
     const Lane& L;
@@ -105,6 +105,10 @@ struct CrossWideEpilogue {
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
+                    // Gates as lane masks on the scalar unit (lanes_le / lanes_ge, pairwise_common.h).  No row-validity or
+                    // "still needs a witness" masks beside them: a row past the end carries thresholds of -inf (thi, tlo, m)
+                    // and xsn = +inf, a row that has its witness xsn = +inf - their compares fail by themselves (combining
+                    // masks costs a chain of dependent scalar instructions per gate; measured, pairwise_common.h).
                     float amax4[4], wmax4[4];
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
@@ -121,10 +125,9 @@ struct CrossWideEpilogue {
                     if constexpr (WANT_MIN) m[nt] = fminf(m[nt], fmaxf(tmin, 0.f));
                     const float prow_thr = WANT_MIN ? fmaxf(thi[nt], m[nt] + e2[nt]) : thi[nt];
                     {
-                        bool hit = rowok[nt] && tmin <= prow_thr;
-                        if constexpr (NEED_ANY)
-                            hit = hit || (rowok[nt] && !anyf[nt] && fmaxf(fmaxf(wmax4[0], wmax4[1]), fmaxf(wmax4[2], wmax4[3])) >= xs[nt]);
-                        if (!__any(hit)) continue;
+                        unsigned long long hit = lanes_le(tmin, prow_thr);
+                        if constexpr (NEED_ANY) hit |= lanes_ge(fmaxf(fmaxf(wmax4[0], wmax4[1]), fmaxf(wmax4[2], wmax4[3])), xsn[nt]);
+                        if (hit == 0ull) continue;
 #ifdef AM_DEV_KNOBS
                         if (g_wide_dbg & 16) continue;
 #endif
@@ -132,9 +135,9 @@ struct CrossWideEpilogue {
                     const float* alo = a + 2 * WTB + mt * 32;
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        const bool row_hit = __any(rowok[nt] && fmaf(dsc, amax4[g4], xn[nt]) <= prow_thr);
+                        const bool row_hit = lanes_le(fmaf(dsc, amax4[g4], xn[nt]), prow_thr) != 0ull;
                         bool any_hit = false;
-                        if constexpr (NEED_ANY) any_hit = __any(rowok[nt] && !anyf[nt] && wmax4[g4] >= xs[nt]);
+                        if constexpr (NEED_ANY) any_hit = lanes_ge(wmax4[g4], xsn[nt]) != 0ull;
 #ifdef AM_DEV_KNOBS
                         if (g_wide_dbg & 8) any_hit = false;
 #endif
@@ -146,8 +149,8 @@ struct CrossWideEpilogue {
                             const int64_t j = jbase + mt * 32 + g4 * 8 + e;
                             bool sure = false, want = false;
                             if (row_hit) {
-                                sure = rowok[nt] && u < tlo[nt];
-                                const unsigned long long mask = __ballot(sure);
+                                const unsigned long long mask = lanes_lt(u, tlo[nt]);
+                                sure = u < tlo[nt];
                                 if (mask != 0ull && L.lane == 0) {
                                     const int lo = __popcll(mask & 0xffffffffull);
                                     const int hi = __popcll(mask >> 32);
@@ -155,13 +158,17 @@ struct CrossWideEpilogue {
                                     if (hi) atomicAdd(col_count + j - L.h * 4 + 4, hi);
                                 }
                                 covf[nt] = covf[nt] || sure;
-                                want = rowok[nt] && !sure && u <= thi[nt];
-                                if constexpr (WANT_MIN) want = want || (rowok[nt] && u <= m[nt] + e2[nt]);
+                                want = !sure && u <= thi[nt];
+                                if constexpr (WANT_MIN) want = want || u <= m[nt] + e2[nt];
                             }
                             if constexpr (NEED_ANY) {
-                                if (rowok[nt] && !anyf[nt] && acc[mt][nt][reg] - ths[g4][e] >= xs[nt]) {
-                                    if (u < alo[g4 * 8 + e]) anyf[nt] = true;       // certain witness
-                                    else want = true;                               // ambiguous "any"
+                                if (acc[mt][nt][reg] - ths[g4][e] >= xsn[nt]) {
+                                    if (u < alo[g4 * 8 + e]) {                      // certain witness
+                                        anyf[nt] = true;
+                                        xsn[nt] = INFINITY;
+                                    } else {
+                                        want = true;                                // ambiguous "any"
+                                    }
                                 }
                             }
                             if (want) push(prow[nt], (unsigned)j | (sure ? FAST_COUNTED : 0u));
@@ -362,8 +369,11 @@ cross_wide_body(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const flo
         epi.thi[nt] = ok ? rthr[i] + e : -INFINITY;
         epi.tlo[nt] = ok ? rthr[i] - e : -INFINITY;
         epi.e2[nt] = 2.f * e;
-        epi.m[nt] = (WANT_MIN && ok) ? __uint_as_float(rmin_approx[i]) : INFINITY;
+        // (ACC_INIT: a row past the end takes part in no test through its thresholds alone - thi, tlo = -inf above, the running
+        // minimum -inf so that m + e2 is, and no witness wanted)
+        epi.m[nt] = (WANT_MIN && ok) ? __uint_as_float(rmin_approx[i]) : (Lane::ACC_INIT ? -INFINITY : INFINITY);
         epi.anyf[nt] = ok ? (row_any[i] != 0u) : true;
+        epi.xsn[nt] = epi.anyf[nt] ? INFINITY : epi.xs[nt];
         epi.covf[nt] = false;
     }
 #ifdef AM_DEV_KNOBS
