@@ -108,5 +108,40 @@ def build_library(force=False, verbose=False, dev=True):
     return LIB_PATH
 
 
+RCCL_ADAPTER_SRC = os.path.join(CSRC, "rccl", "am_rccl.cpp")
+RCCL_ADAPTER_PATH = os.path.join(LIB_DIR, "libaudio_metrics_rccl.so")
+
+
+def build_rccl_adapter(force=False):
+    """libaudio_metrics_rccl.so: am_collectives over an ncclComm_t (csrc/rccl/am_rccl.cpp) - the hooks a host that is not
+    Python hands to am_evaluate_sharded_f32.  Its own library: libaudio_metrics_hip.so links no collective library.  Returns
+    the path, or None where the image has no RCCL headers."""
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if not os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h")):
+        return None
+    h = hashlib.sha256()
+    for path in (RCCL_ADAPTER_SRC, os.path.join(os.path.dirname(PKG_DIR), "include", "audio_metrics_hip.h")):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    digest = h.hexdigest()
+    stamp = _stamp_path(RCCL_ADAPTER_PATH)
+    if not force and os.path.exists(RCCL_ADAPTER_PATH) and os.path.exists(stamp):
+        try:
+            with open(stamp) as f:
+                if json.load(f).get("sources_sha256") == digest:
+                    return RCCL_ADAPTER_PATH
+        except (OSError, ValueError):
+            pass
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", RCCL_ADAPTER_SRC, "-o", RCCL_ADAPTER_PATH,
+           "-L" + os.path.join(rocm, "lib"), "-lrccl"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    with open(stamp, "w") as f:
+        json.dump({"sources_sha256": digest}, f)
+    return RCCL_ADAPTER_PATH
+
+
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))

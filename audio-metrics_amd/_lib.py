@@ -78,6 +78,9 @@ SIGNATURES = {
     "am_evaluate_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int, c_int, ctypes.c_uint]),
     "am_evaluate_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int, ctypes.c_uint, c_int, _P, _P, c_int, c_int,
                                 c_double, c_double, c_int, _P, _P, _P, _P, c_size_t, _P, _P]),
+    "am_evaluate_sharded_workspace_bytes": (c_size_t, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint]),
+    "am_evaluate_sharded_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, _P, ctypes.c_uint, c_int, _P, _P, c_int, c_int,
+                                        c_double, c_double, c_int, _P, _P, c_size_t, _P, _P, _P]),
     "am_kernel_clock_enable": (c_int, [c_int]),
     "am_kernel_clock_read": (c_int, [c_int, _P, _P]),
     "am_knn_path": (c_int, [c_int64, c_int64, c_int, c_int, c_int]),
@@ -100,6 +103,16 @@ class EvaluateSideStruct(ctypes.Structure):
     """am_evaluate_side: results the caller already holds / wants to keep (device pointers, NULL = not given)."""
     _fields_ = [("mean", c_void_p), ("cov", c_void_p), ("radii", c_void_p),
                 ("mean_out", c_void_p), ("cov_out", c_void_p), ("radii_out", c_void_p)]
+
+
+# am_collectives: the two collectives of am_evaluate_sharded_f32 as hooks (include/audio_metrics_hip.h)
+ALL_REDUCE_SUM_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p)
+ALL_GATHER_V_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p)
+
+
+class CollectivesStruct(ctypes.Structure):
+    _fields_ = [("ctx", c_void_p), ("rank", c_int), ("world", c_int),
+                ("all_reduce_sum", ALL_REDUCE_SUM_FN), ("all_gather_v", ALL_GATHER_V_FN)]
 
 
 _lib = None

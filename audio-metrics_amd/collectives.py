@@ -1,0 +1,88 @@
+"""The two collectives am_evaluate_sharded_f32 asks its caller for (include/audio_metrics_hip.h: am_collectives), over
+torch.distributed - the Python counterpart of csrc/rccl/am_rccl.cpp, which builds the same hooks over an ncclComm_t for hosts
+that are not Python.  The library hands the hooks raw device pointers; every buffer it names lies in a tensor this process
+allocated (the call's workspace), which `expose` registers so that a pointer can be turned back into a tensor view."""
+import contextlib
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+COLL_F64, COLL_I32 = 0, 1
+
+
+class TorchCollectives:
+    def __init__(self, group=None):
+        self.group = group
+        active = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if active else 0
+        self.world = dist.get_world_size(group) if active else 1
+        self._tensors = []
+        self.error = None
+        self.calls = []                                     # (name, bytes) of every hook call, in issue order
+        self._reduce = _lib.ALL_REDUCE_SUM_FN(self._all_reduce_sum)
+        self._gather = _lib.ALL_GATHER_V_FN(self._all_gather_v)
+        self.struct = _lib.CollectivesStruct(None, self.rank, self.world, self._reduce, self._gather)
+
+    def expose(self, tensor):
+        self._tensors.append(tensor)
+        return tensor
+
+    def _view(self, ptr, nbytes):
+        for t in self._tensors:
+            base = t.data_ptr()
+            if base <= ptr and ptr + nbytes <= base + t.numel() * t.element_size():
+                flat = t.view(-1).view(torch.uint8)
+                return flat[ptr - base:ptr - base + nbytes]
+        raise RuntimeError(f"collective hook: pointer {ptr:#x} (+{nbytes}) lies in no exposed tensor")
+
+    def _on(self, stream_ptr, device):
+        # torch orders a collective after the work of its CURRENT stream: make that the stream the library named
+        if device.type != "cuda":
+            return contextlib.nullcontext()                  # (host tensors: the hooks' own unit test)
+        if stream_ptr:
+            return torch.cuda.stream(torch.cuda.ExternalStream(stream_ptr, device=device))
+        return torch.cuda.stream(torch.cuda.current_stream(device))
+
+    def _all_reduce_sum(self, ctx, buf, count, dtype, stream):
+        try:
+            dt, size = (torch.float64, 8) if dtype == COLL_F64 else (torch.int32, 4)
+            self.calls.append(("all_reduce_sum", count * size))
+            if self.world == 1:
+                return 0
+            view = self._view(buf, count * size).view(dt)
+            with self._on(stream, view.device):
+                dist.all_reduce(view, group=self.group)
+            return 0
+        except Exception as exc:                            # an exception must not cross the C frames above
+            self.error = exc
+            return 1
+
+    def _all_gather_v(self, ctx, send, recv, bytes_per_rank, stream):
+        try:
+            sizes = [int(bytes_per_rank[r]) for r in range(self.world)]
+            self.calls.append(("all_gather_v", sum(sizes)))
+            if self.world == 1 or sum(sizes) == 0:
+                return 0
+            whole = self._view(recv, sum(sizes))
+            offs = [sum(sizes[:r]) for r in range(self.world)]
+            if send != recv + offs[self.rank]:
+                raise RuntimeError("all_gather_v: the library promises an in-place call")
+            biggest = max(sizes)
+            with self._on(stream, whole.device):
+                mine = torch.zeros(biggest, dtype=torch.uint8, device=whole.device)
+                mine[:sizes[self.rank]] = whole[offs[self.rank]:offs[self.rank] + sizes[self.rank]]
+                parts = [torch.empty(biggest, dtype=torch.uint8, device=whole.device) for _ in range(self.world)]
+                dist.all_gather(parts, mine, group=self.group)
+                for r in range(self.world):
+                    if r != self.rank and sizes[r]:
+                        whole[offs[r]:offs[r] + sizes[r]] = parts[r][:sizes[r]]
+            return 0
+        except Exception as exc:
+            self.error = exc
+            return 1
+
+    def byref(self):
+        return ctypes.byref(self.struct)

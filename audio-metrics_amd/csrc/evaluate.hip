@@ -17,6 +17,7 @@
 // library between the entry points (rocprofv3 timeline, profiles/r3).
 #include "am_common.h"
 #include <algorithm>
+#include <vector>
 
 namespace am {
 
@@ -196,6 +197,385 @@ extern "C" int am_evaluate_f32(const float* ref, int64_t n_ref, int64_t ld_ref, 
         AM_HIP_TRY(hipEventCreateWithFlags(&ev_fad.e, hipEventDisableTiming));
         AM_HIP_TRY(hipEventRecord(ev_fad.e, side));
         AM_HIP_TRY(hipStreamWaitEvent(st, ev_fad.e, 0));
+    }
+    hipLaunchKernelGGL(eval_pack_kernel, dim3(1), dim3(64), 0, st, L.fad_out, L.totals, out, what);
+    AM_LAUNCH_CHECK();
+    return AM_OK;
+}
+
+// =====================================================================================================================
+// One call = one RANK's share of a row-sharded evaluate (VERDICT r4 "missing" item 4): the exchange schedule of
+// audio-metrics_amd/distributed.py: evaluate_sharded behind the C ABI, for hosts that are not Python.  The library links no
+// collective library: the caller hands in the two collectives of the schedule as stream-ordered hooks (am_collectives;
+// audio-metrics_amd/csrc/rccl/am_rccl.cpp builds them over an ncclComm_t, tests build them over torch.distributed).
+//
+// Streams: compute on `stream`; every collective on `comm_stream` in ISSUE ORDER (one communicator = one queue), fenced with
+// events - it waits for the event that marks its input ready, and the compute stream waits for its completion only where
+// the result is first read; the Frechet solve on `side_stream`.  comm_stream == stream gives the serial form.
+//   column sums (2 D f64, all-reduce)  FIRST: the centred scatters need the global means and nothing may queue behind 200 MB
+//   reference rows (all-gather)        under the scatter kernels
+//   scatters (2 D^2 f64, all-reduce)   only the Frechet solve waits for it
+//   reference set: prepare, bounds of this rank's rows -> all-gather -> candidate rows (all-gather) issued right behind:
+//                  they travel under the reference set's sweep -> this rank's share of the sweep -> lists all-gather -> finish
+//   candidate set: the same;  membership counts of this rank's reference rows -> counts + row totals (all-reduce, i32)
+//   kernel distance: subsets rank, rank + world, ... -> all-reduce of the S values
+// Sets the partitioned sweep does not apply to (am_knn_sym_eligible, a rank without rows) take the general kernel on the row
+// shard and an all-gather of the radii.  float32 rows; results in the record of am_evaluate_f32 on every rank.
+namespace am {
+
+__global__ void shard_scale_kernel(double* __restrict__ v, int64_t n, double f) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v[i] *= f;
+}
+// local totals {.., rows any, .., rows covered} -> the two int32 slots behind the column counts
+__global__ void shard_rows_kernel(const long long* __restrict__ totals, int32_t* __restrict__ packed_tail) {
+    if (threadIdx.x == 0) {
+        packed_tail[0] = (int32_t)totals[1];
+        packed_tail[1] = (int32_t)totals[3];
+    }
+}
+__global__ void shard_totals_kernel(const long long* __restrict__ col_totals, const int32_t* __restrict__ packed_tail,
+                                    long long* __restrict__ out4) {
+    if (threadIdx.x == 0) {
+        out4[0] = col_totals[0];
+        out4[1] = packed_tail[0];
+        out4[2] = col_totals[2];
+        out4[3] = packed_tail[1];
+    }
+}
+
+struct ShardLayout {
+    size_t total = 0;
+    int64_t ldf = 0, width = 0;
+    double *sums = nullptr, *scat = nullptr, *fad_out = nullptr, *mmds = nullptr, *mmds_own = nullptr;
+    void* ws_fad = nullptr;
+    size_t fad_ws = 0;
+    float* full[2] = {nullptr, nullptr};
+    float *norms[2] = {nullptr, nullptr}, *radii[2] = {nullptr, nullptr};
+    uint32_t* pstats[2] = {nullptr, nullptr};
+    uint16_t* half[2] = {nullptr, nullptr};
+    float *bounds = nullptr, *lists_own = nullptr, *lists_all = nullptr;
+    int32_t *packed = nullptr, *col = nullptr;
+    uint8_t *rany = nullptr, *rcov = nullptr;
+    long long *totals_local = nullptr, *totals_col = nullptr, *totals = nullptr;
+    int64_t *idx_own[2] = {nullptr, nullptr};
+    void* ws_main = nullptr;
+    size_t ws_main_bytes = 0;
+};
+
+static int64_t shard_sum(const int64_t* c, int n) {
+    int64_t s = 0;
+    for (int i = 0; i < n; ++i) s += c[i];
+    return s;
+}
+
+static bool shard_layout(Carver& c, const int64_t* ref_counts, const int64_t* cand_counts, int rank, int world, int D, int k, int S,
+                         int m, unsigned what, ShardLayout& L) {
+    const int64_t n[2] = {shard_sum(ref_counts, world), shard_sum(cand_counts, world)};
+    const int64_t nl[2] = {ref_counts[rank], cand_counts[rank]};
+    L.ldf = (int64_t)round_up((size_t)D, (size_t)4);
+    size_t main_bytes = 256;
+    if (what & AM_EVAL_FAD) {
+        L.sums = c.take<double>((size_t)2 * D);
+        L.scat = c.take<double>((size_t)2 * D * D);
+        L.fad_ws = am_frechet_workspace_bytes(D);
+        L.ws_fad = c.take<char>(L.fad_ws);
+        L.fad_out = c.take<double>(8);
+        main_bytes = std::max({main_bytes, am_stats_workspace_bytes(std::max<int64_t>(nl[0], 1), D),
+                               am_stats_workspace_bytes(std::max<int64_t>(nl[1], 1), D)});
+    }
+    if (what & (AM_EVAL_KD | AM_EVAL_PRDC))
+        for (int s = 0; s < 2; ++s) L.full[s] = c.take<float>((size_t)n[s] * L.ldf);
+    if (what & AM_EVAL_PRDC) {
+        const int64_t ldh = am_prepared_half_ld(D);
+        L.width = am_knn_list_width(k);
+        int64_t nmax = std::max(n[0], n[1]);
+        for (int s = 0; s < 2; ++s) {
+            L.norms[s] = c.take<float>(n[s]);
+            L.pstats[s] = c.take<uint32_t>(4);
+            L.half[s] = c.take<uint16_t>((size_t)n[s] * ldh);
+            L.radii[s] = c.take<float>(n[s]);
+            main_bytes = std::max(main_bytes, am_knn_workspace_bytes(std::max<int64_t>(nl[s], 1), n[s], D, k));
+            if (world > 1 && am_knn_sym_eligible(n[s], D, k))
+                main_bytes = std::max({main_bytes, am_knn_part_workspace_bytes(n[s], D, k), am_knn_lists_finish_workspace_bytes(n[s], D, k)});
+        }
+        L.bounds = c.take<float>(nmax);
+        L.lists_own = c.take<float>((size_t)nmax * L.width);
+        L.lists_all = c.take<float>((size_t)world * nmax * L.width);
+        L.packed = c.take<int32_t>(n[1] + 2);
+        L.col = c.take<int32_t>(n[1]);
+        L.rany = c.take<uint8_t>(std::max<int64_t>(nl[0], 1));
+        L.rcov = c.take<uint8_t>(std::max<int64_t>(nl[0], 1));
+        L.totals_local = c.take<long long>(4);
+        L.totals_col = c.take<long long>(4);
+        L.totals = c.take<long long>(4);
+        main_bytes = std::max(main_bytes, am_prdc_workspace_bytes(std::max<int64_t>(nl[0], 1), n[1], D));
+    }
+    if (what & AM_EVAL_KD) {
+        const int own = rank < S ? (S - rank + world - 1) / world : 0;
+        L.mmds = c.take<double>(S);
+        L.mmds_own = c.take<double>(std::max(own, 1));
+        for (int s = 0; s < 2; ++s) L.idx_own[s] = c.take<int64_t>((size_t)std::max(own, 1) * m);
+        if (own > 0) main_bytes = std::max(main_bytes, am_kd_poly_workspace_bytes(own, m, D));
+    }
+    L.ws_main_bytes = round_up(main_bytes, (size_t)256);
+    L.ws_main = c.take<char>(L.ws_main_bytes);
+    L.total = c.off;
+    return c.ok();
+}
+
+}  // namespace am
+
+static bool shard_args_ok(const int64_t* ref_counts, const int64_t* cand_counts, int rank, int world) {
+    if (!ref_counts || !cand_counts || world < 1 || rank < 0 || rank >= world) return false;
+    for (int r = 0; r < world; ++r)
+        if (ref_counts[r] < 0 || cand_counts[r] < 0) return false;
+    return true;
+}
+
+extern "C" size_t am_evaluate_sharded_workspace_bytes(const int64_t* ref_counts, const int64_t* cand_counts, int rank, int world,
+                                                      int D, int nearest_k, int kd_subsets, int kd_m, unsigned what) {
+    if (!shard_args_ok(ref_counts, cand_counts, rank, world) || D < 1) return 0;
+    if (shard_sum(ref_counts, world) < 1 || shard_sum(cand_counts, world) < 1) return 0;
+    Carver c(nullptr, 0);
+    ShardLayout L;
+    shard_layout(c, ref_counts, cand_counts, rank, world, D, nearest_k, kd_subsets, kd_m, what, L);
+    return L.total;
+}
+
+extern "C" int am_evaluate_sharded_f32(const float* ref_local, int64_t ld_ref, const float* cand_local, int64_t ld_cand, int D,
+                                       const int64_t* ref_counts, const int64_t* cand_counts, const am_collectives* coll,
+                                       unsigned what, int nearest_k, const int64_t* idx_cand, const int64_t* idx_ref, int kd_subsets,
+                                       int kd_m, double kd_gamma, double kd_coef0, int kd_degree, double* out, void* ws,
+                                       size_t ws_bytes, am_stream_t stream, am_stream_t side_stream, am_stream_t comm_stream) {
+    AM_REQUIRE(coll && coll->all_reduce_sum && coll->all_gather_v && out, AM_ERR_BAD_ARG, "null pointer");
+    const int rank = coll->rank, world = coll->world;
+    AM_REQUIRE(shard_args_ok(ref_counts, cand_counts, rank, world), AM_ERR_BAD_ARG, "rank %d of %d, or negative shard sizes", rank, world);
+    AM_REQUIRE(D >= 1, AM_ERR_BAD_SHAPE, "D = %d", D);
+    AM_REQUIRE((what & ~(unsigned)(AM_EVAL_FAD | AM_EVAL_KD | AM_EVAL_PRDC)) == 0 && what != 0, AM_ERR_BAD_ARG, "what = %u", what);
+    AM_REQUIRE(!(what & AM_EVAL_KD) || (idx_cand && idx_ref && kd_subsets >= 1 && kd_m >= 1), AM_ERR_BAD_ARG,
+               "kernel distance needs the two index tables");
+    AM_REQUIRE(!(what & AM_EVAL_FAD) || side_stream != stream, AM_ERR_BAD_ARG,
+               "the Frechet solve runs on side_stream, which must differ from stream");
+    const int64_t n[2] = {shard_sum(ref_counts, world), shard_sum(cand_counts, world)};
+    // the same error on every rank: all of them hold the totals (distributed.py: evaluate_sharded)
+    AM_REQUIRE(n[0] >= 1 && n[1] >= 1, AM_ERR_BAD_SHAPE, "empty embedding set: %lld reference and %lld candidate rows over %d ranks",
+               (long long)n[0], (long long)n[1], world);
+    const int64_t* counts[2] = {ref_counts, cand_counts};
+    const int64_t nl[2] = {ref_counts[rank], cand_counts[rank]};
+    int64_t lo[2] = {0, 0};
+    for (int r = 0; r < rank; ++r) {
+        lo[0] += ref_counts[r];
+        lo[1] += cand_counts[r];
+    }
+    const float* X[2] = {ref_local, cand_local};
+    const int64_t ld[2] = {ld_ref, ld_cand};
+    for (int s = 0; s < 2; ++s) AM_REQUIRE(nl[s] == 0 || X[s] != nullptr, AM_ERR_BAD_ARG, "null pointer for a shard of %lld rows", (long long)nl[s]);
+    hipStream_t st = static_cast<hipStream_t>(stream), side = static_cast<hipStream_t>(side_stream),
+                cs = static_cast<hipStream_t>(comm_stream ? comm_stream : stream);
+    am_stream_t comm = comm_stream ? comm_stream : stream;
+    Carver c(ws, ws_bytes);
+    ShardLayout L;
+    AM_REQUIRE(shard_layout(c, ref_counts, cand_counts, rank, world, D, nearest_k, kd_subsets, kd_m, what, L), AM_ERR_WORKSPACE,
+               "workspace too small: need %zu bytes, have %zu", L.total, ws_bytes);
+    int rc;
+
+    // events of this call (destroyed on every way out)
+    struct Events {
+        std::vector<hipEvent_t> all;
+        ~Events() {
+            for (hipEvent_t e : all) (void)hipEventDestroy(e);
+        }
+    } events;
+    auto mark = [&](hipStream_t on, hipEvent_t* out_e) -> hipError_t {          // a new event recorded on `on`
+        hipEvent_t e = nullptr;
+        hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (err != hipSuccess) return err;
+        events.all.push_back(e);
+        *out_e = e;
+        return hipEventRecord(e, on);
+    };
+    // a collective: the communication stream waits for the compute stream's present position (its input), the hook
+    // enqueues it there, `done` marks its end - waited for by whoever reads the result first
+    auto collective = [&](hipEvent_t* done, auto&& call) -> int {
+        if (cs != st) {
+            hipEvent_t ready;
+            AM_HIP_TRY(mark(st, &ready));
+            AM_HIP_TRY(hipStreamWaitEvent(cs, ready, 0));
+        }
+        const int hook_rc = call();
+        if (hook_rc != 0) {
+            set_error("a collective hook returned %d", hook_rc);
+            return AM_ERR_HIP;
+        }
+        AM_HIP_TRY(mark(cs, done));
+        return AM_OK;
+    };
+    auto wait_on = [&](hipStream_t who, hipEvent_t e) -> hipError_t { return (who == cs) ? hipSuccess : hipStreamWaitEvent(who, e, 0); };
+    std::vector<int64_t> bytes(world);
+    // all-gather of per-row data of set s (`per_row` bytes each), in place: this rank's part already sits at its offset
+    auto gather_rows = [&](int s, void* buf, int64_t per_row, hipEvent_t* done) -> int {
+        return collective(done, [&]() {
+            for (int r = 0; r < world; ++r) bytes[r] = counts[s][r] * per_row;
+            return coll->all_gather_v(coll->ctx, static_cast<char*>(buf) + lo[s] * per_row, buf, bytes.data(), comm);
+        });
+    };
+
+    // ---- 1. column sums first
+    hipEvent_t ev_sums = nullptr, ev_scat = nullptr, ev_full[2] = {nullptr, nullptr};
+    if (what & AM_EVAL_FAD) {
+        for (int s = 0; s < 2; ++s) {
+            if (nl[s] > 0) {
+                if ((rc = am_colsum_f32(X[s], nl[s], D, ld[s], L.sums + (size_t)s * D, L.ws_main, L.ws_main_bytes, stream)) != AM_OK) return rc;
+            } else {
+                AM_HIP_TRY(hipMemsetAsync(L.sums + (size_t)s * D, 0, (size_t)D * sizeof(double), st));
+            }
+        }
+        if ((rc = collective(&ev_sums, [&]() { return coll->all_reduce_sum(coll->ctx, L.sums, (int64_t)2 * D, AM_COLL_F64, comm); })) != AM_OK)
+            return rc;
+    }
+    // ---- 2. the rows of this rank into their place of the gathered copies; the reference rows' gather starts
+    const bool need_full = (what & (AM_EVAL_KD | AM_EVAL_PRDC)) != 0;
+    auto start_gather = [&](int s) -> int {
+        if (ev_full[s] != nullptr) return AM_OK;
+        return gather_rows(s, L.full[s], L.ldf * (int64_t)sizeof(float), &ev_full[s]);
+    };
+    if (need_full) {
+        for (int s = 0; s < 2; ++s)
+            if (nl[s] > 0)
+                AM_HIP_TRY(hipMemcpy2DAsync(L.full[s] + lo[s] * L.ldf, (size_t)L.ldf * sizeof(float), X[s], (size_t)ld[s] * sizeof(float),
+                                            (size_t)D * sizeof(float), (size_t)nl[s], hipMemcpyDeviceToDevice, st));
+        if (L.ldf != D)                                         // (padding columns of the gathered copies: never read as data)
+            for (int s = 0; s < 2; ++s)
+                if (nl[s] > 0)
+                    AM_HIP_TRY(hipMemset2DAsync(L.full[s] + lo[s] * L.ldf + D, (size_t)L.ldf * sizeof(float), 0,
+                                                (size_t)(L.ldf - D) * sizeof(float), (size_t)nl[s], st));
+        if ((rc = start_gather(0)) != AM_OK) return rc;
+        if (!(what & AM_EVAL_PRDC) && (rc = start_gather(1)) != AM_OK) return rc;          // KD only: nothing to order it behind
+    }
+    // ---- 3. centred scatters around the global means; covariances; the Frechet solve is enqueued at the end
+    if (what & AM_EVAL_FAD) {
+        AM_HIP_TRY(wait_on(st, ev_sums));
+        for (int s = 0; s < 2; ++s)
+            hipLaunchKernelGGL(shard_scale_kernel, dim3(std::min<int64_t>(ceil_div((int64_t)D, (int64_t)256), 1024)), dim3(256), 0, st,
+                               L.sums + (size_t)s * D, (int64_t)D, 1.0 / (double)n[s]);
+        AM_LAUNCH_CHECK();
+        for (int s = 0; s < 2; ++s) {
+            double* sc = L.scat + (size_t)s * D * D;
+            if (nl[s] > 0) {
+                if ((rc = am_scatter_f32(X[s], nl[s], D, ld[s], L.sums + (size_t)s * D, sc, L.ws_main, L.ws_main_bytes, stream)) != AM_OK) return rc;
+            } else {
+                AM_HIP_TRY(hipMemsetAsync(sc, 0, (size_t)D * D * sizeof(double), st));
+            }
+        }
+        if ((rc = collective(&ev_scat, [&]() { return coll->all_reduce_sum(coll->ctx, L.scat, (int64_t)2 * D * D, AM_COLL_F64, comm); })) != AM_OK)
+            return rc;
+    }
+
+    // ---- 4. PRDC
+    if (what & AM_EVAL_PRDC) {
+        am_prepared_set prep[2];
+        for (int s = 0; s < 2; ++s) {
+            if ((rc = start_gather(s)) != AM_OK) return rc;                  // (the candidate rows: issued in the reference pass, below)
+            AM_HIP_TRY(wait_on(st, ev_full[s]));
+            if ((rc = am_prepare_set_f32(L.full[s], n[s], L.ldf, D, L.norms[s], L.pstats[s], L.half[s], stream)) != AM_OK) return rc;
+            prep[s].norms = L.norms[s];
+            prep[s].stats = L.pstats[s];
+            prep[s].half = L.half[s];
+            bool every_rank_has_rows = true;
+            for (int r = 0; r < world; ++r) every_rank_has_rows = every_rank_has_rows && counts[s][r] > 0;
+            hipEvent_t ev = nullptr;
+            if (world > 1 && every_rank_has_rows && am_knn_sym_eligible(n[s], D, nearest_k)) {
+                if ((rc = am_knn_bounds_prepared_f32(L.full[s], n[s], L.ldf, D, &prep[s], nearest_k, lo[s], nl[s], L.bounds + lo[s],
+                                                     L.ws_main, L.ws_main_bytes, stream)) != AM_OK) return rc;
+                if ((rc = gather_rows(s, L.bounds, sizeof(float), &ev)) != AM_OK) return rc;
+                if (s == 0 && (rc = start_gather(1)) != AM_OK) return rc;     // right behind the 400 KB exchange: under the sweep
+                AM_HIP_TRY(wait_on(st, ev));
+                if ((rc = am_knn_sym_part_prepared_f32(L.full[s], n[s], L.ldf, D, &prep[s], nearest_k, rank, world, L.bounds, L.lists_own,
+                                                       L.ws_main, L.ws_main_bytes, stream)) != AM_OK) return rc;
+                const int64_t list_bytes = n[s] * L.width * (int64_t)sizeof(float);
+                AM_HIP_TRY(hipMemcpyAsync(L.lists_all + (size_t)rank * n[s] * L.width, L.lists_own, (size_t)list_bytes, hipMemcpyDeviceToDevice, st));
+                if ((rc = collective(&ev, [&]() {
+                         for (int r = 0; r < world; ++r) bytes[r] = list_bytes;
+                         return coll->all_gather_v(coll->ctx, reinterpret_cast<char*>(L.lists_all) + (size_t)rank * list_bytes, L.lists_all,
+                                                   bytes.data(), comm);
+                     })) != AM_OK) return rc;
+                AM_HIP_TRY(wait_on(st, ev));
+                if ((rc = am_knn_lists_finish_f32(L.lists_all, world, L.full[s], n[s], L.ldf, D, nearest_k, L.radii[s], L.ws_main,
+                                                  L.ws_main_bytes, stream)) != AM_OK) return rc;
+            } else {
+                if (s == 0 && (rc = start_gather(1)) != AM_OK) return rc;
+                if (world == 1) {
+                    if ((rc = am_knn_radii_prepared_f32(L.full[s], n[s], L.ldf, D, &prep[s], nearest_k, L.radii[s], L.ws_main,
+                                                        L.ws_main_bytes, stream)) != AM_OK) return rc;
+                } else {
+                    if (nl[s] > 0 && (rc = am_knn_radii_f32(L.full[s] + lo[s] * L.ldf, nl[s], L.ldf, L.full[s], n[s], L.ldf, D, nearest_k,
+                                                            L.radii[s] + lo[s], L.ws_main, L.ws_main_bytes, stream)) != AM_OK) return rc;
+                    if ((rc = gather_rows(s, L.radii[s], sizeof(float), &ev)) != AM_OK) return rc;
+                    AM_HIP_TRY(wait_on(st, ev));
+                }
+            }
+        }
+        // membership counts of this rank's reference rows against all candidates
+        AM_HIP_TRY(hipMemsetAsync(L.packed, 0, (size_t)(n[1] + 2) * sizeof(int32_t), st));
+        if (nl[0] > 0) {
+            am_prepared_set shard = prep[0];
+            shard.norms = prep[0].norms + lo[0];
+            shard.half = prep[0].half + lo[0] * am_prepared_half_ld(D);
+            if ((rc = am_prdc_counts_prepared_f32(L.full[0] + lo[0] * L.ldf, nl[0], L.ldf, &shard, L.full[1], n[1], L.ldf, &prep[1], D,
+                                                  L.radii[0] + lo[0], L.radii[1], L.col, L.rany, L.rcov, nullptr, L.ws_main, L.ws_main_bytes,
+                                                  stream)) != AM_OK) return rc;
+            if ((rc = am_prdc_reduce(L.col, n[1], L.rany, L.rcov, nl[0], reinterpret_cast<int64_t*>(L.totals_local), stream)) != AM_OK) return rc;
+            AM_HIP_TRY(hipMemcpyAsync(L.packed, L.col, (size_t)n[1] * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(shard_rows_kernel, dim3(1), dim3(64), 0, st, L.totals_local, L.packed + n[1]);
+            AM_LAUNCH_CHECK();
+        }
+        hipEvent_t ev = nullptr;
+        if ((rc = collective(&ev, [&]() { return coll->all_reduce_sum(coll->ctx, L.packed, n[1] + 2, AM_COLL_I32, comm); })) != AM_OK) return rc;
+        AM_HIP_TRY(wait_on(st, ev));
+        if ((rc = am_prdc_reduce(L.packed, n[1], nullptr, nullptr, 0, reinterpret_cast<int64_t*>(L.totals_col), stream)) != AM_OK) return rc;
+        hipLaunchKernelGGL(shard_totals_kernel, dim3(1), dim3(64), 0, st, L.totals_col, L.packed + n[1], L.totals);
+        AM_LAUNCH_CHECK();
+    }
+
+    // ---- 5. kernel distance: the subsets rank, rank + world, ... (features_1 = candidate, audio_metrics.py:260)
+    if (what & AM_EVAL_KD) {
+        for (int s = 0; s < 2; ++s) {
+            if ((rc = start_gather(s)) != AM_OK) return rc;
+            AM_HIP_TRY(wait_on(st, ev_full[s]));
+        }
+        const int own = rank < kd_subsets ? (kd_subsets - rank + world - 1) / world : 0;
+        AM_HIP_TRY(hipMemsetAsync(L.mmds, 0, (size_t)kd_subsets * sizeof(double), st));
+        if (own > 0) {
+            const size_t row_bytes = (size_t)kd_m * sizeof(int64_t);
+            AM_HIP_TRY(hipMemcpy2DAsync(L.idx_own[0], row_bytes, idx_cand + (size_t)rank * kd_m, row_bytes * world, row_bytes, (size_t)own,
+                                        hipMemcpyDeviceToDevice, st));
+            AM_HIP_TRY(hipMemcpy2DAsync(L.idx_own[1], row_bytes, idx_ref + (size_t)rank * kd_m, row_bytes * world, row_bytes, (size_t)own,
+                                        hipMemcpyDeviceToDevice, st));
+            if ((rc = am_kd_poly_f32(L.full[1], n[1], L.ldf, L.full[0], n[0], L.ldf, D, L.idx_own[0], L.idx_own[1], own, kd_m, kd_gamma,
+                                     kd_coef0, kd_degree, L.mmds_own, L.ws_main, L.ws_main_bytes, stream)) != AM_OK) return rc;
+            AM_HIP_TRY(hipMemcpy2DAsync(L.mmds + rank, sizeof(double) * world, L.mmds_own, sizeof(double), sizeof(double), (size_t)own,
+                                        hipMemcpyDeviceToDevice, st));
+        }
+        hipEvent_t ev = nullptr;
+        if ((rc = collective(&ev, [&]() { return coll->all_reduce_sum(coll->ctx, L.mmds, (int64_t)kd_subsets, AM_COLL_F64, comm); })) != AM_OK) return rc;
+        AM_HIP_TRY(wait_on(st, ev));
+        AM_HIP_TRY(hipMemcpyAsync(out + AM_EVAL_HEAD, L.mmds, (size_t)kd_subsets * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+
+    // ---- 6. Frechet blocks on the side stream, replicated on every rank (a 2 MB problem), behind the scatters' all-reduce
+    if (what & AM_EVAL_FAD) {
+        if (cs != side) AM_HIP_TRY(hipStreamWaitEvent(side, ev_scat, 0));
+        for (int s = 0; s < 2; ++s)
+            hipLaunchKernelGGL(shard_scale_kernel, dim3(std::min<int64_t>(ceil_div((int64_t)D * D, (int64_t)256), 1024)), dim3(256), 0, side,
+                               L.scat + (size_t)s * D * D, (int64_t)D * D, 1.0 / (double)std::max<int64_t>(n[s] - 1, 1));
+        AM_LAUNCH_CHECK();
+        const int block = am_frechet_first_block(), max_iter = 64;
+        for (int first = 0; first < 2 * block; first += block)
+            if ((rc = am_frechet_enqueue_f64(L.sums + D, L.scat + (size_t)D * D, L.sums, L.scat, D, first, block, max_iter, 1e-13, L.fad_out,
+                                             L.ws_fad, L.fad_ws, side_stream)) != AM_OK) return rc;
+        hipEvent_t ev_fad;
+        AM_HIP_TRY(mark(side, &ev_fad));
+        AM_HIP_TRY(hipStreamWaitEvent(st, ev_fad, 0));
     }
     hipLaunchKernelGGL(eval_pack_kernel, dim3(1), dim3(64), 0, st, L.fad_out, L.totals, out, what);
     AM_LAUNCH_CHECK();

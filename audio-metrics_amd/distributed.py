@@ -488,9 +488,40 @@ def evaluate_single(ref, cand, metrics, nearest_k, ops, kid_subsets=KID_SUBSETS,
     return result_from_record(head, mmds, metrics, n_ref, n_cand, nearest_k)
 
 
+def _evaluate_sharded_c(ref_local, cand_local, ref_counts, cand_counts, metrics, nearest_k, group, ops, kid_subsets,
+                        kid_subset_size, rng_seed):
+    """The C-level form of evaluate_sharded: one am_evaluate_sharded_f32 call, one read-back."""
+    from .collectives import TorchCollectives
+    from .metrics.kd import device_subset_indices
+    world, _ = _world(group)
+    n_ref, n_cand = sum(ref_counts), sum(cand_counts)
+    idx1 = idx2 = None
+    if "kd" in metrics:
+        m = kid_subset_size
+        if m >= min(n_ref, n_cand):
+            m = max(1, min(n_ref, n_cand) // 2)
+        idx1, idx2 = device_subset_indices(n_cand, n_ref, kid_subsets, m, rng_seed, ref_local.device)     # features_1 = candidate
+    coll = TorchCollectives(group)
+    head, mmds = ops.evaluate_sharded_c(ref_local, cand_local, ref_counts, cand_counts, metrics, coll, nearest_k, idx1, idx2,
+                                        None, KID_COEF0, KID_DEGREE)
+    if "fad" in metrics:
+        code = int(head[4])
+        if code == 4:
+            from ._lib import HipLibraryError
+            raise HipLibraryError("am_evaluate_sharded_f32: non-finite covariance product or trace in Newton-Schulz")
+        if code == 0:          # (more than the 32 iterations the call enqueues: the same on every rank - finish on fresh statistics)
+            (mu_r, cov_r), (mu_c, cov_c) = global_stats_pair(ref_local, cand_local, n_ref, n_cand, ops, world, group)
+            head[0] = ops.frechet(mu_c, cov_c, mu_r, cov_r)["fd"]
+    return result_from_record(head, mmds, metrics, n_ref, n_cand, nearest_k)
+
+
 def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), nearest_k=5, group=None, ops=None,
-                     kid_subsets=KID_SUBSETS, kid_subset_size=KID_SUBSET_SIZE, rng_seed=1234, fused=True, shard_counts=None):
+                     kid_subsets=KID_SUBSETS, kid_subset_size=KID_SUBSET_SIZE, rng_seed=1234, fused=True, shard_counts=None,
+                     c_entry=False):
     """FAD / KD / PRDC of (candidate vs reference) from this rank's row shards.
+    c_entry=True: the whole schedule below as ONE library call per rank (am_evaluate_sharded_f32, float32 rows) with the
+    collectives handed in as hooks over this process group (collectives.TorchCollectives) - what a host that is not Python
+    would call with am_rccl_collectives; same results.
     Returns the same keys as ``AudioMetrics.evaluate`` on every rank.  With one rank the whole chain is one library
     call (``evaluate_single``); fused=False keeps the entry points separate there too (per-entry timing in bench.py).
     shard_counts = ([reference rows of rank 0, 1, ...], [candidate rows ...]) when the caller knows how the rows are dealt
@@ -524,6 +555,9 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
     if n_ref == 0 or n_cand == 0:                          # the same error on every rank (all of them hold the totals)
         raise ValueError(f"empty embedding set: {n_ref} reference and {n_cand} candidate rows over {world} ranks")
     d = ref_local.shape[1]
+    if c_entry and ref_local.dtype != torch.float64 and hasattr(ops, "evaluate_sharded_c"):
+        return _evaluate_sharded_c(ref_local, cand_local, ref_counts, cand_counts, metrics, nearest_k, group, ops, kid_subsets,
+                                   kid_subset_size, rng_seed)
 
     # 1) the 8 KB column-sum all-reduce goes FIRST: the collectives of one communicator run in issue order on one
     #    communication stream, so anything issued behind a 205 MB gather waits for all of it - and the centred scatter

@@ -815,3 +815,60 @@ def evaluate(ref, cand, what, nearest_k=5, idx_cand=None, idx_ref=None, gamma=No
         host = out.cpu()                                             # the one read-back
     head = host[:EVAL_HEAD].tolist()
     return head, (host[EVAL_HEAD:].numpy() if s else None)
+
+
+def evaluate_sharded_c(ref_local, cand_local, ref_counts, cand_counts, what, coll, nearest_k=5, idx_cand=None, idx_ref=None,
+                       gamma=None, coef0=1.0, degree=3, overlap=True):
+    """am_evaluate_sharded_f32: this rank's share of a row-sharded evaluate as ONE library call - the exchange schedule of
+    distributed.evaluate_sharded behind the C ABI, with the collectives supplied as hooks (`coll`: collectives.TorchCollectives
+    here, am_rccl_collectives for a host that is not Python).  ref_counts / cand_counts: rows of every rank.  overlap=False
+    issues the collectives on the compute stream.  Returns the host record like evaluate(): (head f64[16], mmds or None)."""
+    lib = _lib.load()
+    if is_f64(ref_local) or is_f64(cand_local):
+        raise ValueError("am_evaluate_sharded_f32 is the float32 schedule")
+    rank, world = coll.rank, coll.world
+    ref_counts, cand_counts = [int(c) for c in ref_counts], [int(c) for c in cand_counts]
+    if len(ref_counts) != world or len(cand_counts) != world:
+        raise ValueError("one shard size per rank")
+    ref_local, cand_local = as_matrix(ref_local, "reference"), as_matrix(cand_local, "candidate")
+    dev = _same_device(ref_local, cand_local)
+    d = ref_local.shape[1]
+    if cand_local.shape[1] != d or ref_local.shape[0] != ref_counts[rank] or cand_local.shape[0] != cand_counts[rank]:
+        raise ValueError("the shards do not match the shard sizes / each other")
+    flags = sum(bit for name, bit in (("fad", EVAL_FAD), ("kd", EVAL_KD), ("prdc", EVAL_PRDC)) if name in what)
+    s = m = 0
+    if flags & EVAL_KD:
+        idx_cand, idx_ref = _index_table(idx_cand, "idx_cand"), _index_table(idx_ref, "idx_ref")
+        s, m = idx_cand.shape
+    rc_arr = (ctypes.c_int64 * world)(*ref_counts)
+    cc_arr = (ctypes.c_int64 * world)(*cand_counts)
+    with torch.cuda.device(dev):
+        main = torch.cuda.current_stream(dev)
+        side_stream = _SIDE_STREAMS.get(("fad", dev.index))
+        if side_stream is None:
+            side_stream = _SIDE_STREAMS[("fad", dev.index)] = torch.cuda.Stream(dev)
+        comm_stream = _SIDE_STREAMS.get(("comm", dev.index))
+        if comm_stream is None:
+            comm_stream = _SIDE_STREAMS[("comm", dev.index)] = torch.cuda.Stream(dev)
+        nb = lib.am_evaluate_sharded_workspace_bytes(rc_arr, cc_arr, rank, world, d, int(nearest_k), s, m, flags)
+        if nb == 0:
+            raise ValueError(f"empty embedding set: {sum(ref_counts)} reference and {sum(cand_counts)} candidate rows over {world} ranks")
+        ws = coll.expose(torch.empty(nb, dtype=torch.uint8, device=dev))
+        out = torch.empty(EVAL_HEAD + s, dtype=torch.float64, device=dev)
+        status = lib.am_evaluate_sharded_f32(
+            _ptr(ref_local) if ref_counts[rank] else None, _ld(ref_local), _ptr(cand_local) if cand_counts[rank] else None,
+            _ld(cand_local), d, rc_arr, cc_arr, coll.byref(), flags, int(nearest_k), _ptr(idx_cand) if s else None,
+            _ptr(idx_ref) if s else None, s, m, float(1.0 / d if gamma is None else gamma), float(coef0), int(degree), _ptr(out),
+            _ptr(ws), nb, ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(side_stream.cuda_stream),
+            ctypes.c_void_p(comm_stream.cuda_stream if overlap else main.cuda_stream))
+        if getattr(coll, "error", None) is not None:
+            raise coll.error
+        _lib.check(status, "am_evaluate_sharded_f32")
+        for t in (ref_local, cand_local, ws):
+            t.record_stream(side_stream)
+            t.record_stream(comm_stream)
+        host = out.cpu()
+        torch.cuda.current_stream(dev).synchronize()
+        comm_stream.synchronize()
+    head = host[:EVAL_HEAD].tolist()
+    return head, (host[EVAL_HEAD:].numpy() if s else None)

@@ -277,6 +277,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--pairs", type=int, default=2000, help="--config e2e: audio pairs per side")
+    ap.add_argument("--c-entry", action="store_true",
+                    help="N > 1: every rank's step is ONE library call (am_evaluate_sharded_f32 with hooks over the process "
+                         "group) instead of the Python exchange schedule; same results")
     ap.add_argument("--bulk-communicator", action="store_true",
                     help="row gathers on a second RCCL communicator (distributed.enable_bulk_communicator; default: one)")
     args = ap.parse_args()
@@ -352,7 +355,8 @@ def main():
     shard_counts = ([shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0] for r in range(world)],) * 2
 
     def step():
-        return evaluate_sharded(ref_l, cand_l, metrics=("fad", "kd", "prdc"), nearest_k=k, shard_counts=shard_counts)
+        return evaluate_sharded(ref_l, cand_l, metrics=("fad", "kd", "prdc"), nearest_k=k, shard_counts=shard_counts,
+                                c_entry=args.c_entry and world > 1)
 
     # ---- the timed region: K plain steps, nothing else (no event brackets, no statistics kernels)
     for _ in range(args.warmup):
@@ -590,6 +594,9 @@ def main():
                        "inputs": ("numpy PCG64 seed %d: reference randn, candidate randn*1.05+0.05" % gi.BENCH_SEED) if args.data == "randn"
                                  else ("numpy PCG64 seed %d: unit-norm rows of randn+0.5 / randn+0.55 (CLAP-shaped)" % gi.BENCH_SEED),
                        "sharding": f"rows/{world}",
+                       "schedule": ("am_evaluate_sharded_f32 (one library call per rank, collectives as hooks)" if args.c_entry and world > 1
+                                    else "am_evaluate_f32 (one library call)" if world == 1
+                                    else "distributed.evaluate_sharded (Python exchange schedule over the split entry points)"),
                        "arithmetic": "PRDC: results are the exact f32 values (bit-identical to the f32-MFMA kernels); the tile kernels "
                                      "pre-filter on f16 MFMA with f32 accumulation where am_knn_path/am_prdc_path >= 2 and every "
                                      "undecided pair is re-evaluated with the exact f32 fmaf chain.  KD (subsets of >= 512 rows, "

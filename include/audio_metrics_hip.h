@@ -383,6 +383,44 @@ int am_evaluate_f32(const float* ref, int64_t n_ref, int64_t ld_ref, const float
                     const am_evaluate_side* given_cand, double* out, void* ws, size_t ws_bytes, am_stream_t stream,
                     am_stream_t side_stream);
 
+/* ---------------------------------------------------------------------------
+ * One call = one RANK's share of a row-sharded evaluate: the exchange schedule of
+ * audio-metrics_amd/distributed.py: evaluate_sharded behind the C ABI, for one-process-per-GPU hosts that are not Python.
+ * The reference has no multi-GPU metrics path (its only multi-GPU code spreads the embedder, util/gpu_parallel.py:79-118).
+ *
+ *   am_collectives   the two collectives of the schedule as hooks: the library links no collective library.  Both enqueue
+ *                    on the stream they are handed (ncclAllReduce / ncclAllGather semantics: stream-ordered, every rank
+ *                    calls them in the same order) and return 0 on success.  csrc/rccl/am_rccl.cpp builds them over an
+ *                    ncclComm_t (libaudio_metrics_rccl.so: am_rccl_collectives), the tests over torch.distributed.
+ *     all_reduce_sum(ctx, buf, count, dtype, stream)        in place; dtype AM_COLL_F64 or AM_COLL_I32
+ *     all_gather_v(ctx, send, recv, bytes_per_rank, stream) recv = the ranks' contributions in rank order, rank r's being
+ *                    bytes_per_rank[r] bytes (a HOST array of `world` entries, valid during the call only; zero allowed);
+ *                    send == recv + (bytes of the lower ranks): the call is always IN PLACE
+ *   Every rank passes its row shards (row-major f32, ld % 4 == 0, 16-byte aligned; a shard may be empty - NULL - as long as
+ *   each set has rows somewhere), the shard sizes of ALL ranks (host arrays [world], the same on every rank), the metrics
+ *   and, for the kernel distance, the two int64 [kd_subsets, kd_m] DEVICE index tables (the same on every rank:
+ *   am_kd_draw_indices).  Compute runs on `stream`, the collectives in issue order on `comm_stream` (fenced with events;
+ *   pass `stream` itself, or NULL, for the serial form), the Frechet solve on `side_stream`.
+ *   Results: the record of am_evaluate_f32 in `out` (device, 16 + kd_subsets doubles), identical on every rank.
+ *   Wide, large sets with rows on every rank take the partitioned symmetric k-NN sweep (am_knn_sym_eligible), everything
+ *   else the general kernel on the row shard and an all-gather of the radii.
+ * ------------------------------------------------------------------------- */
+#define AM_COLL_F64 0
+#define AM_COLL_I32 1
+typedef struct am_collectives {
+    void* ctx;
+    int rank, world;
+    int (*all_reduce_sum)(void* ctx, void* buf, int64_t count, int dtype, am_stream_t stream);
+    int (*all_gather_v)(void* ctx, const void* send, void* recv, const int64_t* bytes_per_rank, am_stream_t stream);
+} am_collectives;
+size_t am_evaluate_sharded_workspace_bytes(const int64_t* ref_counts, const int64_t* cand_counts, int rank, int world, int D,
+                                           int nearest_k, int kd_subsets, int kd_m, unsigned what);
+int am_evaluate_sharded_f32(const float* ref_local, int64_t ld_ref, const float* cand_local, int64_t ld_cand, int D,
+                            const int64_t* ref_counts, const int64_t* cand_counts, const am_collectives* coll, unsigned what,
+                            int nearest_k, const int64_t* idx_cand, const int64_t* idx_ref, int kd_subsets, int kd_m,
+                            double kd_gamma, double kd_coef0, int kd_degree, double* out, void* ws, size_t ws_bytes,
+                            am_stream_t stream, am_stream_t side_stream, am_stream_t comm_stream);
+
 /* ---- optional kernel clock (benchmark support; bench.py's roofline) --------------------------------
  * When enabled, the library brackets every launch of the two tile kernels with a hipEvent pair recorded on
  * the caller's stream, so a benchmark can report the duration of exactly that kernel (the figure

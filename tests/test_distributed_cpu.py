@@ -178,3 +178,56 @@ def test_global_stats_of_one_sharded_set():
         assert count == n
         np.testing.assert_allclose(mean, x.mean(0).numpy(), rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(cov, torch.cov(x.T).numpy(), rtol=1e-10, atol=1e-13)
+
+
+def _hooks_worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import ctypes
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from audio_metrics_amd.collectives import COLL_F64, COLL_I32, TorchCollectives
+    coll = TorchCollectives(dist.group.WORLD)
+    ws = coll.expose(torch.zeros(4096, dtype=torch.uint8))
+    base = ws.data_ptr()
+    # all_reduce_sum on an f64 and an i32 window of the exposed tensor, through the C function pointers of the struct
+    ws[256:256 + 40].view(torch.float64)[:] = torch.arange(5, dtype=torch.float64) + rank
+    ws[512:512 + 12].view(torch.int32)[:] = torch.tensor([1, 2, 3], dtype=torch.int32) * (rank + 1)
+    assert coll.struct.all_reduce_sum(None, base + 256, 5, COLL_F64, None) == 0
+    assert coll.struct.all_reduce_sum(None, base + 512, 3, COLL_I32, None) == 0
+    # all_gather_v, in place, unequal shares (rank r contributes 7 + 5 r bytes; the last rank nothing)
+    sizes = [7 + 5 * r for r in range(world - 1)] + [0]
+    offs = [sum(sizes[:r]) for r in range(world)]
+    ws[1024 + offs[rank]:1024 + offs[rank] + sizes[rank]] = rank + 10
+    arr = (ctypes.c_int64 * world)(*sizes)
+    assert coll.struct.all_gather_v(None, base + 1024 + offs[rank], base + 1024, arr, None) == 0
+    # a pointer outside every exposed tensor is an error code, not an exception through the C frames
+    assert coll.struct.all_reduce_sum(None, base + 4096, 4, COLL_F64, None) == 1 and coll.error is not None
+    out_q.put((rank, ws[256:296].view(torch.float64).tolist(), ws[512:524].view(torch.int32).tolist(),
+               ws[1024:1024 + sum(sizes)].tolist(), [name for name, _ in coll.calls]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collective_hooks_over_gloo():
+    """collectives.TorchCollectives - the am_collectives hooks am_evaluate_sharded_f32 is handed in this package - called
+    through their C function pointers on host tensors, three ranks over gloo (the GPU tests run the whole C entry point)."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hooks_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = [7 + 5 * r for r in range(world - 1)] + [0]
+    for rank, f64, i32, gathered, names in got:
+        assert f64 == [float(3 * i + 0 + 1 + 2) for i in range(5)]
+        assert i32 == [6, 12, 18]
+        assert gathered == [r + 10 for r in range(world) for _ in range(sizes[r])]
+        assert names == ["all_reduce_sum", "all_reduce_sum", "all_gather_v", "all_reduce_sum"]

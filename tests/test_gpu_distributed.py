@@ -210,7 +210,7 @@ def test_sharded_evaluate_takes_symmetric_path():
 
 
 @pytest.mark.parametrize("ranks,rows,dim,plain", [(2, 3000, 64, False), (2, 3000, 64, True), (2, 9000, 128, False),
-                                                  (8, 66000, 128, True)])
+                                                  (8, 66000, 128, True), (2, 9000, 128, "c-entry")])
 def test_bench_multi_rank_launch(ranks, rows, dim, plain):
     """bench.py launched the way the driver launches it for N=2 (torch.distributed.run, one JSON line from
     rank 0) - and `plain`: invoked as `python bench.py --gpus N` with no launcher (it then starts the ranks itself).  Both ranks share cuda:0 over gloo (bench.py's AM_BENCH_* test hooks); 9000x128 is eligible for the
@@ -223,6 +223,8 @@ def test_bench_multi_rank_launch(ranks, rows, dim, plain):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--steps", "1", "--warmup", "1", "--rows", str(rows), "--dim", str(dim), "--no-cpu-baseline"]
     env = dict(os.environ, AM_BENCH_DEVICE="0", AM_BENCH_BACKEND="gloo")
+    if plain == "c-entry":          # every rank's timed step = ONE library call (am_evaluate_sharded_f32), its collectives hooks over gloo
+        common = common + ["--c-entry"]
     if plain:
         # `python bench.py --gpus N` with no launcher around it: bench.py starts its own ranks in a child process and
         # passes rank 0's line and the exit code through
@@ -243,6 +245,7 @@ def test_bench_multi_rank_launch(ranks, rows, dim, plain):
     assert one.returncode == 0, one.stderr[-2000:]
     out1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert out2["n_gpus"] == ranks and out1["n_gpus"] == 1
+    assert ("am_evaluate_sharded_f32" in out2["config"]["schedule"]) == (plain == "c-entry"), out2["config"]["schedule"]
     assert out2["n_ranks_seen"] == ranks and out1["n_ranks_seen"] == 1      # what the process group connected, not what was asked for
     if rows >= 32768 and dim >= 128:
         assert out2["filter"]["knn_path"] == 3 and out2["filter"]["knn_fallback_rows"] == 0, out2["filter"]
