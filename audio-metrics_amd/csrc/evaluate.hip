@@ -440,13 +440,18 @@ extern "C" int am_evaluate_sharded_f32(const float* ref_local, int64_t ld_ref, c
         return gather_rows(s, L.full[s], L.ldf * (int64_t)sizeof(float), &ev_full[s]);
     };
     if (need_full) {
-        for (int s = 0; s < 2; ++s)
-            if (nl[s] > 0)
+        for (int s = 0; s < 2; ++s) {
+            if (nl[s] == 0) continue;
+            if (ld[s] == L.ldf)                                 // one contiguous copy (a pitched device-to-device copy of 100 000
+                AM_HIP_TRY(hipMemcpyAsync(L.full[s] + lo[s] * L.ldf, X[s], (size_t)nl[s] * L.ldf * sizeof(float),     // rows took 35 ms)
+                                          hipMemcpyDeviceToDevice, st));
+            else
                 AM_HIP_TRY(hipMemcpy2DAsync(L.full[s] + lo[s] * L.ldf, (size_t)L.ldf * sizeof(float), X[s], (size_t)ld[s] * sizeof(float),
                                             (size_t)D * sizeof(float), (size_t)nl[s], hipMemcpyDeviceToDevice, st));
+        }
         if (L.ldf != D)                                         // (padding columns of the gathered copies: never read as data)
             for (int s = 0; s < 2; ++s)
-                if (nl[s] > 0)
+                if (nl[s] > 0 && ld[s] != L.ldf)
                     AM_HIP_TRY(hipMemset2DAsync(L.full[s] + lo[s] * L.ldf + D, (size_t)L.ldf * sizeof(float), 0,
                                                 (size_t)(L.ldf - D) * sizeof(float), (size_t)nl[s], st));
         if ((rc = start_gather(0)) != AM_OK) return rc;

@@ -336,6 +336,7 @@ struct KnnFastEpilogue {
             }
             return;
         }
+        const float mthr = mirror ? 0.f : -INFINITY;        // the diagonal tile holds both directions itself: no margin reaches -inf
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             f32x4 yn[4], tq[4];
@@ -370,7 +371,7 @@ struct KnnFastEpilogue {
                 // Gate 1, one wave-uniform branch per accumulator tile (1024 pairs): nothing to look at.  (Round 2 evaluated
                 // the four group gates of every tile and kept their outcomes as values for two later loops: ~100 VALU
                 // instructions per accumulator tile of which ~50 were flag bookkeeping.)
-                if (!__any(tmin <= pl || (mirror && mmin <= 0.f))) continue;
+                if ((lanes_le(tmin, pl) | lanes_le(mmin, mthr)) == 0ull) continue;      // (lane masks on the scalar unit: see lanes_le)
 #ifdef AM_DEV_KNOBS
                 if constexpr (TBX == WIDE_TILE_ROWS) {
                     if (g_wide_dbg & 16) continue;              // timing experiment: fast path and gate only, no detail path
@@ -379,13 +380,13 @@ struct KnnFastEpilogue {
                 // Gate 2 per register group, then ONE pass over the group's four registers: test, ballot, slot, store.
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    if (!__any(tmin4[g4] <= pl || (mirror && marg4[g4] <= 0.f))) continue;
+                    if ((lanes_le(tmin4[g4], pl) | lanes_le(marg4[g4], mthr)) == 0ull) continue;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int reg = g4 * 4 + e;
                         const float u = fmaf(dsc, acc[mt][nt][reg], xn[nt] + yn[g4][e]);
                         const bool own = u <= pl, mir = mirror && u <= tq[g4][e];
-                        const unsigned long long sel = __ballot(own || mir);
+                        const unsigned long long sel = lanes_le(u, pl) | (mirror ? lanes_le(u, tq[g4][e]) : 0ull);
                         if (sel != 0ull) {                                                  // wave-uniform
                             const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(sel >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sel, 0u));
                             const int slot = wq + below;
@@ -408,7 +409,7 @@ struct KnnFastEpilogue {
 #ifdef AM_DEV_KNOBS
                 if (TBX == WIDE_TILE_ROWS && (g_wide_dbg & 64)) continue;                 // timing experiment: no lane-local lists
 #endif
-                if (__any(vmin < best[nt][KCAP - 1])) list_insert<KCAP>(best[nt], vmin);
+                if (lanes_lt(vmin, best[nt][KCAP - 1]) != 0ull) list_insert<KCAP>(best[nt], vmin);
             }
         }
     }

@@ -41,6 +41,7 @@ struct CrossWideEpilogue {
     float dsc, idsc;
     int64_t prow[NT];
     float xn[NT], xs[NT], xsn[NT], thi[NT], tlo[NT], e2[NT], m[NT];   // xsn (ACC_INIT): xs while the row still lacks its witness, +inf after
+    float athr[NT];             // (not ACC_INIT) what an "any" margin is compared with: 0 while the row lacks its witness, -inf after
     bool rowok[NT], anyf[NT], covf[NT];
     float aux_n, aux_hi;
     const Lane& L;
@@ -214,9 +215,11 @@ struct CrossWideEpilogue {
                 // coverage, row minimum) has a candidate in 0.2 % of the 32 x 32 tiles of the bench problem, the "any"
                 // direction of the rows that still lack a witness in 16 % - the other tiles used to pay four group gates each.
                 {
-                    bool hit = rowok[nt] && tmin <= prow_thr;
-                    if constexpr (NEED_ANY) hit = hit || (rowok[nt] && !anyf[nt] && fminf(fminf(marg4[0], marg4[1]), fminf(marg4[2], marg4[3])) <= 0.f);
-                    if (!__any(hit)) continue;
+                    // (lane masks on the scalar unit; a row past the end or with its witness fails through its thresholds:
+                    // thi, tlo, m = -inf, athr = -inf - see the ACC_INIT form above)
+                    unsigned long long hit = lanes_le(tmin, prow_thr);
+                    if constexpr (NEED_ANY) hit |= lanes_le(fminf(fminf(marg4[0], marg4[1]), fminf(marg4[2], marg4[3])), athr[nt]);
+                    if (hit == 0ull) continue;
 #ifdef AM_DEV_KNOBS
                     if (g_wide_dbg & 16) continue;                 // timing experiment: fast path and gate only, no detail path
 #endif
@@ -227,9 +230,9 @@ struct CrossWideEpilogue {
                 const float* alo = a + 2 * WTB + mt * 32;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const bool row_hit = __any(rowok[nt] && tmin4[g4] <= prow_thr);
+                    const bool row_hit = lanes_le(tmin4[g4], prow_thr) != 0ull;
                     bool any_hit = false;
-                    if constexpr (NEED_ANY) any_hit = __any(rowok[nt] && !anyf[nt] && marg4[g4] <= 0.f);
+                    if constexpr (NEED_ANY) any_hit = lanes_le(marg4[g4], athr[nt]) != 0ull;
 #ifdef AM_DEV_KNOBS
                     if (g_wide_dbg & 8) any_hit = false;               // timing experiment: the gate's cost without its loop
 #endif
@@ -241,8 +244,8 @@ struct CrossWideEpilogue {
                         const int64_t j = jbase + mt * 32 + g4 * 8 + e;
                         bool sure = false, want = false;
                         if (row_hit) {
-                            sure = rowok[nt] && u < tlo[nt];
-                            const unsigned long long mask = __ballot(sure);
+                            sure = u < tlo[nt];
+                            const unsigned long long mask = lanes_lt(u, tlo[nt]);
                             if (mask != 0ull && L.lane == 0) {               // lanes 0-31: column j, lanes 32-63: column j + 4
                                 const int lo = __popcll(mask & 0xffffffffull);
                                 const int hi = __popcll(mask >> 32);
@@ -250,13 +253,17 @@ struct CrossWideEpilogue {
                                 if (hi) atomicAdd(col_count + j - L.h * 4 + 4, hi);
                             }
                             covf[nt] = covf[nt] || sure;
-                            want = rowok[nt] && !sure && u <= thi[nt];
-                            if constexpr (WANT_MIN) want = want || (rowok[nt] && u <= m[nt] + e2[nt]);
+                            want = !sure && u <= thi[nt];
+                            if constexpr (WANT_MIN) want = want || u <= m[nt] + e2[nt];
                         }
                         if constexpr (NEED_ANY) {
-                            if (rowok[nt] && !anyf[nt] && u <= th[g4][e]) {
-                                if (u < alo[g4 * 8 + e]) anyf[nt] = true;       // certain witness
-                                else want = true;                               // ambiguous "any"
+                            if (!anyf[nt] && u <= th[g4][e]) {
+                                if (u < alo[g4 * 8 + e]) {                      // certain witness
+                                    anyf[nt] = true;
+                                    athr[nt] = -INFINITY;
+                                } else {
+                                    want = true;                                // ambiguous "any"
+                                }
                             }
                         }
                         if (want) push(prow[nt], (unsigned)j | (sure ? FAST_COUNTED : 0u));
@@ -369,11 +376,12 @@ cross_wide_body(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const flo
         epi.thi[nt] = ok ? rthr[i] + e : -INFINITY;
         epi.tlo[nt] = ok ? rthr[i] - e : -INFINITY;
         epi.e2[nt] = 2.f * e;
-        // (ACC_INIT: a row past the end takes part in no test through its thresholds alone - thi, tlo = -inf above, the running
-        // minimum -inf so that m + e2 is, and no witness wanted)
-        epi.m[nt] = (WANT_MIN && ok) ? __uint_as_float(rmin_approx[i]) : (Lane::ACC_INIT ? -INFINITY : INFINITY);
+        // (a row past the end takes part in no test through its thresholds alone - thi, tlo = -inf above, the running minimum
+        // -inf so that m + e2 is, and no witness wanted)
+        epi.m[nt] = (WANT_MIN && ok) ? __uint_as_float(rmin_approx[i]) : -INFINITY;
         epi.anyf[nt] = ok ? (row_any[i] != 0u) : true;
         epi.xsn[nt] = epi.anyf[nt] ? INFINITY : epi.xs[nt];
+        epi.athr[nt] = epi.anyf[nt] ? -INFINITY : 0.f;
         epi.covf[nt] = false;
     }
 #ifdef AM_DEV_KNOBS

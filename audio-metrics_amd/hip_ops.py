@@ -853,7 +853,7 @@ def evaluate_sharded_c(ref_local, cand_local, ref_counts, cand_counts, what, col
         nb = lib.am_evaluate_sharded_workspace_bytes(rc_arr, cc_arr, rank, world, d, int(nearest_k), s, m, flags)
         if nb == 0:
             raise ValueError(f"empty embedding set: {sum(ref_counts)} reference and {sum(cand_counts)} candidate rows over {world} ranks")
-        ws = coll.expose(torch.empty(nb, dtype=torch.uint8, device=dev))
+        ws = coll.expose(_eval_workspace(nb, dev))            # (kept per device and stream, like the fused call's)
         out = torch.empty(EVAL_HEAD + s, dtype=torch.float64, device=dev)
         status = lib.am_evaluate_sharded_f32(
             _ptr(ref_local) if ref_counts[rank] else None, _ld(ref_local), _ptr(cand_local) if cand_counts[rank] else None,
@@ -864,11 +864,9 @@ def evaluate_sharded_c(ref_local, cand_local, ref_counts, cand_counts, what, col
         if getattr(coll, "error", None) is not None:
             raise coll.error
         _lib.check(status, "am_evaluate_sharded_f32")
-        for t in (ref_local, cand_local, ws):
+        for t in (ref_local, cand_local):
             t.record_stream(side_stream)
             t.record_stream(comm_stream)
-        host = out.cpu()
-        torch.cuda.current_stream(dev).synchronize()
-        comm_stream.synchronize()
+        host = out.cpu()                                     # the one read-back: the pack kernel behind it waits for all three streams' work
     head = host[:EVAL_HEAD].tolist()
     return head, (host[EVAL_HEAD:].numpy() if s else None)
