@@ -722,8 +722,14 @@ static CrossFastPlan plan_cross_fast(int64_t Nr, int64_t Nc) {
         p.nchunks = (int)want;
         p.blocks = wide_grouped_blocks(rbw, p.nchunks, p.grp_rows);
     }
-    static const int stride = env_int("AM_FAST_PRE_STRIDE", 16);
-    p.qstride = stride;
+    // Sampled "any" pre-pass: every stride-th candidate tile.  16 until round 5; since the main pass's hit path got cheap (scalar
+    // gates, accumulator start values) a witness found there costs little, and what the pre-pass is still good for - taking
+    // the rows with MANY witnesses out of the "any" direction early - needs about six sampled tiles: at 100 000 x 512 stride
+    // 16 / 32 / 64 / 128 / no pre-pass give 9.88 / 9.75 / 9.68 / 9.75 / 9.96 ms per call on the bench sets and 10.72 / 10.48 /
+    // 10.47 / 10.32 / 10.29 ms on CLAP-shaped ones with k = 10 (profiles/r5/ab_pre_stride.txt); narrow rows are flat.
+    static const int stride_env = env_int("AM_FAST_PRE_STRIDE", 0);
+    p.qstride = stride_env > 0 ? stride_env
+                               : (p.wide ? (int)std::min<int64_t>(std::max<int64_t>(ceil_div(Nc, WIDE_TILE_ROWS) / 6, 16), 64) : 16);
     const int64_t sample_tiles = ceil_div(ceil_div(Nc, TB), p.qstride);
     p.pre_chunks = (int)std::min<int64_t>(sample_tiles, 8);
     static const int qcap = std::min(env_int("AM_FAST_QCAP", 2048), 2048);       // cross_verify_kernel: <= 256 * 8
