@@ -1002,8 +1002,13 @@ static KnnPlan plan_knn(int64_t N, int64_t M, int D, int k, bool self, bool part
     if (stride_env > 0) stride = stride_env;
     // (A rank of a PARTITIONED run sees an n-th of each row's columns: the bounds its own sweep publishes tighten little, the
     // sampled bound carries the filter - with stride 48 a rank's eighth of the sweep queued 2.4x the pairs, 1.34 -> 1.56 ms.)
-    else if (self && !partitioned && knn_fast_enabled(N, D))
-        stride = (int)std::min<int64_t>(48, std::max<int64_t>(16, ceil_div(N, 256) / 8));
+    // Narrow rows: the pre-pass's matrix work shrinks with D, what a looser bound costs the sweep's epilogue does not - a denser
+    // sample pays (100 000 rows, stride 16 / 24 / 32 / 48: D = 64 2.34 / 2.38 / 2.42 / 2.45 ms, D = 128 2.93 / 2.91 / 2.93 / 2.97,
+    // D = 256 4.08 / 4.02 / 4.03 / 4.07, D = 384 5.16 / 5.04 / 5.03 / 5.02; profiles/r5/ab_knn_stride2.txt).
+    else if (self && !partitioned && knn_fast_enabled(N, D)) {
+        const int64_t cap = D >= 384 ? 48 : D >= 192 ? 32 : D >= 96 ? 24 : 16;
+        stride = (int)std::min<int64_t>(cap, std::max<int64_t>(16, ceil_div(N, 256) / 8));
+    }
     const int pre_windows = 0;
     KnnPlan p;
     p.tile_rows = TB;
