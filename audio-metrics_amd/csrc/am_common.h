@@ -75,4 +75,15 @@ struct Carver {
     bool ok() const { return base != nullptr && off <= size; }
 };
 
+// ---- float64 rows through the f16 filter (round 5): pairwise.hip finds each row's candidates with the float32 path's filter
+// sweep on a rounded copy and evaluates / selects them in f64; pairwise_f64.hip supplies the general f64 kernels behind a
+// device flag for the calls the filter gives up on
+bool knn64_filter_eligible(int64_t N, int D, int k);
+size_t knn64_filter_workspace(int64_t N, int D, int k);
+int knn64_filter(const double* X, int64_t N, int64_t ld, int D, int k, double* out_r, void* ws, size_t ws_bytes, hipStream_t st);
+size_t knn64_self_workspace(int64_t N, int k);
+int knn64_self_gated(const double* X, int64_t N, int64_t ld, int D, int k, double* out_r, void* ws, size_t ws_bytes, const int* run_flag,
+                     hipStream_t st);
+
+
 }  // namespace am

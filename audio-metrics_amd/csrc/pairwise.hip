@@ -1335,6 +1335,73 @@ static int knn_radii_impl(const float* X, int64_t N, int64_t ldx, const float* Y
     }
 }
 
+// ---- float64 rows through the f16 filter sweep (declared in am_common.h; called by am_knn_radii_f64) ---------------------------
+namespace am {
+
+__global__ void __launch_bounds__(256) cast64_kernel(const double* __restrict__ X, int64_t N, int64_t ld, int D, float* __restrict__ out,
+                                                     int64_t ldo) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = idx / ldo;
+    const int col = (int)(idx % ldo);
+    if (row < N) out[row * ldo + col] = col < D ? (float)X[row * ld + col] : 0.f;
+}
+
+// the shapes whose float32 twin takes the filter sweep on the 256-row engine (k <= 10) - and rows that survive the rounding:
+// |x| up to ~1e38 and down to the f32 subnormals is checked on the device (unscalable operands raise the fallback flag)
+bool knn64_filter_eligible(int64_t N, int D, int k) {
+    if (k < 1 || k > 10 || N < 2 || D < 1 || (int64_t)k + 1 > N) return false;
+    if (!knn_fast_enabled(N, D)) return false;
+    const KnnPlan p = plan_knn(N, N, D, k, true);
+    return p.sym && p.tile_rows == WIDE_TILE_ROWS;
+}
+
+struct Knn64Layout {
+    float* x32 = nullptr;
+    int *pair_start = nullptr, *pair_n = nullptr;
+    void *ws32 = nullptr, *ws64 = nullptr;
+    size_t ws32_bytes = 0, ws64_bytes = 0, total = 0;
+    int64_t ld32 = 0;
+};
+static bool knn64_layout(Carver& c, int64_t N, int D, int k, Knn64Layout& L) {
+    L.ld32 = (int64_t)round_up((size_t)D, (size_t)4);
+    L.x32 = c.take<float>((size_t)N * L.ld32);
+    L.pair_start = c.take<int>((size_t)N);
+    L.pair_n = c.take<int>((size_t)N);
+    L.ws32_bytes = round_up(am_knn_workspace_bytes(N, N, D, k), (size_t)256);
+    L.ws32 = c.take<char>(L.ws32_bytes);
+    L.ws64_bytes = round_up(knn64_self_workspace(N, k), (size_t)256);
+    L.ws64 = c.take<char>(L.ws64_bytes);
+    L.total = c.off;
+    return c.ok();
+}
+size_t knn64_filter_workspace(int64_t N, int D, int k) {
+    Carver c(nullptr, 0);
+    Knn64Layout L;
+    knn64_layout(c, N, D, k, L);
+    return L.total;
+}
+
+int knn64_filter(const double* X, int64_t N, int64_t ld, int D, int k, double* out_r, void* ws, size_t ws_bytes, hipStream_t st) {
+    Carver c(ws, ws_bytes);
+    Knn64Layout L;
+    AM_REQUIRE(knn64_layout(c, N, D, k, L), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", L.total, ws_bytes);
+    hipLaunchKernelGGL(cast64_kernel, dim3((unsigned)ceil_div(N * L.ld32, 256)), dim3(256), 0, st, X, N, ld, D, L.x32, L.ld32);
+    AM_LAUNCH_CHECK();
+    int rc;
+    const KnnPlan p = plan_knn(N, N, D, k, true);
+    Carver c32(L.ws32, L.ws32_bytes);
+    KnnBuffers b;
+    carve_knn(c32, N, N, p, b);
+    KnnFastBuffers fb = carve_knn_fast(c32, N, D, p);
+    AM_REQUIRE(c32.ok(), AM_ERR_WORKSPACE, "float32 part of the workspace too small: need %zu bytes, have %zu", c32.off, L.ws32_bytes);
+    if ((rc = norms_of(nullptr, L.x32, N, L.ld32, D, b.xn, st)) != AM_OK) return rc;
+    Knn64Hook h{X, ld, out_r, L.pair_start, L.pair_n, L.ws64, L.ws64_bytes, k};
+    if (p.kcap == 6) return run_knn_fast<6>(L.x32, N, L.ld32, D, k + 1, p, b, fb, nullptr, st, 0, 1, nullptr, nullptr, nullptr, &h);
+    return run_knn_fast<11>(L.x32, N, L.ld32, D, k + 1, p, b, fb, nullptr, st, 0, 1, nullptr, nullptr, nullptr, &h);
+}
+
+}  // namespace am
+
 extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const float* Y, int64_t M, int64_t ldy,
                                 int D, int k, float* out_r, void* ws, size_t ws_bytes, am_stream_t stream) {
     return knn_radii_impl(X, N, ldx, Y, M, ldy, D, k, out_r, ws, ws_bytes, stream, nullptr);

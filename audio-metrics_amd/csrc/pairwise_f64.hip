@@ -166,8 +166,10 @@ __global__ void threshold64_kernel(const double* __restrict__ R, int64_t n, doub
 template <int KCAP>
 __global__ void __launch_bounds__(FTHREADS) knn64_kernel(const double* __restrict__ X, int64_t N, int64_t ldx, const double* __restrict__ xn,
                                                          const double* __restrict__ Y, int64_t M, int64_t ldy, const double* __restrict__ yn,
-                                                         int D, int k1, int nchunks, double* __restrict__ partial) {
+                                                         int D, int k1, int nchunks, double* __restrict__ partial,
+                                                         const int* __restrict__ run_flag) {
     extern __shared__ __attribute__((aligned(16))) double lds64[];
+    if (run_flag != nullptr && *run_flag == 0) return;               // (behind the f16 filter route: only when that gave up)
     double* qnorm = lds64 + FENGINE_DOUBLES;                          // [64] norms of the Q tile
     const FLane L;
     const int64_t pb = blockIdx.x / nchunks;
@@ -220,9 +222,10 @@ __global__ void __launch_bounds__(FTHREADS) knn64_kernel(const double* __restric
 }
 
 template <int KCAP>
-__global__ void __launch_bounds__(256) knn64_merge_kernel(const double* __restrict__ partial, int64_t N, int nchunks, double* __restrict__ out_r) {
+__global__ void __launch_bounds__(256) knn64_merge_kernel(const double* __restrict__ partial, int64_t N, int nchunks, double* __restrict__ out_r,
+                                                          const int* __restrict__ run_flag) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
+    if (i >= N || (run_flag != nullptr && *run_flag == 0)) return;
     double m[KCAP];
 #pragma unroll
     for (int s = 0; s < KCAP; ++s) m[s] = partial[i * KCAP + s];
@@ -501,15 +504,40 @@ static Knn64Plan plan_knn64(int64_t N, int64_t M, int k) {
 
 template <int KCAP>
 static int launch_knn64(const double* X, int64_t N, int64_t ldx, const double* xn, const double* Y, int64_t M, int64_t ldy, const double* yn,
-                        int D, int k1, int nchunks, double* partial, double* out_r, hipStream_t st) {
+                        int D, int k1, int nchunks, double* partial, double* out_r, hipStream_t st, const int* run_flag = nullptr) {
     const size_t lds = lds_bytes_knn(KCAP);
     AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn64_kernel<KCAP>), (int)lds));
     hipLaunchKernelGGL(knn64_kernel<KCAP>, dim3((unsigned)(ceil_div(N, FT) * nchunks)), dim3(FTHREADS), lds, st, X, N, ldx, xn, Y, M, ldy, yn,
-                       D, k1, nchunks, partial);
+                       D, k1, nchunks, partial, run_flag);
     AM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn64_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, partial, N, nchunks, out_r);
+    hipLaunchKernelGGL(knn64_merge_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, partial, N, nchunks, out_r, run_flag);
     AM_LAUNCH_CHECK();
     return AM_OK;
+}
+
+// the general f64 kernels of a set against itself, launched behind a device flag (knn64_filter in pairwise.hip: the f16
+// filter route's fallback - they return at once unless *run_flag != 0); k + 1 <= 32
+size_t knn64_self_workspace(int64_t N, int k) {
+    const Knn64Plan p = plan_knn64(N, N, k);
+    Carver c(nullptr, 0);
+    c.take<double>((size_t)N);
+    c.take<double>((size_t)p.nchunks * N * p.kcap);
+    return c.off;
+}
+int knn64_self_gated(const double* X, int64_t N, int64_t ld, int D, int k, double* out_r, void* ws, size_t ws_bytes, const int* run_flag,
+                     hipStream_t st) {
+    const Knn64Plan p = plan_knn64(N, N, k);
+    Carver c(ws, ws_bytes);
+    double* xn = c.take<double>((size_t)N);
+    double* scratch = c.take<double>((size_t)p.nchunks * N * p.kcap);
+    AM_REQUIRE(c.ok() && !p.select, AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
+    hipLaunchKernelGGL(row_sqnorm64_kernel, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, st, X, N, ld, D, xn);
+    AM_LAUNCH_CHECK();
+    switch (p.kcap) {
+        case 8: return launch_knn64<8>(X, N, ld, xn, X, N, ld, xn, D, k + 1, p.nchunks, scratch, out_r, st, run_flag);
+        case 16: return launch_knn64<16>(X, N, ld, xn, X, N, ld, xn, D, k + 1, p.nchunks, scratch, out_r, st, run_flag);
+        default: return launch_knn64<32>(X, N, ld, xn, X, N, ld, xn, D, k + 1, p.nchunks, scratch, out_r, st, run_flag);
+    }
 }
 
 }  // namespace am
@@ -517,7 +545,6 @@ static int launch_knn64(const double* X, int64_t N, int64_t ldx, const double* x
 using namespace am;
 
 extern "C" size_t am_knn_f64_workspace_bytes(int64_t N, int64_t M, int D, int k) {
-    (void)D;
     if (N < 1 || M < 1 || k < 1) return 0;
     const Knn64Plan p = plan_knn64(N, M, k);
     Carver c(nullptr, 0);
@@ -525,7 +552,8 @@ extern "C" size_t am_knn_f64_workspace_bytes(int64_t N, int64_t M, int D, int k)
     c.take<double>((size_t)M);
     if (p.select) c.take<double>((size_t)p.block_rows * M);
     else c.take<double>((size_t)p.nchunks * N * p.kcap);
-    return c.off;
+    // (a set against itself may take the f16 filter route: sized for whichever is larger)
+    return N == M && knn64_filter_eligible(N, D, k) ? std::max(c.off, knn64_filter_workspace(N, D, k)) : c.off;
 }
 
 extern "C" int am_knn_radii_f64(const double* X, int64_t N, int64_t ldx, const double* Y, int64_t M, int64_t ldy, int D, int k,
@@ -536,6 +564,10 @@ extern "C" int am_knn_radii_f64(const double* X, int64_t N, int64_t ldx, const d
     AM_REQUIRE(k >= 1 && (int64_t)k + 1 <= M, AM_ERR_BAD_SHAPE, "nearest_k=%d needs 1 <= k and k + 1 <= %lld rows (torch.kthvalue would raise)", k,
                (long long)M);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // a large set against itself: candidates from the f16 filter sweep of the float32 path, their distances and the selection
+    // in f64 (pairwise.hip: knn64_filter) - where the caller's workspace holds it
+    if (X == Y && N == M && ldx == ldy && knn64_filter_eligible(N, D, k) && ws_bytes >= knn64_filter_workspace(N, D, k))
+        return knn64_filter(X, N, ldx, D, k, out_r, ws, ws_bytes, st);
     const Knn64Plan p = plan_knn64(N, M, k);
     Carver c(ws, ws_bytes);
     double* xn = c.take<double>((size_t)N);

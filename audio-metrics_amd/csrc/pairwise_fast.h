@@ -1103,7 +1103,8 @@ __global__ void __launch_bounds__(256) knn_fast_prune_kernel(const float* __rest
                                                              const float* __restrict__ xnorm, const unsigned* __restrict__ maxn,
                                                              uint2* __restrict__ pairs, float* __restrict__ pair_val, int pair_cap,
                                                              int* __restrict__ pair_count, int* __restrict__ cnt2, int partitioned,
-                                                             float fc, int* __restrict__ gate) {
+                                                             float fc, int* __restrict__ gate, int* __restrict__ pair_start = nullptr,
+                                                             int* __restrict__ pair_n = nullptr) {
     if (gate != nullptr && gate[0] != 0) return;          // (gate: data-dependent fallback, see knn_fast_predict_kernel)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -1145,6 +1146,10 @@ __global__ void __launch_bounds__(256) knn_fast_prune_kernel(const float* __rest
     base = __shfl(base, 63);
     if (i >= N) return;
     int at = base + incl - ns;
+    if (pair_start != nullptr) {                          // (float64 route: where this row's pairs lie, -1 = no list)
+        pair_start[i] = (bad || at + ns > pair_cap) ? -1 : at;
+        pair_n[i] = ns;
+    }
     if (bad || at + ns > pair_cap) {                      // overflow on the way here, or the pair list is full: -> exact fix-up
         cnt2[i] = cap + 1;
         // a range that straddles the end of the list is not written: mark its slots below the end as holes
@@ -1301,6 +1306,88 @@ static KnnFixup carve_knn_fixup(Carver& c, int64_t N, int D, int kcap) {
 
 // radii of the rows in ov_list (a device-side count): one row at a time below KNN_FIX_BATCH_FROM rows, through the gathered
 // copy from there on (rows past the copy's capacity: one at a time again - the callers keep the list below it)
+// ---- float64 rows (round 5): the candidates of the f16 filter sweep, evaluated and selected in f64 --------------------------
+// The sweep, the scatter and the prune step run on a float32-rounded copy of the rows exactly as for float32 sets; their
+// product is, per row, the list of partners whose squared distance can be among the row's k + 1 smallest.  That statement is
+// about the TRUE distances of the float64 rows as well: the f16 value a of a pair differs from the real-number distance of the
+// rounded rows by at most fast_c (|x|^2 + G) (the derivation above bounds exactly that, the f32 chain's own error is a term of
+// it), and rounding the rows to float32 first moves a distance by at most 2^-21 (|x|^2 + |y|^2) - run_knn_fast adds 2^-19 to
+// fast_c for this route.  One wave per row then evaluates the row's pairs in f64, sum of squared differences (no norms, exact
+// zero for the row itself), and takes the (k+1)-th smallest by repeated extraction.  A row without a usable list (overflow on
+// the way, a block of identical rows taken out of the sweep, operands that cannot be scaled) raises gate[1]: the general f64
+// kernels, launched behind it, then compute the whole call (pairwise_f64.hip: knn64_self_gated).
+struct Knn64Hook {
+    const double* X;
+    int64_t ld;
+    double* out_r;
+    int *pair_start, *pair_n;       // [N] each
+    void* gen_ws;                   // workspace of the gated general kernels
+    size_t gen_ws_bytes;
+    int k;
+};
+constexpr int KNN64_PER_LANE = 12;                       // 64 x 12 >= the candidate slots of a row (64 (k + 1), k <= 10)
+
+__global__ void __launch_bounds__(256) knn_fast_select64_kernel(const double* __restrict__ X, int64_t ld, int D,
+                                                                const uint2* __restrict__ pairs, const int* __restrict__ pair_start,
+                                                                const int* __restrict__ pair_n, int64_t N, int k1,
+                                                                const unsigned* __restrict__ maxn, double* __restrict__ out_r,
+                                                                int* __restrict__ gate) {
+    if (*reinterpret_cast<volatile int*>(gate + 1) != 0) return;     // the general kernels take the call anyway
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int start = pair_start[row], n = pair_n[row];
+    if (start < 0 || n < k1 || n > 64 * KNN64_PER_LANE || !half_scale_ok(maxn[2])) {
+        if (lane == 0) atomicOr(gate + 1, 1);
+        return;
+    }
+    const double* xi = X + row * ld;
+    double v[KNN64_PER_LANE];
+#pragma unroll
+    for (int q = 0; q < KNN64_PER_LANE; ++q) {
+        v[q] = __builtin_inf();
+        const int p = lane + 64 * q;
+        if (p < n) {
+            const double* xj = X + (int64_t)pairs[start + p].y * ld;
+            double sum = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double t = xi[d] - xj[d];
+                sum = fma(t, t, sum);
+            }
+            v[q] = sum == sum ? sum : __builtin_inf();           // (a NaN distance is nobody's neighbour: clamp0)
+        }
+    }
+    double kth = __builtin_inf();
+    for (int r = 0; r < k1; ++r) {
+        double m = v[0];
+        int mq = 0;
+#pragma unroll
+        for (int q = 1; q < KNN64_PER_LANE; ++q)
+            if (v[q] < m) {
+                m = v[q];
+                mq = q;
+            }
+        double wm = m;
+        int wl = lane;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double om = __shfl_xor(wm, off);
+            const int ol = __shfl_xor(wl, off);
+            if (om < wm || (om == wm && ol < wl)) {
+                wm = om;
+                wl = ol;
+            }
+        }
+        kth = wm;
+        if (lane == wl) {
+#pragma unroll
+            for (int q = 0; q < KNN64_PER_LANE; ++q)
+                if (q == mq) v[q] = __builtin_inf();
+        }
+    }
+    if (lane == 0) out_r[row] = __dsqrt_rn(kth);
+}
+
 template <int KCAP>
 static int run_knn_fixup(const float* X, int64_t N, int64_t ld, const float* xn, int D, int k1, const int* ov_list, const int* ov_count,
                          const KnnFixup& x, float* out_r, hipStream_t st) {
@@ -1476,8 +1563,11 @@ static int wide_sample_chunks(int64_t row_blocks, int64_t samples) {
 template <int KCAP>
 static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, const KnnPlan& p, const KnnBuffers& b,
                         const KnnFastBuffers& f, float* out_r, hipStream_t st, int part = 0, int nparts = 1,
-                        const float* bounds_in = nullptr, float* out_lists = nullptr, const PreparedSet* prep = nullptr) {
+                        const float* bounds_in = nullptr, float* out_lists = nullptr, const PreparedSet* prep = nullptr,
+                        const Knn64Hook* h64 = nullptr) {
     int rc;
+    // (float64 route: X is the float32-rounded copy of h64->X; the rounding is priced into the bound, see Knn64Hook)
+    const float fc = h64 != nullptr ? fast_c(D) + 1.9073486328125e-06f : fast_c(D);
     const int64_t ldh = half_ld(D) / 2;                              // row stride of the f16 copy in f32 words
     const int Dh = (int)ldh;
     const float* Xb = reinterpret_cast<const float*>(prep != nullptr ? prep->half : f.xb);
@@ -1499,7 +1589,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     // 1) filter bounds for every row from a sampled f16 pass of the general kernel (here a row's OWN entries are
     //    queued too, so - unlike in the exact symmetric kernel - every row needs a bound from the start)
     if (bounds_in != nullptr) {
-        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, bounds_in, thr, b.xn, N, maxn, fast_c(D));
+        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, bounds_in, thr, b.xn, N, maxn, fc);
         AM_LAUNCH_CHECK();
     } else {
         int sample_chunks = p.pre_chunks;
@@ -1516,10 +1606,10 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
                            k1, 1, thr, static_cast<const int*>(nullptr));
         if (gate != nullptr) {                           // check A: can the f16 values separate the rows' neighbours at all?
             hipLaunchKernelGGL(knn_fast_predict_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.partial, N,
-                               sample_chunks, k1, b.xn, maxn, fast_c(D), gate, f.flat_rows);
+                               sample_chunks, k1, b.xn, maxn, fc, gate, f.flat_rows);
             hipLaunchKernelGGL(knn_fast_decide_kernel, dim3(1), dim3(64), 0, st, gate, N, k1, 0, f.pair_count, maxn, b.ov_count);
         }
-        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, thr, thr, b.xn, N, maxn, 2.f * fast_c(D));
+        hipLaunchKernelGGL(knn_fast_bound_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, thr, thr, b.xn, N, maxn, 2.f * fc);
         AM_LAUNCH_CHECK();
     }
     AM_HIP_TRY(hipMemsetAsync(b.cnt, 0, (size_t)(N + 1) * sizeof(int), st));
@@ -1560,13 +1650,13 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     if (p.tile_rows == WIDE_TILE_ROWS) {
         const auto launch_sweep = wide_stationary(Dh) ? &launch_knn_pstat : &launch_knn_wide;
         if ((rc = launch_sweep(KCAP, nwg, Xb, N, ldh, b.xn, thr, Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt,
-                                  p.cap, b.wgq, f.wgv, qcap, b.wgq_count, part, nparts, fast_c(D), f.ovq, f.ovv, f.ovn, ovcap,
+                                  p.cap, b.wgq, f.wgv, qcap, b.wgq_count, part, nparts, fc, f.ovq, f.ovv, f.ovn, ovcap,
                                   skip_sweep, region_counter, st)) != AM_OK)
             return rc;
     } else {
         hipLaunchKernelGGL(knn_fast_kernel<KCAP>, dim3(nwg), dim3(ENGINE_THREADS), PAIRWISE_LDS_BYTES + 16, st, Xb, N, ldh, b.xn,
                            thr, Dh, p.win_tiles, p.nwin, p.per_win, k1, maxn, b.partial, b.cnt, p.cap, b.wgq, f.wgv, qcap,
-                           b.wgq_count, part, nparts, fast_c(D), f.ovq, f.ovv, f.ovn, ovcap, skip_sweep, region_counter);
+                           b.wgq_count, part, nparts, fc, f.ovq, f.ovv, f.ovn, ovcap, skip_sweep, region_counter);
     }
     clock_end(AM_KERNEL_KNN, st);
     AM_LAUNCH_CHECK();
@@ -1580,10 +1670,30 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     const int64_t pair_cap64 = std::min<int64_t>((int64_t)nwg * p.qcap, (int64_t)1 << 30);   // (the pair list reuses the region memory)
     const int pair_cap = (int)pair_cap64;
     hipLaunchKernelGGL(knn_fast_prune_kernel<KCAP>, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, b.cand, f.fidx, b.cnt, p.cap,
-                       N, k1, b.xn, maxn, b.wgq, f.wgv, pair_cap, f.pair_count, f.cnt2, out_lists != nullptr ? 1 : 0, fast_c(D), gate);
+                       N, k1, b.xn, maxn, b.wgq, f.wgv, pair_cap, f.pair_count, f.cnt2, out_lists != nullptr ? 1 : 0, fc, gate,
+                       h64 != nullptr ? h64->pair_start : nullptr, h64 != nullptr ? h64->pair_n : nullptr);
     if (gate != nullptr)                                 // check B: did the prune step leave a verifiable amount of work?
         hipLaunchKernelGGL(knn_fast_decide_kernel, dim3(1), dim3(64), 0, st, gate, N, k1, 1, f.pair_count, maxn, b.ov_count);
     AM_LAUNCH_CHECK();
+    if (h64 != nullptr) {
+        AM_REQUIRE(gate != nullptr && out_lists == nullptr, AM_ERR_BAD_ARG, "the float64 route is the single-GPU form");
+        clock_begin(AM_KERNEL_KNN_VERIFY, st);
+        hipLaunchKernelGGL(knn_fast_select64_kernel, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, st, h64->X, h64->ld, D, b.wgq,
+                           h64->pair_start, h64->pair_n, N, k1, maxn, h64->out_r, gate);
+        clock_end(AM_KERNEL_KNN_VERIFY, st);
+        AM_LAUNCH_CHECK();
+        // the general f64 kernels behind the route: they return at once unless check A / B or a row without a list gave up
+        if ((rc = knn64_self_gated(h64->X, N, h64->ld, D, h64->k, h64->out_r, h64->gen_ws, h64->gen_ws_bytes, gate + 1, st)) != AM_OK) return rc;
+        hipLaunchKernelGGL(knn_fast_decide_kernel, dim3(1), dim3(64), 0, st, gate, N, k1, 2, f.pair_count, maxn, b.ov_count);
+        AM_LAUNCH_CHECK();
+        if (long long* stats = filter_stats_for_current_device()) {
+            hipLaunchKernelGGL(filter_stats_kernel, dim3(1), dim3(256), 0, st, b.wgq_count, (int64_t)nreg, stats, 0, 1,
+                               (const unsigned long long*)f.ovn, (const int*)nullptr, ovcap, 2, (const int*)f.pair_count, 3,
+                               (const int*)b.ov_count, 4);
+            AM_LAUNCH_CHECK();
+        }
+        return AM_OK;
+    }
     clock_begin(AM_KERNEL_KNN_VERIFY, st);
     {
         AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_fast_verify_kernel), (int)VERIFY_LDS_BYTES));
@@ -1591,7 +1701,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     {
         long long* stats = filter_stats_for_current_device();      // (the approximate values of the pairs: f.wgv, free since the scatter)
         hipLaunchKernelGGL(knn_fast_verify_kernel, dim3(2048), dim3(256), VERIFY_LDS_BYTES, st, X, ld, b.xn, D, b.wgq, f.pair_count,
-                           pair_cap, b.cand, f.cnt2, p.cap, skip_verify, (const float*)f.wgv, fast_c(D), (const unsigned*)maxn,
+                           pair_cap, b.cand, f.cnt2, p.cap, skip_verify, (const float*)f.wgv, fc, (const unsigned*)maxn,
                            stats != nullptr ? reinterpret_cast<unsigned long long*>(stats) + 9 : nullptr);
     }
     clock_end(AM_KERNEL_KNN_VERIFY, st);

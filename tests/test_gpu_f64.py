@@ -177,3 +177,40 @@ def test_f64_select_path_and_errors(am):
     y[5, 3] = np.nan
     r = ops.knn_radii(dev(y), 4).cpu().numpy()
     assert np.isinf(r[5]) and np.isfinite(np.delete(r, 5)).all()
+
+
+@pytest.mark.parametrize("rows,dim,k,kind", [(30000, 48, 5, "randn"), (20000, 8, 10, "randn"), (16500, 130, 3, "unit"),
+                                              (30000, 48, 5, "block"), (20000, 64, 5, "tiny")])
+def test_f64_radii_through_the_f16_filter_sweep(am, rows, dim, k, kind):
+    """A large float64 set against itself takes the float32 path's f16 filter sweep for its CANDIDATES (on a rounded copy) and
+    evaluates / selects them in f64 (csrc/pairwise_fast.h: knn_fast_select64_kernel); rows the sweep cannot serve - a block of
+    identical rows, operands the f16 scaling cannot hold - send the call to the general f64 kernels behind a device flag.
+    Against those general kernels (the same rows against a COPY of the set, which never takes the filter route): the same
+    radii to the rounding of two different summation orders."""
+    rng = np.random.default_rng(rows + dim)
+    x = rng.standard_normal((rows, dim))
+    if kind == "unit":
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+    elif kind == "block":
+        x[5000:8000] = x[5000]                                # 3000 identical rows: taken out of the sweep -> fallback
+    elif kind == "tiny":
+        x *= 1e-30                                            # squares underflow in float32: the rounded copy cannot be scaled
+    ops = am.hip_ops
+    xd = dev(x)
+    assert am._lib.load().am_knn_f64_workspace_bytes(rows, rows, dim, k) > am._lib.load().am_knn_f64_workspace_bytes(rows, rows + 1, dim, k)
+    ops.filter_stats_enable("cuda:0", True)
+    ops.filter_stats_read("cuda:0")
+    r = ops.knn_radii(xd, k)
+    s = ops.filter_stats_read("cuda:0")
+    ops.filter_stats_enable("cuda:0", False)
+    general = ops.knn_radii(xd, k, columns=xd.clone())
+    assert r.dtype == torch.float64
+    scale = float(np.linalg.norm(x, axis=1).max())
+    err = (r - general).abs().cpu().numpy()
+    bound = 1e-12 * scale + 4e-16 * scale * scale / np.maximum(general.cpu().numpy(), 1e-300)
+    assert (err <= bound).all(), float((err / bound).max())
+    assert s["knn_calls"] == 1                                # the filter route ran ...
+    if kind in ("block", "tiny"):
+        assert s["knn_fallback_rows"] == rows, s               # ... and handed the call to the general kernels
+    else:
+        assert s["knn_fallback_rows"] == 0 and s["knn_verified_pairs"] > rows * (k + 1), s
