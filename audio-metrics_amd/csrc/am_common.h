@@ -81,6 +81,13 @@ struct Carver {
 bool knn64_filter_eligible(int64_t N, int D, int k);
 size_t knn64_filter_workspace(int64_t N, int D, int k);
 int knn64_filter(const double* X, int64_t N, int64_t ld, int D, int k, double* out_r, void* ws, size_t ws_bytes, hipStream_t st);
+bool prdc64_filter_eligible(int64_t Nr, int64_t Nc, int D);
+size_t prdc64_filter_workspace(int64_t Nr, int64_t Nc, int D);
+// rt, ct: the f64 thresholds; col_count / row_any / row_cover: zeroed accumulators (int32 / unsigned); *fail_flag: the device
+// flag behind which the caller launches the general f64 kernel (it runs for real only when the filter route gave up)
+int prdc64_filter(const double* R, int64_t Nr, int64_t ldr, const double* C, int64_t Nc, int64_t ldc, int D, const double* rt,
+                  const double* ct, int32_t* col_count, unsigned* row_any, unsigned* row_cover, const int** fail_flag, void* ws,
+                  size_t ws_bytes, hipStream_t st);
 size_t knn64_self_workspace(int64_t N, int k);
 int knn64_self_gated(const double* X, int64_t N, int64_t ld, int D, int k, double* out_r, void* ws, size_t ws_bytes, const int* run_flag,
                      hipStream_t st);

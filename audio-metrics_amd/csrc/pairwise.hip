@@ -1400,6 +1400,67 @@ int knn64_filter(const double* X, int64_t N, int64_t ld, int D, int k, double* o
     return run_knn_fast<11>(L.x32, N, L.ld32, D, k + 1, p, b, fb, nullptr, st, 0, 1, nullptr, nullptr, nullptr, &h);
 }
 
+__global__ void __launch_bounds__(256) narrow64_kernel(const double* __restrict__ v, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)v[i];
+}
+
+bool prdc64_filter_eligible(int64_t Nr, int64_t Nc, int D) {
+    return Nr >= 1 && Nc >= 1 && cross_fast_enabled(Nr, Nc, D) && plan_cross_fast(Nr, Nc).wide;
+}
+
+struct Prdc64Layout {
+    float *r32 = nullptr, *c32 = nullptr, *rn = nullptr, *cn = nullptr, *rt = nullptr, *ct = nullptr;
+    unsigned* rmin = nullptr;
+    CrossFastPlan plan{};
+    CrossFastBuffers buf{};
+    int64_t ld32 = 0;
+    size_t total = 0;
+};
+static bool prdc64_layout(Carver& c, int64_t Nr, int64_t Nc, int D, Prdc64Layout& L) {
+    L.ld32 = (int64_t)round_up((size_t)D, (size_t)4);
+    L.r32 = c.take<float>((size_t)Nr * L.ld32);
+    L.c32 = c.take<float>((size_t)Nc * L.ld32);
+    L.rn = c.take<float>(Nr);
+    L.rt = c.take<float>(Nr);
+    L.cn = c.take<float>(Nc);
+    L.ct = c.take<float>(Nc);
+    L.rmin = c.take<unsigned>(Nr);
+    L.plan = plan_cross_fast(Nr, Nc);
+    L.buf = carve_cross_fast(c, Nr, Nc, D, L.plan);
+    L.total = c.off;
+    return c.ok();
+}
+size_t prdc64_filter_workspace(int64_t Nr, int64_t Nc, int D) {
+    Carver c(nullptr, 0);
+    Prdc64Layout L;
+    prdc64_layout(c, Nr, Nc, D, L);
+    return L.total;
+}
+
+int prdc64_filter(const double* R, int64_t Nr, int64_t ldr, const double* C, int64_t Nc, int64_t ldc, int D, const double* rt,
+                  const double* ct, int32_t* col_count, unsigned* row_any, unsigned* row_cover, const int** fail_flag, void* ws,
+                  size_t ws_bytes, hipStream_t st) {
+    Carver c(ws, ws_bytes);
+    Prdc64Layout L;
+    AM_REQUIRE(prdc64_layout(c, Nr, Nc, D, L), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", L.total, ws_bytes);
+    hipLaunchKernelGGL(cast64_kernel, dim3((unsigned)ceil_div(Nr * L.ld32, 256)), dim3(256), 0, st, R, Nr, ldr, D, L.r32, L.ld32);
+    hipLaunchKernelGGL(cast64_kernel, dim3((unsigned)ceil_div(Nc * L.ld32, 256)), dim3(256), 0, st, C, Nc, ldc, D, L.c32, L.ld32);
+    hipLaunchKernelGGL(narrow64_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, rt, Nr, L.rt);
+    hipLaunchKernelGGL(narrow64_kernel, dim3((unsigned)ceil_div(Nc, 256)), dim3(256), 0, st, ct, Nc, L.ct);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, L.rmin, Nr, 0x7f800000u);
+    AM_LAUNCH_CHECK();
+    int rc;
+    if ((rc = norms_of(nullptr, L.r32, Nr, L.ld32, D, L.rn, st)) != AM_OK) return rc;
+    if ((rc = norms_of(nullptr, L.c32, Nc, L.ld32, D, L.cn, st)) != AM_OK) return rc;
+    const Prdc64Hook h{R, C, ldr, ldc, rt, ct};
+    if ((rc = run_cross_fast(L.r32, Nr, L.ld32, L.rn, L.rt, L.c32, Nc, L.ld32, L.cn, L.ct, D, L.plan, L.buf, col_count, L.rmin, row_any,
+                             row_cover, false, st, nullptr, nullptr, &h)) != AM_OK)
+        return rc;
+    *fail_flag = L.buf.ov_count + 1;
+    return AM_OK;
+}
+
 }  // namespace am
 
 extern "C" int am_knn_radii_f32(const float* X, int64_t N, int64_t ldx, const float* Y, int64_t M, int64_t ldy,

@@ -300,8 +300,10 @@ __global__ void __launch_bounds__(FTHREADS) prdc64_kernel(const double* __restri
                                                           const double* __restrict__ rt, const double* __restrict__ C, int64_t Nc,
                                                           int64_t ldc, const double* __restrict__ cn, const double* __restrict__ ct, int D,
                                                           int nchunks, int32_t* __restrict__ col_count, unsigned* __restrict__ row_any,
-                                                          unsigned* __restrict__ row_cover, unsigned long long* __restrict__ row_min_bits) {
+                                                          unsigned* __restrict__ row_cover, unsigned long long* __restrict__ row_min_bits,
+                                                          const int* __restrict__ run_flag) {
     extern __shared__ __attribute__((aligned(16))) double lds64[];
+    if (run_flag != nullptr && *run_flag == 0) return;               // (behind the f16 filter route: only when that gave up)
     double* qnorm = lds64 + FENGINE_DOUBLES;                          // [64] |c_j|^2
     double* qthr = qnorm + FT;                                       // [64] T(r_cand[j]); -inf past the end: no witness there
     const FLane L;
@@ -600,7 +602,6 @@ extern "C" int am_knn_radii_f64(const double* X, int64_t N, int64_t ldx, const d
 }
 
 extern "C" size_t am_prdc_f64_workspace_bytes(int64_t Nr, int64_t Nc, int D) {
-    (void)D;
     if (Nr < 1 || Nc < 1) return 0;
     Carver c(nullptr, 0);
     c.take<double>((size_t)Nr);
@@ -610,6 +611,7 @@ extern "C" size_t am_prdc_f64_workspace_bytes(int64_t Nr, int64_t Nc, int D) {
     c.take<unsigned>((size_t)Nr);
     c.take<unsigned>((size_t)Nr);
     c.take<unsigned long long>((size_t)Nr);
+    if (prdc64_filter_eligible(Nr, Nc, D)) c.take<char>(prdc64_filter_workspace(Nr, Nc, D));     // (the f16 filter route's part)
     return c.off;
 }
 
@@ -628,6 +630,11 @@ extern "C" int am_prdc_counts_f64(const double* R, int64_t Nr, int64_t ldr, cons
     unsigned* rany = c.take<unsigned>((size_t)Nr);
     unsigned* rcov = c.take<unsigned>((size_t)Nr);
     unsigned long long* rmin = c.take<unsigned long long>((size_t)Nr);
+    // large problems without a row minimum: the float32 path's f16 filter pass decides what it can, the pairs inside its band are
+    // evaluated in f64 (pairwise.hip: prdc64_filter); the general kernel below then runs behind the route's fail flag
+    const size_t filter_bytes = prdc64_filter_eligible(Nr, Nc, D) ? prdc64_filter_workspace(Nr, Nc, D) : 0;
+    void* filter_ws = nullptr;
+    if (filter_bytes != 0 && out_row_min == nullptr && c.off + filter_bytes <= ws_bytes) filter_ws = c.take<char>(filter_bytes);
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);
     hipLaunchKernelGGL(row_sqnorm64_kernel, dim3((unsigned)ceil_div(Nr, 4)), dim3(256), 0, st, R, Nr, ldr, D, rn);
     hipLaunchKernelGGL(row_sqnorm64_kernel, dim3((unsigned)ceil_div(Nc, 4)), dim3(256), 0, st, C, Nc, ldc, D, cn);
@@ -641,10 +648,15 @@ extern "C" int am_prdc_counts_f64(const double* R, int64_t Nr, int64_t ldr, cons
         hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, rmin, Nr, 0x7ff0000000000000ull);
         AM_LAUNCH_CHECK();
     }
+    const int* run_flag = nullptr;
+    if (filter_ws != nullptr) {
+        int rc = prdc64_filter(R, Nr, ldr, C, Nc, ldc, D, rt, ct, out_col_count, rany, rcov, &run_flag, filter_ws, filter_bytes, st);
+        if (rc != AM_OK) return rc;
+    }
     const int nchunks = chunks_for(ceil_div(Nr, FT), ceil_div(Nc, FT));
     AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&prdc64_kernel), (int)LDS_BYTES_PRDC));
     hipLaunchKernelGGL(prdc64_kernel, dim3((unsigned)(ceil_div(Nr, FT) * nchunks)), dim3(FTHREADS), LDS_BYTES_PRDC, st, R, Nr, ldr, rn, rt, C, Nc,
-                       ldc, cn, ct, D, nchunks, out_col_count, rany, rcov, out_row_min != nullptr ? rmin : nullptr);
+                       ldc, cn, ct, D, nchunks, out_col_count, rany, rcov, out_row_min != nullptr ? rmin : nullptr, run_flag);
     AM_LAUNCH_CHECK();
     hipLaunchKernelGGL(prdc64_finish_kernel, dim3((unsigned)ceil_div(Nr, 256)), dim3(256), 0, st, rany, rcov, rmin, Nr, out_row_any, out_row_cover,
                        out_row_min);

@@ -661,6 +661,65 @@ __global__ void __launch_bounds__(256) cross_verify_overflow_kernel(const float*
     }
 }
 
+// ---- float64 rows (round 5): the membership filter's queued pairs evaluated in f64 ------------------------------------------
+// The filter pass runs on float32-rounded copies of the two sets with float32-rounded thresholds; what it decides WITHOUT
+// looking again - "certainly inside" (a < T - E), "certainly a witness", "certainly outside" (not queued) - holds for the
+// float64 rows because its band is widened by the two roundings (run_cross_fast: fast_c + 2^-18: a distance moves by at most
+// 2^-21 (|x|^2 + |y|^2) when the rows are rounded, a threshold by 2^-24 of itself); every pair inside the band is queued and
+// evaluated here as a sum of squared differences in f64 against the f64 thresholds T(R) (pairwise_f64.hip).
+struct Prdc64Hook {
+    const double *R, *C;
+    int64_t ldr, ldc;
+    const double *rt, *ct;          // thresholds T(r_ref[i]), T(r_cand[j]) in f64
+};
+
+__device__ __forceinline__ void cross_apply64(const double* __restrict__ x, const double* __restrict__ y, int D, int64_t i, int64_t j,
+                                              unsigned jflag, const double* __restrict__ rt, const double* __restrict__ ct,
+                                              int32_t* __restrict__ col_count, unsigned* __restrict__ row_any,
+                                              unsigned* __restrict__ row_cover) {
+    double t = 0.0;
+    for (int d = 0; d < D; ++d) {
+        const double u = x[d] - y[d];
+        t = fma(u, u, t);
+    }
+    if (t < ct[j]) atomicOr(row_any + i, 1u);               // (a NaN distance is inside nothing)
+    if (t < rt[i]) {
+        atomicOr(row_cover + i, 1u);
+        if (!(jflag & FAST_COUNTED)) atomicAdd(col_count + j, 1);
+    }
+}
+
+__global__ void __launch_bounds__(256) cross_verify_regions64_kernel(Prdc64Hook h, int D, const uint2* __restrict__ wgq, int qcap,
+                                                                     const int* __restrict__ wgq_count, const uint2* __restrict__ items,
+                                                                     const int* __restrict__ item_count, int32_t* __restrict__ col_count,
+                                                                     unsigned* __restrict__ row_any, unsigned* __restrict__ row_cover,
+                                                                     const int* __restrict__ fail) {
+    if (*fail) return;
+    const int nitems = *item_count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int it = blockIdx.x * 4 + wave; it < nitems; it += gridDim.x * 4) {
+        const uint2 item = items[it];
+        const int e = (int)item.y + lane;
+        if (e >= wgq_count[item.x]) continue;
+        const uint2 v = wgq[(int64_t)item.x * qcap + e];
+        const int64_t i = v.x, j = v.y & ~FAST_COUNTED;
+        cross_apply64(h.R + i * h.ldr, h.C + j * h.ldc, D, i, j, v.y, h.rt, h.ct, col_count, row_any, row_cover);
+    }
+}
+
+__global__ void __launch_bounds__(256) cross_verify_overflow64_kernel(Prdc64Hook h, int D, const uint2* __restrict__ ovq,
+                                                                      const int* __restrict__ ov_count, int ovcap,
+                                                                      const int* __restrict__ fail, int32_t* __restrict__ col_count,
+                                                                      unsigned* __restrict__ row_any, unsigned* __restrict__ row_cover) {
+    if (*fail) return;
+    const int n = *ov_count < ovcap ? *ov_count : ovcap;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const uint2 v = ovq[e];
+        const int64_t i = v.x, j = v.y & ~FAST_COUNTED;
+        cross_apply64(h.R + i * h.ldr, h.C + j * h.ldc, D, i, j, v.y, h.rt, h.ct, col_count, row_any, row_cover);
+    }
+}
+
 // Data-dependent fallback of the membership filter (round 4), the counterpart of check B of the k-NN filter: when the filter
 // pass has queued more pairs than an exact verification is worth - both sets drawn around the SAME tight clusters: every
 // candidate of a reference row's cluster lies inside the error band of that row's radius, 400 undecidable pairs per row at
@@ -785,8 +844,11 @@ static bool cross_fast_enabled(int64_t Nr, int64_t Nc, int D) {
 static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* rn, const float* rt, const float* C, int64_t Nc,
                           int64_t ldc, const float* cn, const float* ct, int D, const CrossFastPlan& p, const CrossFastBuffers& b,
                           int32_t* col_count, unsigned* rmin, unsigned* rany, unsigned* rcov, bool want_min, hipStream_t st,
-                          const PreparedSet* prep_r = nullptr, const PreparedSet* prep_c = nullptr) {
+                          const PreparedSet* prep_r = nullptr, const PreparedSet* prep_c = nullptr, const Prdc64Hook* h64 = nullptr) {
     int rc;
+    // (float64 route: R, C are float32-rounded copies and rt, ct rounded thresholds; both roundings are priced into the band)
+    const float fc = h64 != nullptr ? fast_c(D) + 3.814697265625e-06f : fast_c(D);
+    AM_REQUIRE(h64 == nullptr || (p.wide && !want_min), AM_ERR_BAD_ARG, "the float64 route is the 256-row form without row minima");
     AM_HIP_TRY(hipMemsetAsync(b.maxn, 0, 4 * sizeof(unsigned), st));
     AM_HIP_TRY(hipMemsetAsync(b.ov_count, 0, 4 * sizeof(int), st));
     if (prep_r != nullptr) hipLaunchKernelGGL(prepared_stats_kernel, dim3(1), dim3(64), 0, st, prep_r->stats, b.maxn, 0, 2, -1);
@@ -814,7 +876,7 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
     auto launch_filter = [&](auto kernel, unsigned grid, int nchunks, int qstride, int grp_rows) {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(ENGINE_THREADS), FAST_LDS_BYTES, st, Rb, Nr, ldb / 2, rn, rt, Cb, Nc, ldb / 2,
                            cn, ct, Dh, nchunks, qstride, b.maxn, b.rmin_approx, rany, rcov, col_count, b.wgq, p.qcap, b.wgq_count,
-                           b.ovq, b.ov_count, p.ovcap, fail, dbg, fast_c(D), grp_rows);
+                           b.ovq, b.ov_count, p.ovcap, fail, dbg, fc, grp_rows);
     };
     const unsigned pre_grid = (unsigned)(ceil_div(Nr, TB) * p.pre_chunks);
     static const int pre_any = env_int("AM_FAST_PRE_ANY", 1);          // 1: on the engine of the main pass, 2: 128-row engine, 0: none
@@ -832,7 +894,7 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
                 chunks = c;
             }
         }
-        if ((rc = launch_cross_wide_sample(Rb, Nr, ldb / 2, rn, Cb, Nc, ldb / 2, cn, ct, Dh, p.qstride, chunks, b.maxn, rany, fast_c(D),
+        if ((rc = launch_cross_wide_sample(Rb, Nr, ldb / 2, rn, Cb, Nc, ldb / 2, cn, ct, Dh, p.qstride, chunks, b.maxn, rany, fc,
                                            st)) != AM_OK)
             return rc;
     } else if (pre_any) launch_filter(&cross_fast_kernel<true, false>, pre_grid, p.pre_chunks, p.qstride, 0);
@@ -852,14 +914,19 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
         const auto launch_main = wide_stationary(Dh) ? &launch_cross_pstat : &launch_cross_wide;
         if ((rc = launch_main(want_min, (unsigned)p.blocks, Rb, Nr, ldb / 2, rn, rt, Cb, Nc, ldb / 2, cn, ct, Dh, p.nchunks,
                                     p.grp_rows, b.maxn, b.rmin_approx, rany, rcov, col_count, b.wgq, p.qcap, b.wgq_count, b.items,
-                                    b.ovq, b.ov_count, limit_overflow, fail, fast_c(D), st)) != AM_OK)
+                                    b.ovq, b.ov_count, limit_overflow, fail, fc, st)) != AM_OK)
             return rc;
         clock_end(AM_KERNEL_PRDC_CROSS, st);
         hipLaunchKernelGGL(cross_fast_decide_kernel, dim3(1), dim3(64), 0, st, b.ov_count, p.ovcap, fail, limit_total, limit_overflow);
         clock_begin(AM_KERNEL_PRDC_VERIFY, st);
-        AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&cross_verify_regions_kernel), (int)VERIFY_LDS_BYTES));
-        hipLaunchKernelGGL(cross_verify_regions_kernel, dim3(CROSS_VERIFY_GRID), dim3(256), VERIFY_LDS_BYTES, st, R, ldr, rn, rt, C, ldc,
-                           cn, ct, D, b.wgq, p.qcap, b.wgq_count, b.items, b.ov_count + 2, col_count, rmin_or_null, rany, rcov, fail);
+        if (h64 != nullptr) {
+            hipLaunchKernelGGL(cross_verify_regions64_kernel, dim3(CROSS_VERIFY_GRID), dim3(256), 0, st, *h64, D, b.wgq, p.qcap, b.wgq_count,
+                               b.items, b.ov_count + 2, col_count, rany, rcov, fail);
+        } else {
+            AM_HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&cross_verify_regions_kernel), (int)VERIFY_LDS_BYTES));
+            hipLaunchKernelGGL(cross_verify_regions_kernel, dim3(CROSS_VERIFY_GRID), dim3(256), VERIFY_LDS_BYTES, st, R, ldr, rn, rt, C, ldc,
+                               cn, ct, D, b.wgq, p.qcap, b.wgq_count, b.items, b.ov_count + 2, col_count, rmin_or_null, rany, rcov, fail);
+        }
         clock_end(AM_KERNEL_PRDC_VERIFY, st);
     } else {
         clock_begin(AM_KERNEL_PRDC_CROSS, st);
@@ -874,6 +941,10 @@ static int run_cross_fast(const float* R, int64_t Nr, int64_t ldr, const float* 
         clock_end(AM_KERNEL_PRDC_VERIFY, st);
     }
     AM_LAUNCH_CHECK();
+    if (h64 != nullptr)
+        hipLaunchKernelGGL(cross_verify_overflow64_kernel, dim3(1024), dim3(256), 0, st, *h64, D, b.ovq, b.ov_count, p.ovcap, fail, col_count,
+                           rany, rcov);
+    else
     hipLaunchKernelGGL(cross_verify_overflow_kernel, dim3(1024), dim3(256), 0, st, R, ldr, rn, rt, C, ldc, cn, ct, D, b.ovq,
                        b.ov_count, p.ovcap, fail, col_count, rmin_or_null, rany, rcov);
     AM_LAUNCH_CHECK();

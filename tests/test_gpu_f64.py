@@ -214,3 +214,39 @@ def test_f64_radii_through_the_f16_filter_sweep(am, rows, dim, k, kind):
         assert s["knn_fallback_rows"] == rows, s               # ... and handed the call to the general kernels
     else:
         assert s["knn_fallback_rows"] == 0 and s["knn_verified_pairs"] > rows * (k + 1), s
+
+
+@pytest.mark.parametrize("nr,nc,dim,k,kind", [(30000, 28000, 48, 5, "randn"), (20000, 20000, 8, 10, "randn"), (16500, 16400, 130, 3, "unit"),
+                                               (30000, 9000, 48, 5, "shared"), (20000, 20000, 64, 5, "tiny")])
+def test_f64_membership_counts_through_the_f16_filter(am, nr, nc, dim, k, kind):
+    """Large float64 problems: the float32 path's f16 filter pass on rounded copies decides what its (widened) band allows, the
+    pairs inside the band are evaluated in f64 against the f64 thresholds (csrc/pairwise_fast.h: cross_verify_regions64_kernel);
+    sets the filter cannot serve - shared tight clusters, operands that cannot be scaled - go to the general f64 kernel behind
+    the route's fail flag.  Against the general kernel itself (asking for the row minimum keeps a call on it): counts and flags
+    EXACTLY equal."""
+    rng = np.random.default_rng(nr + dim)
+    if kind == "shared":                                        # both sets around the same 40 tight clusters
+        centres = rng.standard_normal((40, dim))
+        x = centres[rng.integers(0, 40, nr)] + 1e-3 * rng.standard_normal((nr, dim))
+        y = centres[rng.integers(0, 40, nc)] + 1e-3 * rng.standard_normal((nc, dim))
+    else:
+        x, y = rng.standard_normal((nr, dim)), rng.standard_normal((nc, dim)) * 1.05 + 0.05
+    if kind == "unit":
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        y /= np.linalg.norm(y, axis=1, keepdims=True)
+    elif kind == "tiny":
+        x, y = x * 1e-30, y * 1e-30
+    ops = am.hip_ops
+    xd, yd = dev(x), dev(y)
+    rx, ry = ops.knn_radii(xd, k), ops.knn_radii(yd, k)
+    ops.filter_stats_enable("cuda:0", True)
+    ops.filter_stats_read("cuda:0")
+    col, rany, rcov = ops.prdc_counts(xd, yd, rx, ry)
+    s = ops.filter_stats_read("cuda:0")
+    ops.filter_stats_enable("cuda:0", False)
+    want = ops.prdc_counts(xd, yd, rx, ry, want_min=True)
+    assert torch.equal(col, want[0]) and torch.equal(rany, want[1]) and torch.equal(rcov, want[2])
+    assert s["prdc_calls"] == 1                               # the filter route ran ...
+    assert s["prdc_fallback_calls"] == (1 if kind in ("shared", "tiny") else 0), s
+    print(f"{kind} {nr} x {nc} x {dim}: inside pairs {int(col.sum())}, rows with a witness {int(rany.sum())}, covered {int(rcov.sum())}, "
+          f"queued {s['prdc_queued']}")
