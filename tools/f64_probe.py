@@ -48,6 +48,6 @@ for shape in shapes.split(","):
         out[name] = (t_knn, t_cnt, t_kd, m)
     (t_knn, t_cnt, t_kd, m), f32 = out["f64"], out["f32"]
     flop = 2.0 * n * n * d
-    print(f"{n} x {d}, k = {k}: f64 radii {t_knn:.2f} ms ({flop / t_knn * 1e3 / F64_PEAK:.2f} of the f64 matrix peak, all pairs), "
+    print(f"{n} x {d}, k = {k}: f64 radii {t_knn:.2f} ms (all pairs / time = {flop / t_knn * 1e3 / F64_PEAK:.2f} x the f64 matrix peak: above 1 = the f16 filter route), "
           f"membership {t_cnt:.2f} ms ({flop / t_cnt * 1e3 / F64_PEAK:.2f}), kernel distance 100 x {m}: {t_kd:.2f} ms "
           f"({100 * 3 * 2.0 * m * m * d / t_kd * 1e3 / F64_PEAK:.2f})  |  float32 rows: {f32[0]:.2f} / {f32[1]:.2f} / {f32[2]:.2f} ms", flush=True)
