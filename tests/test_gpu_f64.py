@@ -250,3 +250,22 @@ def test_f64_membership_counts_through_the_f16_filter(am, nr, nc, dim, k, kind):
     assert s["prdc_fallback_calls"] == (1 if kind in ("shared", "tiny") else 0), s
     print(f"{kind} {nr} x {nc} x {dim}: inside pairs {int(col.sum())}, rows with a witness {int(rany.sum())}, covered {int(rcov.sum())}, "
           f"queued {s['prdc_queued']}")
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), 1e200, 1e-200])
+def test_f64_filter_routes_with_values_float32_cannot_hold(am, bad):
+    """A NaN / Inf / 1e200 element makes the float32-rounded copy unscalable: the filter routes hand the call to the general f64
+    kernels on the device (a NaN row is nobody's neighbour and has an infinite radius); 1e-200 rounds to zero in the copy and is
+    evaluated exactly in f64."""
+    rng = np.random.default_rng(3)
+    x, y = rng.standard_normal((20000, 32)), rng.standard_normal((18000, 32))
+    x[5, 3] = bad
+    y[7, 1] = bad
+    ops = am.hip_ops
+    xd, yd = dev(x), dev(y)
+    r, general = ops.knn_radii(xd, 4), ops.knn_radii(xd, 4, columns=xd.clone())
+    fin = torch.isfinite(general)
+    assert torch.equal(torch.isfinite(r), fin) and bool(((r - general).abs()[fin] <= 1e-9 * general[fin]).all())
+    r2 = ops.knn_radii(yd, 4)
+    got, want = ops.prdc_counts(xd, yd, r, r2), ops.prdc_counts(xd, yd, r, r2, want_min=True)
+    assert all(torch.equal(a, b) for a, b in zip(got, want[:3]))
