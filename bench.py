@@ -111,14 +111,14 @@ def warm_evaluate(am, ref, cand, k, steps):
             "what": "reference statistics and radii cached (second evaluate() against the same reference)", "result": res}
 
 
-def check_against_fixture(result, kind, n, d, k):
+def check_against_fixture(result, kind, n, d, k, suffix=""):
     """`result` against the fixture for the same numpy-seeded sets (tests/golden/bench_prdc.npz, written by
     tests/golden/make_goldens.py bench in the build container): FAD and KD are the reference's OWN frechet_distance /
     kernel_distance outputs on these inputs, the four PRDC values come from oracle.prdc_blocked (row blocks of the
     reference's torch calls - its N x N formulation needs 164 GB at 100k rows)."""
     path = os.path.join(ROOT, "tests", "golden", "bench_prdc.npz")
     if d != 512:
-        kind = f"{kind}_d{d}"                       # the narrower sets' keys carry the width (make_goldens.py gen_bench)
+        kind = f"{kind}_d{d}{suffix}"               # the narrower sets' keys carry the width (make_goldens.py gen_bench), float64 ones "_f64"
     tag = f"{kind}_k{k}"
     if not (os.path.exists(path) and n == 100000):
         return None
@@ -461,6 +461,15 @@ def main():
                                       "filter": per_step(stats, 7), "result": vres,
                                       "knn_path": ops.knn_path(n, n, 128, k), "prdc_path": ops.prdc_path(n, n, 128),
                                       "result_check": check_against_fixture(vres, "randn", n, 128, k)}
+            del vr, vc
+            # float64 rows of width 64 - what n_pca = 64 hands on (reference projection.py:20-21; every stage then runs in float64,
+            # data.py:39-44, prdc.py:12-13, kd.py:112-116): the *_f64 entry points, the large sets through the f16 filter with an f64
+            # evaluation of the undecided pairs; checked against the reference's own float64 values / the blocked oracle in float64
+            vr, vc = (torch.as_tensor(a).to(dev) for a in gi.pair64("randn", gi.BENCH_SEED, n, n, 64))
+            dt, vres = timed_steps(lambda: evaluate_sharded(vr, vc, metrics=("fad", "kd", "prdc"), nearest_k=k), fence, 5, 2)
+            variants["pca64_f64"] = {"ms_per_step": dt / 5 * 1e3, "embeddings_per_s": 5 * 2 * n / dt, "dtype": "f64",
+                                     "workload": f"FAD+KD+PRDC(k={k}) cold evaluate() of 2x{n}x64 FLOAT64 randn sets (the shape n_pca = 64 leaves)",
+                                     "result": vres, "result_check": check_against_fixture(vres, "randn", n, 64, k, "_f64")}
             del vr, vc
         for name, kind, vk in (("clap_shaped_k5", "clap", 5), ("randn_k10", "randn", 10), ("clap_shaped_k10", "clap", 10)):
             if (kind, vk) == (args.data, k):

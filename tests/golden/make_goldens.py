@@ -235,8 +235,11 @@ def gen_bench():
     # (kind, width): 512 = the CLAP-shaped headline sets; 128 = VGGish's width (reference embedders/vggish.py:5-33,
     # BASELINE configs[0]'s shape) at the same 100 000 rows - the bench variant `vggish_128`.  Keys of the narrower sets
     # carry the width: "randn_d128/fad", "randn_d128_k5/precision".
-    for kind_name, kind, width in (("randn", "randn", 512), ("clap", "clap", 512), ("randn_d128", "randn", 128)):
-        ref, cand = gi.bench_pair(kind, 100000, width)
+    # "randn_d64_f64": float64 rows of width 64 - what n_pca = 64 hands on (projection.py:20-21) - at the headline row count: the
+    # bench variant `pca64_f64`; the reference's functions and the blocked oracle then run in float64 throughout
+    for kind_name, kind, width in (("randn", "randn", 512), ("clap", "clap", 512), ("randn_d128", "randn", 128),
+                                   ("randn_d64_f64", "randn64", 64)):
+        ref, cand = gi.pair64("randn", gi.BENCH_SEED, 100000, 100000, width) if kind == "randn64" else gi.bench_pair(kind, 100000, width)
         kind = kind_name
         if f"{kind}/fad" not in out:
             t0 = time.time()

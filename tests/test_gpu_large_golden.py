@@ -85,3 +85,27 @@ def test_bench_size_result_vs_blocked_oracle(am, golden, kind, k):
     for key in ("precision", "recall", "density", "coverage"):
         want = float(g[f"{kind}_k{k}/{key}"])
         assert abs(res[key] - want) <= max(REL * abs(want), 5.0 / n), (key, res[key], want)
+
+
+def test_bench_size_float64_rows_vs_the_reference_in_float64(am, golden):
+    """bench.py's variant `pca64_f64`: 2 x 100 000 float64 rows of width 64 (what n_pca = 64 hands on).  FAD and the kernel
+    distance against the reference's own float64 outputs, PRDC against oracle.prdc_blocked in float64 (make_goldens.py
+    gen_bench) - through the *_f64 entry points, the radii and the membership counts on the f16 filter routes."""
+    from audio_metrics_amd import hip_ops as ops
+    from audio_metrics_amd.distributed import evaluate_sharded
+    g = golden("bench_prdc")
+    n, d, k = 100000, 64, 5
+    ref, cand = gi.pair64("randn", gi.BENCH_SEED, n, n, d)
+    dev = torch.device("cuda:0")
+    ops.filter_stats_enable(dev, True)
+    ops.filter_stats_read(dev)
+    res = evaluate_sharded(torch.as_tensor(ref).to(dev), torch.as_tensor(cand).to(dev), metrics=("fad", "kd", "prdc"), nearest_k=k)
+    s = ops.filter_stats_read(dev)
+    ops.filter_stats_enable(dev, False)
+    assert s["knn_calls"] == 2 and s["prdc_calls"] == 1 and s["knn_fallback_rows"] == 0 and s["prdc_fallback_calls"] == 0, s
+    for key in ("precision", "recall", "density", "coverage"):
+        want = float(g[f"randn_d64_f64_k{k}/{key}"])
+        assert abs(res[key] - want) <= 2.0 / n, (key, res[key], want)          # float64 on both sides: at most a pair or two on a tie
+    assert abs(res["fad"] - float(g["randn_d64_f64/fad"])) <= 1e-7 * abs(res["fad"])
+    assert abs(res["kernel_distance_mean"] - float(g["randn_d64_f64/kernel_distance_mean"])) <= 1e-10
+    assert abs(res["kernel_distance_std"] - float(g["randn_d64_f64/kernel_distance_std"])) <= 1e-10
