@@ -305,6 +305,14 @@ int am_prdc_reduce(const int32_t* col_count, int64_t Nc,
  *   (v_mfma_f64_16x16x4_f64, csrc/pairwise_f64.hip):  d2 = max(fma(-2, <x, y>, |x|^2 + |y|^2), 0), radius = sqrt_rn of the
  *   (k+1)-th smallest d2, membership  sqrt_rn(d2) < r  decided exactly through d2 < T(r).  Rows need no alignment
  *   (ld >= D, in elements).  Any 1 <= k < M (k > 31: distance blocks + a radix select, a correctness path).
+ *   Large problems - am_knn_radii_f64 of a set against itself (Y == X, k <= 10) and am_prdc_counts_f64 without a row minimum,
+ *   from the row counts at which the float32 entry points switch to their f16 filter form - take that filter too: the sweep
+ *   runs on a float32-rounded copy inside the workspace with an error band widened by the rounding, and every pair the band
+ *   cannot decide is evaluated in f64 as a sum of squared differences against the f64 thresholds (csrc/pairwise_fast.h:
+ *   knn_fast_select64_kernel, cross_verify_regions64_kernel).  Same results as the general kernels to rounding (counts equal;
+ *   the sum of squared differences is the more accurate form on near-duplicate rows), about a tenth of their time at 100 000
+ *   rows; data the filter cannot serve runs the general kernels, launched behind a device flag.  The workspace queries cover
+ *   the route; with a smaller workspace the general kernels run.
  * ------------------------------------------------------------------------- */
 size_t am_knn_f64_workspace_bytes(int64_t N, int64_t M, int D, int k);
 int am_knn_radii_f64(const double* X, int64_t N, int64_t ldx,
