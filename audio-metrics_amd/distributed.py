@@ -426,6 +426,12 @@ def sharded_radii(local, full, counts, k, ops, world, rank, group, prepared=None
         return r_full[lo:hi], r_full
     if after_first_exchange is not None:
         after_first_exchange()
+    if not _alone(world) and full.dtype == torch.float64 and hasattr(ops, "knn_path") and ops.knn_path(n, n, d, k) == 3 and k <= 10:
+        # float64 rows at the sizes of the f16 filter sweep: the whole set's radii on the filter route cost a rank less than its
+        # share of the general f64 kernel would (100 000 x 64: 2.6 ms against 32 ms / world) - every rank computes them, nothing
+        # is exchanged (a pure function of the shapes: the same branch on every rank)
+        r_full = ops.knn_radii(full, k)
+        return r_full[lo:hi], r_full
     if _alone(world) and prepared is not None:
         r_local = ops.knn_radii(full, k, prepared=prepared)
     elif local.shape[0] > 0:

@@ -365,3 +365,55 @@ def test_collectives_over_rccl_in_a_group_of_one():
         assert abs(got["fad"] - want["fad"]) <= 1e-5 * abs(want["fad"]), (name, got["fad"], want["fad"])
         assert abs(got["kernel_distance_mean"] - want["kernel_distance_mean"]) <= 1e-9, name
         assert abs(got["kernel_distance_std"] - want["kernel_distance_std"]) <= 1e-9, name
+
+
+def _f64_worker(rank, world, port, n_ref, n_cand, d, k, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from audio_metrics_amd import distributed as dmod
+    ref, cand = gi.pair64("randn", 97, n_ref, n_cand, d)
+    rl, rh = dmod.shard_bounds(n_ref, world, rank)
+    cl, ch = dmod.shard_bounds(n_cand, world, rank)
+    dev = torch.device("cuda:0")
+    dmod.exchange_log_begin()
+    res = dmod.evaluate_sharded(torch.as_tensor(ref[rl:rh]).to(dev), torch.as_tensor(cand[cl:ch]).to(dev), nearest_k=k,
+                                kid_subsets=8, kid_subset_size=300)
+    names = [r["name"] for r in dmod.exchange_log_end()]
+    out_q.put((rank, res, names))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluate_of_float64_rows():
+    """float64 row shards on two ranks (sharing cuda:0 over gloo): every stage in float64; at these sizes each rank computes the
+    gathered sets' radii on the f16 filter route with the f64 evaluation - no radius exchange - and its share of the membership
+    counts the same way.  Equal to the one-rank result."""
+    from audio_metrics_amd.distributed import evaluate_sharded
+    n_ref, n_cand, d, k, world = 16500, 16400, 48, 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_f64_worker, args=(r, world, port, n_ref, n_cand, d, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results = {rank: res for rank, res, _ in got}
+    names = got[0][2]
+    assert "radii" not in names and "knn_lists" not in names, names           # nothing exchanged for the radii
+    ref, cand = gi.pair64("randn", 97, n_ref, n_cand, d)
+    dev = torch.device("cuda:0")
+    single = evaluate_sharded(torch.as_tensor(ref).to(dev), torch.as_tensor(cand).to(dev), nearest_k=k, kid_subsets=8, kid_subset_size=300)
+    assert results[0] == results[1]
+    for key, w in single.items():
+        if key in ("precision", "recall", "density", "coverage"):
+            assert results[0][key] == w, key
+        else:
+            assert abs(results[0][key] - w) <= 1e-9 * abs(w) + 1e-13, (key, results[0][key], w)
