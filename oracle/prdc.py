@@ -38,11 +38,15 @@ def prdc(reference, candidate, k):
     return prdc_from_features(reference.embeddings, candidate.embeddings, r_ref, r_cand, k)
 
 
-def prdc_blocked(ref, cand, k, block=4096):
+def prdc_blocked(ref, cand, k, block=4096, return_counts=False):
     """Same quantities without materialising N x N matrices (row blocks of the
-    same torch calls).  Used only as the timed CPU baseline at sizes where the
-    reference's own N x N formulation does not fit host memory; values can
-    differ from ``prdc`` in the last f32 bit of individual distances."""
+    same torch calls).  Used as the timed CPU baseline and as the generator of
+    ``tests/golden/bench_prdc.npz`` at sizes where the reference's own N x N
+    formulation does not fit host memory; values can differ from ``prdc`` in the
+    last f32 bit of individual distances (``torch.cdist`` picks its summation
+    blocking by shape).  ``tests/test_oracle_golden.py::test_prdc_blocked_vs_reference_large``
+    pins it against the REFERENCE's own outputs at 33 000 - 40 000 rows
+    (radii, integer column counts, row flags)."""
     ref, cand = torch.as_tensor(ref), torch.as_tensor(cand)
 
     def radii(x):
@@ -60,7 +64,10 @@ def prdc_blocked(ref, cand, k, block=4096):
         col_count += (d < r_ref[s:s + block, None]).sum(dim=0)
         row_any[s:s + block] = (d < r_cand[None, :]).any(dim=1)
         row_min[s:s + block] = d.min(dim=1)[0]
-    return dict(precision=(col_count > 0).double().mean().item(),
-                recall=row_any.double().mean().item(),
-                density=(1.0 / float(k)) * col_count.double().mean().item(),
-                coverage=(row_min < r_ref).double().mean().item())
+    out = dict(precision=(col_count > 0).double().mean().item(),
+               recall=row_any.double().mean().item(),
+               density=(1.0 / float(k)) * col_count.double().mean().item(),
+               coverage=(row_min < r_ref).double().mean().item())
+    if return_counts:
+        return out, dict(r_ref=r_ref, r_cand=r_cand, col_count=col_count, row_any=row_any, row_cover=row_min < r_ref)
+    return out
