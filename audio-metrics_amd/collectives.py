@@ -22,6 +22,7 @@ class TorchCollectives:
         self._tensors = []
         self.error = None
         self.calls = []                                     # (name, bytes) of every hook call, in issue order
+        self.gather_form = None                             # which torch.distributed call the last all_gather_v became
         self._reduce = _lib.ALL_REDUCE_SUM_FN(self._all_reduce_sum)
         self._gather = _lib.ALL_GATHER_V_FN(self._all_gather_v)
         self.struct = _lib.CollectivesStruct(None, self.rank, self.world, self._reduce, self._gather)
@@ -37,6 +38,10 @@ class TorchCollectives:
                 flat = t.view(-1).view(torch.uint8)
                 return flat[ptr - base:ptr - base + nbytes]
         raise RuntimeError(f"collective hook: pointer {ptr:#x} (+{nbytes}) lies in no exposed tensor")
+
+    def _in_place_ok(self, tensor):
+        """input = a slice of the output: RCCL's in-place all-gather (ncclAllGather with sendbuff = recvbuff + rank * count)"""
+        return tensor.is_cuda and dist.get_backend(self.group) == "nccl"
 
     def _on(self, stream_ptr, device):
         # torch orders a collective after the work of its CURRENT stream: make that the stream the library named
@@ -70,15 +75,24 @@ class TorchCollectives:
             offs = [sum(sizes[:r]) for r in range(self.world)]
             if send != recv + offs[self.rank]:
                 raise RuntimeError("all_gather_v: the library promises an in-place call")
-            biggest = max(sizes)
+            mine = whole[offs[self.rank]:offs[self.rank] + sizes[self.rank]]
             with self._on(stream, whole.device):
-                mine = torch.zeros(biggest, dtype=torch.uint8, device=whole.device)
-                mine[:sizes[self.rank]] = whole[offs[self.rank]:offs[self.rank] + sizes[self.rank]]
-                parts = [torch.empty(biggest, dtype=torch.uint8, device=whole.device) for _ in range(self.world)]
-                dist.all_gather(parts, mine, group=self.group)
-                for r in range(self.world):
-                    if r != self.rank and sizes[r]:
-                        whole[offs[r]:offs[r] + sizes[r]] = parts[r][:sizes[r]]
+                if len(set(sizes)) == 1 and self._in_place_ok(whole):
+                    # equal shares on RCCL: ONE all-gather straight into the library's buffer, the rank's own share already at
+                    # its offset - what csrc/rccl/am_rccl.cpp does with ncclAllGather (no staging copy, no copy back)
+                    self.gather_form = "all_gather_into_tensor, in place"
+                    dist.all_gather_into_tensor(whole, mine, group=self.group)
+                elif len(set(sizes)) == 1:
+                    # gloo (the CPU tests, ranks sharing one GPU): the same call from a copy of the own share
+                    self.gather_form = "all_gather_into_tensor, own share copied"
+                    dist.all_gather_into_tensor(whole, mine.clone(), group=self.group)
+                else:
+                    # unequal shares: one broadcast per rank into its slice, in place (am_rccl.cpp: the same, inside a group call)
+                    self.gather_form = "broadcast per rank, in place"
+                    for r in range(self.world):
+                        if sizes[r]:
+                            src = dist.get_global_rank(self.group, r) if self.group is not None else r
+                            dist.broadcast(whole[offs[r]:offs[r] + sizes[r]], src=src, group=self.group)
             return 0
         except Exception as exc:
             self.error = exc

@@ -109,6 +109,14 @@ extern "C" int am_evaluate_f32(const float* ref, int64_t n_ref, int64_t ld_ref, 
     AM_REQUIRE(!(what & AM_EVAL_FAD) || side_stream != stream, AM_ERR_BAD_ARG,
                "the Frechet solve runs on side_stream, which must differ from stream");
     hipStream_t st = static_cast<hipStream_t>(stream), side = static_cast<hipStream_t>(side_stream);
+    // Where the Frechet blocks run (A/B build only, AM_EVAL_FAD_PLACE; profiles/r6/ab_frechet_stream.txt): 0 = the side stream,
+    // free to start once the statistics exist (shipped); 1 = the caller's stream, behind the kernel distance; 2 = the side
+    // stream, held back until the first k-NN entry has finished
+#ifdef AM_DEV_KNOBS
+    static const int fad_place = getenv("AM_EVAL_FAD_PLACE") ? atoi(getenv("AM_EVAL_FAD_PLACE")) : 0;
+#else
+    constexpr int fad_place = 0;
+#endif
     Carver c(ws, ws_bytes);
     EvalLayout L;
     AM_REQUIRE(eval_layout(c, n_ref, n_cand, D, nearest_k, kd_subsets, kd_m, what, L), AM_ERR_WORKSPACE,
@@ -145,7 +153,7 @@ extern "C" int am_evaluate_f32(const float* ref, int64_t n_ref, int64_t ld_ref, 
             if (e) (void)hipEventDestroy(e);                         // (released once the recorded work has completed)
         }
     } ev_stats, ev_fad;
-    if (what & AM_EVAL_FAD) {
+    if ((what & AM_EVAL_FAD) && fad_place != 2) {
         AM_HIP_TRY(hipEventCreateWithFlags(&ev_stats.e, hipEventDisableTiming));
         AM_HIP_TRY(hipEventRecord(ev_stats.e, st));
     }
@@ -170,6 +178,10 @@ extern "C" int am_evaluate_f32(const float* ref, int64_t n_ref, int64_t ld_ref, 
                                                 stream)) != AM_OK)
                 return rc;
             radii[s] = r_out;
+            if ((what & AM_EVAL_FAD) && fad_place == 2 && ev_stats.e == nullptr) {
+                AM_HIP_TRY(hipEventCreateWithFlags(&ev_stats.e, hipEventDisableTiming));
+                AM_HIP_TRY(hipEventRecord(ev_stats.e, st));
+            }
         }
         if ((rc = am_prdc_counts_prepared_f32(ref, n_ref, ld_ref, &prep[0], cand, n_cand, ld_cand, &prep[1], D, radii[0], radii[1],
                                               L.col, L.rany, L.rcov, nullptr, L.ws_main, L.ws_main_bytes, stream)) != AM_OK)
@@ -188,15 +200,24 @@ extern "C" int am_evaluate_f32(const float* ref, int64_t n_ref, int64_t ld_ref, 
     // ---- Frechet blocks: enqueued LAST by the host (the caller's stream already holds the long kernels, so the GPU never
     //      waits for these launches), executed on the side stream as soon as the statistics exist
     if (what & AM_EVAL_FAD) {
-        AM_HIP_TRY(hipStreamWaitEvent(side, ev_stats.e, 0));
+        const bool serial = fad_place == 1;
+        if (!serial) {
+            if (ev_stats.e == nullptr) {                              // (place 2 without a k-NN entry in this call)
+                AM_HIP_TRY(hipEventCreateWithFlags(&ev_stats.e, hipEventDisableTiming));
+                AM_HIP_TRY(hipEventRecord(ev_stats.e, st));
+            }
+            AM_HIP_TRY(hipStreamWaitEvent(side, ev_stats.e, 0));
+        }
         const int block = am_frechet_first_block(), max_iter = 64;
         for (int first = 0; first < 2 * block; first += block)
             if ((rc = am_frechet_enqueue_f64(mean[1], cov[1], mean[0], cov[0], D, first, block, max_iter, 1e-13, L.fad_out,
-                                             L.ws_fad, L.fad_ws, side_stream)) != AM_OK)
+                                             L.ws_fad, L.fad_ws, serial ? stream : side_stream)) != AM_OK)
                 return rc;
-        AM_HIP_TRY(hipEventCreateWithFlags(&ev_fad.e, hipEventDisableTiming));
-        AM_HIP_TRY(hipEventRecord(ev_fad.e, side));
-        AM_HIP_TRY(hipStreamWaitEvent(st, ev_fad.e, 0));
+        if (!serial) {
+            AM_HIP_TRY(hipEventCreateWithFlags(&ev_fad.e, hipEventDisableTiming));
+            AM_HIP_TRY(hipEventRecord(ev_fad.e, side));
+            AM_HIP_TRY(hipStreamWaitEvent(st, ev_fad.e, 0));
+        }
     }
     hipLaunchKernelGGL(eval_pack_kernel, dim3(1), dim3(64), 0, st, L.fad_out, L.totals, out, what);
     AM_LAUNCH_CHECK();

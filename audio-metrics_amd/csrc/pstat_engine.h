@@ -48,6 +48,8 @@ constexpr int pstat_lds_words(int kslabs) { return PRING * PSTAGE_WORDS + pstat_
 // to (the engine sets it; in wide_engine.h it is a property of the wave), NT = 32-row P tiles per wave.
 struct PLane {
     static constexpr int NT = 1;
+    static constexpr int MT = 4;                      // 32-row Q tiles of a unit (accumulator tiles per P tile)
+    static constexpr int WAVES = 8;
     static constexpr int LISTS = 2;                   // partial per-row lists after the sweep: the two lane halves
     // The accumulators of a unit do not start at zero but at a per-COLUMN value the epilogue supplies (acc_init): the k-NN
     // sweep and the membership filter start them at -|y_j|^2 / 2 in the units of the scaled dot product, so that what comes out
@@ -223,6 +225,185 @@ __device__ __forceinline__ void pstat_pipeline(const float* __restrict__ Q, int6
                         L.wm = second ? 0 : 1;
 #pragma unroll
                         for (int m = 0; m < 4; ++m) acc[m][0] = epi.acc_init((u + 1) >> 1, m);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // the (empty) fetches past the end: nothing in flight when LDS is reused
+    __syncthreads();
+}
+
+// ---- the stationary engine for NARROW rows (round 6): KSLABS <= P64_MAX_SLABS, i.e. D <= 128 (VGGish, n_pca = 64 ...) -------------
+//
+// At D = 128 a unit of the engine above is two stages long and its epilogue (vector ALU, matrix pipe idle) is 55 % of the k-NN
+// sweep.  VERDICT r5 asked for the epilogue of one wave to run under the MFMAs of its SIMD partner.  What the
+// microbenchmark found (tools/ubench/pskew.hip, profiles/r6/ubench_pskew_v*.txt):
+//   * beside an OLDER wave that issues MFMAs a wave's vector instructions get about half their issue slots (s_setprio changes
+//     nothing; with the vector wave the older one both run at their own pace), and the chip sits at its power limit while the
+//     matrix pipe runs (1.5-1.65 GHz against 2.3 GHz in a vector-only phase): overlap buys cycles, the clock gives part back;
+//   * skewing waves 0-3 against 4-7 on ONE Q stream with ONE barrier per stage is slower than lockstep (the wave in its
+//     epilogue is alone on the vector ALU at ~5 cycles per instruction and every other wave waits for it at the barrier);
+//     LDS-flag synchronisation instead of s_barrier costs more than it frees;
+//   * what does pay where the registers allow it: TWO INDEPENDENT 256-thread workgroups per CU (own ring, own barriers - the two
+//     waves of a SIMD drift apart by themselves) whose waves own 64 P rows = TWO row tiles each, against 64-row Q units:
+//     every Q fragment read from LDS feeds two MFMAs (half the LDS reads per flop), the LDS-DMA bytes per flop stay those of
+//     the 512-thread form, 64 accumulator registers, and the P fragments of two row tiles (32 registers per slab) fit beside
+//     them up to two slabs.  Synthetic epilogue, us per 256 MFMAs of a CU: D = 128 3.17 -> 2.43 (epilogue of 4 passes), 3.75 ->
+//     2.98 (6 passes); D = 64 5.15 -> 4.49.
+// Same ring (four slots, three stages ahead, counted vmcnt, raw s_barrier), same LDS image and swizzle, same k order: the
+// accumulator values are those of pstat_pipeline, bit for bit.  A stage is 64 Q rows x 64 elements = 8 KB (two pieces per wave,
+// as above); a 256-row Q tile is four units (L.wm = 0 .. 3).
+constexpr int P64_THREADS = 256;
+constexpr int P64_QROWS = 64;
+constexpr int P64_STAGE_WORDS = P64_QROWS * WROW;    // 8 KB
+constexpr int P64_MAX_SLABS = 2;
+constexpr int pstat64_lds_words() { return PRING * P64_STAGE_WORDS; }
+
+struct P64Lane {
+    static constexpr int NT = 2;                      // 32-row P tiles per wave
+    static constexpr int MT = 2;                      // 32-row Q tiles of a unit
+    static constexpr int WAVES = 4;
+    static constexpr int LISTS = 2;
+    static constexpr bool ACC_INIT = true;
+    int tid, lane, wave, wm, r, h;
+    __device__ __forceinline__ P64Lane() {
+        tid = threadIdx.x;
+        lane = tid & 63;
+        wave = tid >> 6;
+        wm = 0;
+        r = lane & 31;
+        h = lane >> 5;
+    }
+    __device__ __forceinline__ int prow(int nt) const { return wave * 64 + nt * 32 + r; }
+    __device__ __forceinline__ int list_slot() const { return h; }
+};
+
+template <int KSLABS, class TileMap, class Epi>
+__device__ __forceinline__ void pstat64_pipeline(const float* __restrict__ Q, int64_t nq, int64_t ldq, const TileMap& tmap,
+                                                 const float* __restrict__ P, int64_t np, int64_t ldp, int64_t prow0, int ntiles,
+                                                 float* __restrict__ lds, P64Lane& L, Epi& epi) {
+    static_assert(KSLABS >= 1 && KSLABS <= P64_MAX_SLABS, "two row tiles of P fragments beside 64 accumulators");
+    static_assert(Epi::ACC_INIT, "the epilogues of this engine start their accumulators at the column norm");
+    constexpr int KSTEPS = KSLABS * 4;
+    constexpr int PIECES = 2;
+    constexpr int DEPTH = 3;
+    const int wave = __builtin_amdgcn_readfirstlane(L.wave);
+
+    // ---- the stationary operand: two row tiles
+    f32x4 pf[2][KSTEPS];
+    {
+        const TileRsrc prs = make_wide_rsrc(P, ldp, np, prow0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const unsigned vop = (unsigned)(((int64_t)(wave * 64 + nt * 32 + L.r) * ldp + L.h * 4) * 4);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s)
+                pf[nt][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs.rsrc, (int)vop, s * 32, 0));
+        }
+    }
+
+    // ---- Q slabs: piece p = 8 rows x 128 B; wave w fetches pieces 2 w, 2 w + 1 (rows 16 w .. 16 w + 15 of the unit's 64)
+    const int lr = L.lane >> 3, slot8 = L.lane & 7;
+    const unsigned voq0 = (unsigned)(((int64_t)lr * ldq + (slot8 ^ ((lr >> 1) & 7)) * 4) * 4);
+    const unsigned odd_soff = (unsigned)((int64_t)8 * ldq * 4);
+    const unsigned wave_soff = (unsigned)((int64_t)wave * 16 * ldq * 4), unit_soff = (unsigned)((int64_t)P64_QROWS * ldq * 4);
+    const int64_t q_tiles_total = (nq + WTB - 1) / WTB;
+    auto qtile_of = [&](int t) -> int64_t { return t < ntiles ? tmap(t) : q_tiles_total; };   // past the end: empty descriptor
+    int ft = 0, fq = 0, fk = 0, fslot = 0;            // (tile, quarter, slab, ring slot) of the stage being fetched
+    TileRsrc qrs = make_wide_rsrc(Q, ldq, nq, qtile_of(0) * WTB);
+    auto fetch_stage = [&](int i) {
+        float* dst = lds + fslot * P64_STAGE_WORDS + (wave * 2 + i) * 8 * WROW;
+        lds_direct_b128(qrs, dst, i == 0 ? voq0 : (voq0 ^ 64u), (unsigned)(fk * 128) + (unsigned)fq * unit_soff + wave_soff + (i == 0 ? 0u : odd_soff));
+    };
+    auto advance_fetch = [&]() {
+        fslot = (fslot + 1) & (PRING - 1);
+        if (++fk == KSLABS) {
+            fk = 0;
+            if (++fq == 4) {
+                fq = 0;
+                ++ft;
+                qrs = make_wide_rsrc(Q, ldq, nq, qtile_of(ft) * WTB);
+            }
+        }
+    };
+
+    const int sw = (L.r >> 1) & 7;
+    int coff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) coff[c] = L.r * WROW + ((2 * c + L.h) ^ sw) * 4;
+    auto qfrag = [&](int ring_slot, int c, int m) -> f32x4 {
+        return *reinterpret_cast<const f32x4*>(lds + ring_slot * P64_STAGE_WORDS + m * 32 * WROW + coff[c]);
+    };
+
+    f32x16 acc[2][2];
+
+#pragma unroll
+    for (int g = 0; g < DEPTH; ++g) {
+        fetch_stage(0);
+        fetch_stage(1);
+        advance_fetch();
+    }
+    epi.aux_issue(0, qtile_of(0));
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): side data (and the P fragments) are here
+    epi.aux_commit(0);
+    pstat_wait<0>();
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 q[2];
+    int slot = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) q[m] = qfrag(0, 0, m);
+    L.wm = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const f32x16 c0 = epi.acc_init(0, m);
+        acc[m][0] = c0;
+        acc[m][1] = c0;
+    }
+    const int units = 4 * ntiles;
+    for (int u = 0; u < units; ++u) {
+        const int t = u >> 2, quarter = u & 3;
+#pragma unroll
+        for (int ks = 0; ks < KSLABS; ++ks) {
+            const bool last_stage = ks == KSLABS - 1;
+            const int next_slot = (slot + 1) & (PRING - 1);
+            if (last_stage && quarter == 3 && t + 1 < ntiles) epi.aux_issue(t + 1, qtile_of(t + 1));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int step = ks * 4 + c;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, q[m]), __builtin_bit_cast(f16x8, pf[nt][step]),
+                                                                              acc[m][nt], 0, 0, 0);
+                    if (c < 3) q[m] = qfrag(slot, c + 1, m);
+                    else if (!last_stage) q[m] = qfrag(next_slot, 0, m);     // published by the barrier of the stage before
+                    if (m == 1 && (c & 1) == 0) fetch_stage(c >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            advance_fetch();
+            if (last_stage) {
+                L.wm = quarter;
+                epi.finish(t, qtile_of(t), acc);
+                if (quarter == 3 && t + 1 < ntiles) epi.aux_commit(t + 1);
+            }
+            pstat_wait<PIECES>();
+            __builtin_amdgcn_s_barrier();
+            slot = next_slot;
+            if (last_stage) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) q[m] = qfrag(slot, 0, m);
+                if (u + 1 < units) {
+                    L.wm = (u + 1) & 3;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const f32x16 c0 = epi.acc_init((u + 1) >> 2, m);
+                        acc[m][0] = c0;
+                        acc[m][1] = c0;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);

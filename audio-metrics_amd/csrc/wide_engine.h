@@ -39,6 +39,8 @@ constexpr int WENGINE_LDS_WORDS = 2 * WSTAGE_WORDS;   // two stages, 128 KB
 
 struct WLane {
     static constexpr int NT = 2;                      // 32-row P tiles per wave
+    static constexpr int MT = 4;                      // 32-row Q tiles per wave
+    static constexpr int WAVES = 8;
     static constexpr int LISTS = 4;                   // partial per-row lists after a sweep: Q half x lane half
     static constexpr bool ACC_INIT = false;
     int tid, lane, wave, wm, wn, r, h;

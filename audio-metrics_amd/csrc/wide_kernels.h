@@ -19,6 +19,7 @@ template <class Eng> constexpr size_t wide_cross_lds_bytes() { return (Eng::LDS_
 template <class Lane>
 struct CrossWideEpilogue {
     static constexpr int NT = Lane::NT;
+    static constexpr int MT = Lane::MT;               // 32-row Q tiles of a finish() call: L.wm counts units of MT * 32 columns
     // ACC_INIT (pstat_engine.h; the scheme of KnnFastEpilogue): accumulators start at |c_j|^2 / dsc, an element holds
     // a' = <r_i, c_j>' + |c_j|^2 / dsc and the approximate squared distance is dsc a' + |r_i|^2.  Row direction (thresholds of
     // the lane's own row): fma(dsc, max_j a'_j, |r_i|^2) against them; "any" direction (column thresholds T'_j + E'_j):
@@ -80,7 +81,7 @@ struct CrossWideEpilogue {
     // NEED_ANY = false: every row of this block already has its "any" witness - the column-threshold test (one subtraction
     // and half a min3 per accumulator element, and the threshold loads) is not compiled in
     __device__ __forceinline__ f32x16 acc_init(int t, int mt) const {
-        const float* a = aux + (t & 1) * 3 * WTB + L.wm * 128 + L.h * 4 + mt * 32;
+        const float* a = aux + (t & 1) * 3 * WTB + L.wm * (MT * 32) + L.h * 4 + mt * 32;
         f32x16 c;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -90,15 +91,15 @@ struct CrossWideEpilogue {
         return c;
     }
     template <bool WANT_MIN, bool NEED_ANY>
-    __device__ __forceinline__ void finish_impl(int t, int64_t qtile, f32x16 (&acc)[4][NT]) {
-        const float* a = aux + (t & 1) * 3 * WTB + L.wm * 128 + L.h * 4;
-        const int64_t jbase = qtile * WTB + L.wm * 128 + L.h * 4;
+    __device__ __forceinline__ void finish_impl(int t, int64_t qtile, f32x16 (&acc)[MT][NT]) {
+        const float* a = aux + (t & 1) * 3 * WTB + L.wm * (MT * 32) + L.h * 4;
+        const int64_t jbase = qtile * WTB + L.wm * (MT * 32) + L.h * 4;
 #ifdef AM_DEV_KNOBS
         if (g_wide_dbg & 2) return;                            // timing experiment: MFMA pipeline only
 #endif
         if constexpr (ACC_INIT) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 f32x4 ths[4];
                 if constexpr (NEED_ANY) {
 #pragma unroll
@@ -180,7 +181,7 @@ struct CrossWideEpilogue {
             return;
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             f32x4 yn[4], th[4];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -279,7 +280,7 @@ struct CrossWideShim {
     CrossWideEpilogue<Lane>& e;
     __device__ __forceinline__ void aux_issue(int t, int64_t q) { e.aux_issue(t, q); }
     __device__ __forceinline__ void aux_commit(int t) { e.aux_commit(t); }
-    __device__ __forceinline__ void finish(int t, int64_t q, f32x16 (&acc)[4][Lane::NT]) { e.template finish_impl<WANT_MIN, NEED_ANY>(t, q, acc); }
+    __device__ __forceinline__ void finish(int t, int64_t q, f32x16 (&acc)[Lane::MT][Lane::NT]) { e.template finish_impl<WANT_MIN, NEED_ANY>(t, q, acc); }
     static constexpr bool ACC_INIT = Lane::ACC_INIT;
     __device__ __forceinline__ f32x16 acc_init(int t, int mt) const { return e.acc_init(t, mt); }
 };
@@ -418,7 +419,7 @@ cross_wide_body(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const flo
     }
     __syncthreads();
     const int n = qn[0], base = qn[1];
-    for (int t = L.tid; t * 64 < n; t += WTHREADS) items[base + t] = make_uint2(blockIdx.x, (unsigned)(t * 64));
+    for (int t = L.tid; t * 64 < n; t += Lane::WAVES * 64) items[base + t] = make_uint2(blockIdx.x, (unsigned)(t * 64));
 }
 
 
@@ -427,7 +428,7 @@ cross_wide_body(const float* __restrict__ Rb, int64_t Nr, int64_t ldr, const flo
 template <class Eng> constexpr size_t knn_wide_lds_bytes() { return (Eng::LDS_WORDS + 8 * WTB) * sizeof(float) + 16; }   // + aux [2][2][256] + raw [2][2][256]
 
 template <int KCAP, class Lane>
-using KnnWideEpilogue = KnnFastEpilogue<KCAP, Lane, WTB, 4>;
+using KnnWideEpilogue = KnnFastEpilogue<KCAP, Lane, WTB, Lane::MT>;
 
 template <class Eng, int KCAP>
 __device__ __forceinline__ void
@@ -441,7 +442,12 @@ knn_wide_body(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float*
     Lane L;
     const int64_t T = (N + WTB - 1) / WTB;
     const SymWork sw = sym_work(T, win_tiles, nwin, per_win, part, nparts);
+    // The queue region of a 256-row workgroup is NW = 8 private sub-regions + a shared part (what the host sizes, zeroes and
+    // scatters: pairwise_fast.h).  An engine of four waves (pstat64) gives each wave SPW = 2 adjacent sub-regions as ONE private
+    // part and reports its fill as two counts.
     constexpr int NW = KnnWideEpilogue<KCAP, Lane>::NWAVES;
+    constexpr int SPW = NW / Lane::WAVES;
+    static_assert(SPW * Lane::WAVES == NW, "sub-regions per wave");
     if (sw.ntiles == 0 || (skip != nullptr && *skip != 0)) {      // (skip: the data-dependent fallback took over, pairwise_fast.h)
         if (region_counter == nullptr && L.tid <= NW) wgq_count[(int64_t)blockIdx.x * (NW + 1) + L.tid] = 0;
         return;
@@ -469,13 +475,14 @@ knn_wide_body(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float*
     epi.pblock = sw.pb;
     epi.aux = lds + Eng::LDS_WORDS;
     const int wave = __builtin_amdgcn_readfirstlane(L.wave);
-    epi.wcap = qcap / (2 * NW);                       // private sub-regions: half of the workgroup's region in all
+    const int wc1 = qcap / (2 * NW);                  // private sub-regions: half of the workgroup's region in all
+    epi.wcap = SPW * wc1;
     epi.wgq = wgq + region * qcap + wave * epi.wcap;
     epi.wgv = wgv + region * qcap + wave * epi.wcap;
     epi.wq = 0;
-    epi.shcap = qcap - NW * epi.wcap;                 // the shared part behind them
-    epi.shq = wgq + region * qcap + NW * epi.wcap;
-    epi.shv = wgv + region * qcap + NW * epi.wcap;
+    epi.shcap = qcap - NW * wc1;                      // the shared part behind them
+    epi.shq = wgq + region * qcap + NW * wc1;
+    epi.shv = wgv + region * qcap + NW * wc1;
     epi.qn = reinterpret_cast<int*>(lds + Eng::LDS_WORDS + 8 * WTB);
     if (L.tid == 0) *epi.qn = 0;                    // visible after the pipeline's first barrier
     epi.ovq = ovq;
@@ -508,7 +515,10 @@ knn_wide_body(const float* __restrict__ Xb, int64_t N, int64_t ldh, const float*
         for (int s = 0; s < KCAP; ++s) dst[s] = epi.best[nt][s];
     }
     __syncthreads();
-    if (L.lane == 0) wgq_count[region * (NW + 1) + wave] = min(epi.wq, epi.wcap);
+    if (L.lane == 0) {
+#pragma unroll
+        for (int sub = 0; sub < SPW; ++sub) wgq_count[region * (NW + 1) + wave * SPW + sub] = max(0, min(min(epi.wq, epi.wcap) - sub * wc1, wc1));
+    }
     if (L.tid == 0) wgq_count[region * (NW + 1) + NW] = min(*epi.qn, epi.shcap);
     if (L.tid < WTB) {
         const int64_t i = sw.pb * WTB + L.tid;

@@ -49,6 +49,8 @@ class AudioMetricsData:
         self._embeddings = None           # [n, D] view of self._buf (property `embeddings`): f32, or f64 once float64 rows came in
         self.radii = {}                   # "radii_{k}" -> [n] in the dtype of the rows
         self.dtype = torch.float64        # dtype of the statistics
+        self.stats_rows_dtype = None      # dtype of the rows the statistics were accumulated from (float32 once any float32 row came in;
+                                          # None: unknown, e.g. a loaded state) - metrics/fad.py warns about n <= D unless float64
         self._device = torch.device(device) if device is not None else None
         self._buf = None                  # [capacity, ld] f32 / f64, rows 16-B aligned
         self._mean_spare = None           # second mean buffer of the one-launch add (am_stats_push_f32 reads one, writes the other)
@@ -65,6 +67,14 @@ class AudioMetricsData:
         # any assignment - the class's own appends or a caller's - makes the cached PreparedSet (norms, f16 copy) stale
         self._embeddings = rows
         self._content_version += 1
+
+    def _note_rows_dtype(self, dtype):
+        """called BEFORE the rows are merged in: float64 only while every row so far was float64"""
+        first = not self.n
+        if dtype == torch.float64 and (first or self.stats_rows_dtype == torch.float64):
+            self.stats_rows_dtype = torch.float64
+        else:
+            self.stats_rows_dtype = torch.float32
 
     # ------------------------------------------------------------ plumbing
     @property
@@ -138,6 +148,7 @@ class AudioMetricsData:
         n = e.shape[0]
         if n == 0:
             raise ValueError("cannot add an empty batch of embeddings")
+        self._note_rows_dtype(torch.float32)
         f32_store = self._buf is None or self._buf.dtype == torch.float32      # (a float64 store takes the general path)
         if n <= ops.stats_push_max_rows() and f32_store and self._push(e):
             return
@@ -160,6 +171,7 @@ class AudioMetricsData:
         n = e.shape[0]
         if n == 0:
             raise ValueError("cannot add an empty batch of embeddings")
+        self._note_rows_dtype(torch.float64)
         mean, cov = ops.stats_f64(e)
         self._update_stats(mean, cov, n)
         if self.store_embeddings:
@@ -202,6 +214,7 @@ class AudioMetricsData:
         if rows is None:
             return
         self.n = int(rows.shape[0])
+        self.stats_rows_dtype = rows.dtype
         self.mean, self.cov = ops.stats(rows)
         if self.n < 2:
             # reference quirk kept on purpose: a (1, 1) zero matrix, not (D, D) (data.py:56)
@@ -287,6 +300,7 @@ class AudioMetricsData:
                 self.store_embeddings = other.store_embeddings
             elif self.store_embeddings != other.store_embeddings:
                 raise AssertionError("cannot merge a set that stores its embeddings with one that does not")
+            self._note_rows_dtype(other.stats_rows_dtype)          # (unknown counts as float32: the warning stays on)
             self._update_stats(other.mean.clone(), other.cov.clone(), other.n)
             if self.store_embeddings:
                 self._update_embeddings(other.embeddings)

@@ -463,6 +463,9 @@ def evaluate_single(ref, cand, metrics, nearest_k, ops, kid_subsets=KID_SUBSETS,
     n_ref, n_cand = ref.shape[0], cand.shape[0]
     if n_ref == 0 or n_cand == 0:
         raise ValueError(f"empty embedding set: {n_ref} reference and {n_cand} candidate rows over 1 ranks")
+    if "fad" in metrics:
+        from .metrics.fad import warn_if_rank_deficient
+        warn_if_rank_deficient(n_ref, n_cand, ref.shape[1], ref.dtype)
     idx1 = idx2 = None
     if "kd" in metrics:
         m = kid_subset_size
@@ -561,6 +564,9 @@ def evaluate_sharded(ref_local, cand_local, metrics=("fad", "kd", "prdc"), neare
     if n_ref == 0 or n_cand == 0:                          # the same error on every rank (all of them hold the totals)
         raise ValueError(f"empty embedding set: {n_ref} reference and {n_cand} candidate rows over {world} ranks")
     d = ref_local.shape[1]
+    if "fad" in metrics:
+        from .metrics.fad import warn_if_rank_deficient
+        warn_if_rank_deficient(n_ref, n_cand, d, ref_local.dtype)
     if c_entry and ref_local.dtype != torch.float64 and hasattr(ops, "evaluate_sharded_c"):
         return _evaluate_sharded_c(ref_local, cand_local, ref_counts, cand_counts, metrics, nearest_k, group, ops, kid_subsets,
                                    kid_subset_size, rng_seed)

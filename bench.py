@@ -252,6 +252,76 @@ def first_call(step, fence, samples=3):
                     "caching allocator (hipMalloc of ~1.2 GB + table draw and upload are inside)"}
 
 
+def process_cold_child(args):
+    """`bench.py --process-cold-child` (started by the parent BEFORE it touches the GPU): what a user's process pays for ONE
+    evaluate() - VERDICT r5 next-6.  Everything from interpreter start to the floats on the host, split by where it goes;
+    the sets are generated on the device (no upload).  Prints one JSON line."""
+    t_proc = float(os.environ.get("AM_BENCH_T0", "0")) or None
+    marks = [("python_start", time.perf_counter())]
+    import torch as th
+    marks.append(("import_torch", time.perf_counter()))
+    th.cuda.set_device(0)
+    th.zeros(1, device="cuda").add_(1)
+    th.cuda.synchronize()
+    marks.append(("hip_runtime_and_first_torch_kernel", time.perf_counter()))
+    import audio_metrics_amd as am
+    from audio_metrics_amd import hip_ops as ops
+    from audio_metrics_amd import distributed
+    from audio_metrics_amd.metrics import kd
+    am._lib.load()
+    marks.append(("import_package_and_dlopen_library", time.perf_counter()))
+    n, d, k = args.rows, args.dim, args.nearest_k
+    g = th.Generator(device="cuda").manual_seed(1234)
+    ref = th.randn(n, d, device="cuda", generator=g)
+    cand = th.randn(n, d, device="cuda", generator=g) * 1.05 + 0.05
+    th.cuda.synchronize()
+    marks.append(("sets_generated_on_device", time.perf_counter()))
+
+    def one():
+        t0 = time.perf_counter()
+        res = distributed.evaluate_single(ref, cand, ("fad", "kd", "prdc"), k, ops)
+        th.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, res
+
+    first_ms, res = one()                                # code objects, workspace hipMalloc, KD table, the step
+    kd._DEVICE_TABLES.clear()
+    ops.release_workspaces()
+    th.cuda.synchronize()
+    th.cuda.empty_cache()
+    realloc_ms, _ = one()                                # workspace + table again, code objects resident
+    warm_ms = min(one()[0] for _ in range(3))
+    phases = {name: (t - marks[i][1]) * 1e3 for i, (name, t) in enumerate(marks[1:])}
+    out = {"process_cold_ms": first_ms, "above_warm_step_ms": first_ms - warm_ms, "warm_step_ms": warm_ms,
+           "split_ms": {"first_launch_code_objects": first_ms - realloc_ms, "workspace_hipMalloc_and_kd_table": realloc_ms - warm_ms,
+                        "step": warm_ms},
+           "before_the_call_ms": phases,
+           "interpreter_start_to_first_result_ms": ((time.time() - t_proc) * 1e3 if t_proc else None),
+           "what": "a FRESH process: import torch, HIP runtime, import the package + dlopen the library, sets generated on the "
+                   "device, then ONE evaluate() (am_evaluate_f32) timed to the floats on the host; the split comes from a "
+                   "second call after releasing the workspace / KD table / allocator cache and a third, warm one",
+           "fad": res["fad"], "precision": res["precision"]}
+    print(json.dumps(out), flush=True)
+
+
+def process_cold(argv_tail):
+    """Runs process_cold_child in a child process and returns its record (None + reason on failure).  Called before the parent
+    initialises the GPU; the child has the device to itself."""
+    import subprocess
+    env = dict(os.environ, AM_BENCH_T0=repr(time.time()))
+    cmd = [sys.executable, os.path.abspath(__file__), "--process-cold-child", *argv_tail]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    except subprocess.TimeoutExpired:
+        return {"error": "child timed out"}
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {"error": "no record", "returncode": r.returncode, "stderr_tail": r.stderr[-400:]}
+
+
 def timed_steps(step, fence, steps, warmup):
     for _ in range(warmup):
         result = step()
@@ -276,6 +346,8 @@ def main():
                     help="randn: SURVEY 8(d) C3 sets; clap: unit-norm rows with offsets 0.5 / 0.55 (CLAP-shaped)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-process-cold", action="store_true", help="skip the fresh-process time-to-first-result child")
+    ap.add_argument("--process-cold-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pairs", type=int, default=2000, help="--config e2e: audio pairs per side")
     ap.add_argument("--c-entry", action="store_true",
                     help="N > 1: every rank's step is ONE library call (am_evaluate_sharded_f32 with hooks over the process "

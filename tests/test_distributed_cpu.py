@@ -203,10 +203,16 @@ def _hooks_worker(rank, world, port, out_q):
     ws[1024 + offs[rank]:1024 + offs[rank] + sizes[rank]] = rank + 10
     arr = (ctypes.c_int64 * world)(*sizes)
     assert coll.struct.all_gather_v(None, base + 1024 + offs[rank], base + 1024, arr, None) == 0
+    forms = [coll.gather_form]
+    # ... and equal shares: ONE all_gather_into_tensor into the caller's buffer (in place on RCCL; gloo takes the own share from a copy)
+    ws[2048 + 16 * rank:2048 + 16 * (rank + 1)] = rank + 50
+    arr_eq = (ctypes.c_int64 * world)(*([16] * world))
+    assert coll.struct.all_gather_v(None, base + 2048 + 16 * rank, base + 2048, arr_eq, None) == 0
+    forms.append(coll.gather_form)
     # a pointer outside every exposed tensor is an error code, not an exception through the C frames
     assert coll.struct.all_reduce_sum(None, base + 4096, 4, COLL_F64, None) == 1 and coll.error is not None
     out_q.put((rank, ws[256:296].view(torch.float64).tolist(), ws[512:524].view(torch.int32).tolist(),
-               ws[1024:1024 + sum(sizes)].tolist(), [name for name, _ in coll.calls]))
+               ws[1024:1024 + sum(sizes)].tolist(), [name for name, _ in coll.calls], ws[2048:2048 + 16 * world].tolist(), forms))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -226,8 +232,10 @@ def test_collective_hooks_over_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     sizes = [7 + 5 * r for r in range(world - 1)] + [0]
-    for rank, f64, i32, gathered, names in got:
+    for rank, f64, i32, gathered, names, gathered_eq, forms in got:
         assert f64 == [float(3 * i + 0 + 1 + 2) for i in range(5)]
         assert i32 == [6, 12, 18]
         assert gathered == [r + 10 for r in range(world) for _ in range(sizes[r])]
-        assert names == ["all_reduce_sum", "all_reduce_sum", "all_gather_v", "all_reduce_sum"]
+        assert names == ["all_reduce_sum", "all_reduce_sum", "all_gather_v", "all_gather_v", "all_reduce_sum"]
+        assert gathered_eq == [r + 50 for r in range(world) for _ in range(16)]
+        assert forms == ["broadcast per rank, in place", "all_gather_into_tensor, own share copied"]

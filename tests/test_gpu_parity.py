@@ -525,6 +525,28 @@ def test_fad_vs_golden(am, golden, name):
         assert np.abs(f64_values - fad).max() <= 1e-6 * abs(fad) + slack          # = the reference fed float64 rows
 
 
+def test_fad_warns_when_rows_do_not_exceed_dimensions(am):
+    """n <= D on float32 rows is where the reference's own value moves by up to 1.5e-4 with its add() batch
+    size and by 2.6e-4 / 3.6e-4 between f32 and f64 rows (profiles/r6/fad_f32_probe.txt, reference fad.py:28-31 + data.py:44);
+    the build returns the dust-free value and says so - once per call, for float32-derived statistics only."""
+    import warnings
+    for name, (kind, seed, nr, nc, d) in gi.FAD_CASES.items():
+        ref, cand = gi.pair(kind, seed, nr, nc, d)
+        a, b = amd_of(am, cand, False), amd_of(am, ref, False)
+        if min(nr, nc) <= d:
+            with pytest.warns(RuntimeWarning, match="no more rows than dimensions") as rec:
+                am.frechet_distance(a, b)
+            assert len([w for w in rec if issubclass(w.category, RuntimeWarning)]) == 1
+            a64, b64 = amd_of(am, cand.astype(np.float64), False), amd_of(am, ref.astype(np.float64), False)
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                am.frechet_distance(a64, b64)                                # float64 rows: no dust, no warning
+        else:
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                am.frechet_distance(a, b)
+
+
 def test_fad_properties(am):
     x, y = gi.pair("randn", 71, 5000, 5000, 128)
     a, b = amd_of(am, x, False), amd_of(am, y, False)

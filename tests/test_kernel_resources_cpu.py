@@ -71,6 +71,12 @@ def test_operand_stationary_kernels_do_not_spill():
     assert len(kernels) == 32, sorted(usage)
     for n, u in kernels.items():
         assert u["VGPRs"] <= 256 and u["occupancy"] >= 2 and u["scratch"] == 0, (n, u)
+    # round 6: the 256-thread form for rows of up to two slabs (D <= 128) - TWO workgroups per CU, so again two waves per SIMD:
+    # 64 accumulators + the P fragments of two row tiles (32 registers per slab) + the epilogue
+    narrow = {n: u for n, u in usage.items() if "pstat64_kernel" in n}
+    assert len(narrow) == 8, sorted(usage)
+    for n, u in narrow.items():
+        assert u["VGPRs"] <= 256 and u["occupancy"] >= 2 and u["scratch"] == 0, (n, u)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
