@@ -19,6 +19,9 @@ class TorchCollectives:
         active = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if active else 0
         self.world = dist.get_world_size(group) if active else 1
+        # a group of ONE rank still runs its collectives for real when asked to (tests: everything of the RCCL path but the wire)
+        self.force = False
+        self._active = active
         self._tensors = []
         self.error = None
         self.calls = []                                     # (name, bytes) of every hook call, in issue order
@@ -55,7 +58,7 @@ class TorchCollectives:
         try:
             dt, size = (torch.float64, 8) if dtype == COLL_F64 else (torch.int32, 4)
             self.calls.append(("all_reduce_sum", count * size))
-            if self.world == 1:
+            if self.world == 1 and not (self.force and self._active):
                 return 0
             view = self._view(buf, count * size).view(dt)
             with self._on(stream, view.device):
@@ -69,7 +72,7 @@ class TorchCollectives:
         try:
             sizes = [int(bytes_per_rank[r]) for r in range(self.world)]
             self.calls.append(("all_gather_v", sum(sizes)))
-            if self.world == 1 or sum(sizes) == 0:
+            if (self.world == 1 and not (self.force and self._active)) or sum(sizes) == 0:
                 return 0
             whole = self._view(recv, sum(sizes))
             offs = [sum(sizes[:r]) for r in range(self.world)]

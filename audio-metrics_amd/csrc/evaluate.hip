@@ -463,16 +463,18 @@ extern "C" int am_evaluate_sharded_f32(const float* ref_local, int64_t ld_ref, c
     if (need_full) {
         for (int s = 0; s < 2; ++s) {
             if (nl[s] == 0) continue;
-            if (ld[s] == L.ldf)                                 // one contiguous copy (a pitched device-to-device copy of 100 000
-                AM_HIP_TRY(hipMemcpyAsync(L.full[s] + lo[s] * L.ldf, X[s], (size_t)nl[s] * L.ldf * sizeof(float),     // rows took 35 ms)
+            // ld == ldf: one contiguous copy (a pitched device-to-device copy of 100 000 rows took 35 ms) of everything up to the
+            // LAST row's D-th element - the header promises ld % 4 == 0 and 16-byte alignment, not a padded final row
+            if (ld[s] == L.ldf)
+                AM_HIP_TRY(hipMemcpyAsync(L.full[s] + lo[s] * L.ldf, X[s], ((size_t)(nl[s] - 1) * L.ldf + (size_t)D) * sizeof(float),
                                           hipMemcpyDeviceToDevice, st));
             else
                 AM_HIP_TRY(hipMemcpy2DAsync(L.full[s] + lo[s] * L.ldf, (size_t)L.ldf * sizeof(float), X[s], (size_t)ld[s] * sizeof(float),
                                             (size_t)D * sizeof(float), (size_t)nl[s], hipMemcpyDeviceToDevice, st));
         }
-        if (L.ldf != D)                                         // (padding columns of the gathered copies: never read as data)
-            for (int s = 0; s < 2; ++s)
-                if (nl[s] > 0 && ld[s] != L.ldf)
+        if (L.ldf != D)                                         // padding columns of the gathered copies: zero in BOTH forms (never
+            for (int s = 0; s < 2; ++s)                         // read as data; the caller's padding is not propagated to other ranks)
+                if (nl[s] > 0)
                     AM_HIP_TRY(hipMemset2DAsync(L.full[s] + lo[s] * L.ldf + D, (size_t)L.ldf * sizeof(float), 0,
                                                 (size_t)(L.ldf - D) * sizeof(float), (size_t)nl[s], st));
         if ((rc = start_gather(0)) != AM_OK) return rc;

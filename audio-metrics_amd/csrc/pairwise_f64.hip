@@ -146,6 +146,17 @@ __device__ __forceinline__ double threshold_of_radius64(double R) {
     if (isinf(R)) return R;
     double c = R * R;
     if (isinf(c)) c = 1.7976931348623157e308;
+    if (c < 1.0e-290) {
+        // R * R in or near the subnormal range (R below ~1e-145: radii of near-duplicate rows): its rounding error is many ulps
+        // of the result and the 8-step walk below could not reach T(R).  sqrt_rn is monotone and, for 0 < R < 1, sqrt_rn(R) >= R:
+        // bisect the bit pattern of t over [0, R] (positive doubles order like their bit patterns).
+        long long lo = 0, hi = __double_as_longlong(R);            // sqrt(lo) = 0 < R <= sqrt(hi)
+        while (hi - lo > 1) {
+            const long long mid = lo + (hi - lo) / 2;
+            if (__dsqrt_rn(__longlong_as_double(mid)) >= R) hi = mid; else lo = mid;
+        }
+        return __longlong_as_double(hi);
+    }
     for (int it = 0; it < 8; ++it) {                               // walk down while the predecessor still reaches R
         const double p = __longlong_as_double(__double_as_longlong(c) - 1);
         if (c > 0.0 && __dsqrt_rn(p) >= R) c = p; else break;

@@ -46,6 +46,7 @@ def _world(group):
 # (all_gather_into_tensor, asynchronous work handles, the ordering of the communication stream against the compute and
 # side streams) is executed before the first multi-GPU run.  Never set by the product.
 COLLECTIVES_AT_WORLD_ONE = False
+LAST_C_ENTRY_COLLECTIVES = None
 
 
 def _alone(world):
@@ -511,6 +512,9 @@ def _evaluate_sharded_c(ref_local, cand_local, ref_counts, cand_counts, metrics,
             m = max(1, min(n_ref, n_cand) // 2)
         idx1, idx2 = device_subset_indices(n_cand, n_ref, kid_subsets, m, rng_seed, ref_local.device)     # features_1 = candidate
     coll = TorchCollectives(group)
+    coll.force = COLLECTIVES_AT_WORLD_ONE              # (test hook: a group of one rank runs its collectives for real)
+    global LAST_C_ENTRY_COLLECTIVES
+    LAST_C_ENTRY_COLLECTIVES = coll                    # which torch.distributed calls the hooks became (tests, bench)
     head, mmds = ops.evaluate_sharded_c(ref_local, cand_local, ref_counts, cand_counts, metrics, coll, nearest_k, idx1, idx2,
                                         None, KID_COEF0, KID_DEGREE)
     if "fad" in metrics:

@@ -252,6 +252,13 @@ def test_bench_multi_rank_launch(ranks, rows, dim, plain):
     for key in ("metric", "value", "unit", "ms_per_step", "scaling", "roofline", "config"):
         assert key in out2
     assert out2["roofline"]["frac"] > 0
+    # a multi-rank line carries BOTH exchange schedules (the first 8-GPU run then says which is faster),
+    # a one-rank line the fresh-process time to the first result
+    assert out2["c_entry_ms"] > 0 and out2["python_schedule_ms"] > 0, sorted(out2)
+    assert (out2["c_entry_ms"] if plain == "c-entry" else out2["python_schedule_ms"]) == out2["ms_per_step"]
+    cold = out1["process_cold"]
+    assert "error" not in cold, cold
+    assert cold["process_cold_ms"] >= cold["warm_step_ms"] > 0 and set(cold["split_ms"]) == {"first_launch_code_objects", "workspace_hipMalloc_and_kd_table", "step"}
     if rows >= 8192 and dim >= 128:
         tiles = [out2["roofline"], out2["other_tile_kernel"]]
         assert any(t["entry_point"] in ("am_knn_sym_part_f32", "am_knn_sym_part_prepared_f32") for t in tiles)
@@ -321,6 +328,11 @@ for name, rows, dim, k in (("small", 2500, 96, 4), ("partitioned", 33000, 128, 5
             got = D.evaluate_sharded(ref, cand, nearest_k=k, kid_subsets=8, kid_subset_size=300)
             out[f"{name}_{comms}c_{rep}"] = {"want": want, "got": got}
     D.disable_bulk_communicator()
+    # the one-call-per-rank form (am_evaluate_sharded_f32) with its hooks over THIS RCCL group: equal shares -> ONE
+    # all_gather_into_tensor per row gather, in place in the library's buffer (VERDICT r5 next-5a)
+    got_c = D.evaluate_sharded(ref, cand, nearest_k=k, kid_subsets=8, kid_subset_size=300, c_entry=True)
+    coll = D.LAST_C_ENTRY_COLLECTIVES
+    out[f"{name}_c_entry"] = {"want": want, "got": got_c, "gather_form": coll.gather_form, "calls": [n_ for n_, _ in coll.calls]}
     # the stats-only front end: (n, mean, cov) triples through the all-gather
     data = am.AudioMetricsData(store_embeddings=False); data.add(ref)
     merged = D.merged_stats(data)
@@ -360,6 +372,8 @@ def test_collectives_over_rccl_in_a_group_of_one():
             assert rec["n"] in (2500, 33000) and rec["mean_diff"] == 0.0 and rec["cov_diff"] == 0.0, (name, rec)
             continue
         want, got = rec["want"], rec["got"]
+        if name.endswith("_c_entry"):
+            assert rec["gather_form"] == "all_gather_into_tensor, in place" and rec["calls"].count("all_gather_v") == 2, rec
         for key in ("precision", "recall", "density", "coverage"):
             assert got[key] == want[key], (name, key)
         assert abs(got["fad"] - want["fad"]) <= 1e-5 * abs(want["fad"]), (name, got["fad"], want["fad"])

@@ -269,3 +269,21 @@ def test_f64_filter_routes_with_values_float32_cannot_hold(am, bad):
     r2 = ops.knn_radii(yd, 4)
     got, want = ops.prdc_counts(xd, yd, r, r2), ops.prdc_counts(xd, yd, r, r2, want_min=True)
     assert all(torch.equal(a, b) for a, b in zip(got, want[:3]))
+
+
+def test_f64_thresholds_of_radii_whose_square_underflows(am):
+    """ADVICE r5 (pairwise_f64.hip: threshold_of_radius64): the strict `sqrt(d2) < R` of the reference (prdc.py:34-48) becomes
+    `d2 < T(R)`, T(R) = min{t : sqrt_rn(t) >= R}.  For R below ~1.5e-154 R * R is subnormal or zero: T(R) is then found by
+    bisection over the bit patterns.  Rows on an axis at 0, 1e-160, 3e-160, 1e-170, 1e-150: squared distances to the origin
+    1e-320 (subnormal), 9e-320, 0 (1e-340 underflows, as it does in torch), 1e-300 - tested against radii on both sides of
+    every one of them, the expectation written down from the definition."""
+    ops = am.hip_ops
+    ref = dev(np.array([[0.0, 0.0]], dtype=np.float64))
+    axis = np.array([0.0, 1e-160, 3e-160, 1e-170, 1e-150])
+    cand = dev(np.stack([axis, np.zeros_like(axis)], axis=1))
+    r_cand = dev(np.full(len(axis), 1e-3))
+    for radius in (2e-160, 0.5e-160, 1e-160, 3.5e-160, 1e-165, 5e-151, 2e-150, 1e-200, 4.9e-324):
+        d2 = axis * axis                                                     # what the device's |x|^2 + |y|^2 - 2 <x, y> gives here
+        want = (np.sqrt(d2) < radius).astype(np.int32)
+        col, rany, rcov = ops.prdc_counts(ref, cand, dev(np.array([radius])), r_cand)
+        assert col.cpu().numpy().tolist() == want.tolist(), (radius, col.cpu().numpy(), want)

@@ -17,22 +17,16 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import route_probe  # noqa: E402
 from audio_metrics_amd import hip_ops as ops  # noqa: E402
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-ops.filter_stats_enable("cuda:0", True)
-bad = 0
-for case in range(n_cases):
-    fam = rnd.choice(["randn", "unit", "clustered", "scales", "lowrank", "dups", "silence", "hub", "sparse", "tiny", "huge"])
-    rows = rnd.choice([16500, 20000, 24001, 33000, 40000, 52000])
-    rows2 = rnd.choice([rows, rows, max(9000, rows // 2), 16400])
-    dim = rnd.choice([8, 16, 33, 64, 67, 96, 128, 200])
-    k = rnd.choice([1, 3, 5, 10])
-    seed = rnd.randrange(1000)
+
+
+def run_case(fam, rows, rows2, dim, k, seed, factor=1.0):
+    """One case: (radii ok, counts ok, text).  factor: both sets multiplied by it AFTER the float64 perturbation (ADVICE r5:
+    1e-30 ... 1e30 - past float32's range the filter route must hand the call to the general kernels, not lose memberships)."""
     g = torch.Generator(device="cuda").manual_seed(seed)
     x = route_probe.make(fam, rows, dim, seed).double()
     y = route_probe.make(fam, rows2, dim, seed + 100).double()
-    x = x * (1.0 + 1e-9 * torch.randn(x.shape, generator=g, device="cuda", dtype=torch.float64))
-    y = y * (1.0 + 1e-9 * torch.randn(y.shape, generator=g, device="cuda", dtype=torch.float64))
+    x = x * (1.0 + 1e-9 * torch.randn(x.shape, generator=g, device="cuda", dtype=torch.float64)) * factor
+    y = y * (1.0 + 1e-9 * torch.randn(y.shape, generator=g, device="cuda", dtype=torch.float64)) * factor
     ops.filter_stats_read("cuda:0")
     r = ops.knn_radii(x, k)
     s_knn = ops.filter_stats_read("cuda:0")
@@ -74,12 +68,34 @@ for case in range(n_cases):
             dist = (y - x[i]).square().sum(1).sqrt()
             ok_c = ok_c and bool((dist < r2).any()) == bool(got[1][i]) and bool((dist < r[i]).any()) == bool(got[2][i])
         recount = int(cols.numel() + rows_d.numel())
-    line = (f"case {case}: {fam} rows={rows}/{rows2} dim={dim} k={k} seed={seed} | radii {'ok' if ok_r else 'MISMATCH'} "
+    line = (f"{fam} rows={rows}/{rows2} dim={dim} k={k} seed={seed} factor={factor:g} | radii {'ok' if ok_r else 'MISMATCH'} "
             f"(filter route {s_knn['knn_calls']}, fallback rows {s_knn['knn_fallback_rows']}, worst err/bound {float((err / bound).max()):.2e}"
             f"{', ' + str(noisy) + ' near-duplicate rows checked against a difference-form recomputation' if noisy else ''}) | "
             f"counts {'ok' if ok_c else 'MISMATCH'} (filter route {s_cnt['prdc_calls']}, fallback {s_cnt['prdc_fallback_calls']}"
             f"{', ' + str(recount) + ' entries where the general kernel differs recounted from differences' if recount else ''})")
-    print(line, flush=True)
-    bad += (not ok_r) + (not ok_c)
-print(f"mismatches: {bad}")
-sys.exit(1 if bad else 0)
+    return ok_r, ok_c, line
+
+
+FAMILIES = ["randn", "unit", "clustered", "scales", "lowrank", "dups", "silence", "hub", "sparse", "tiny", "huge"]
+
+
+def draw_case(rnd, rows_choices=(16500, 20000, 24001, 33000, 40000, 52000)):
+    fam = rnd.choice(FAMILIES)
+    rows = rnd.choice(list(rows_choices))
+    rows2 = rnd.choice([rows, rows, max(9000, rows // 2), 16400])
+    dim = rnd.choice([8, 16, 33, 64, 67, 96, 128, 200])
+    k = rnd.choice([1, 3, 5, 10])
+    return fam, rows, rows2, dim, k, rnd.randrange(1000)
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    ops.filter_stats_enable("cuda:0", True)
+    bad = 0
+    for case in range(n_cases):
+        ok_r, ok_c, line = run_case(*draw_case(rnd))
+        print(f"case {case}: {line}", flush=True)
+        bad += (not ok_r) + (not ok_c)
+    print(f"mismatches: {bad}")
+    sys.exit(1 if bad else 0)
