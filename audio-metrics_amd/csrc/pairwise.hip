@@ -1406,7 +1406,7 @@ __global__ void __launch_bounds__(256) narrow64_kernel(const double* __restrict_
 }
 
 bool prdc64_filter_eligible(int64_t Nr, int64_t Nc, int D) {
-    return Nr >= 1 && Nc >= 1 && cross_fast_enabled(Nr, Nc, D) && plan_cross_fast(Nr, Nc).wide;
+    return Nr >= 1 && Nc >= 1 && cross_fast_enabled(Nr, Nc, D) && plan_cross_fast(Nr, Nc, D).wide;
 }
 
 struct Prdc64Layout {
@@ -1426,7 +1426,7 @@ static bool prdc64_layout(Carver& c, int64_t Nr, int64_t Nc, int D, Prdc64Layout
     L.cn = c.take<float>(Nc);
     L.ct = c.take<float>(Nc);
     L.rmin = c.take<unsigned>(Nr);
-    L.plan = plan_cross_fast(Nr, Nc);
+    L.plan = plan_cross_fast(Nr, Nc, D);
     L.buf = carve_cross_fast(c, Nr, Nc, D, L.plan);
     L.total = c.off;
     return c.ok();
@@ -1515,7 +1515,7 @@ extern "C" int am_knn_path(int64_t N, int64_t M, int D, int k, int self) {
 extern "C" int am_prdc_path(int64_t Nr, int64_t Nc, int D) {
     if (Nr < 1 || Nc < 1 || D < 1) return -1;
     if (!cross_fast_enabled(Nr, Nc, D)) return 0;
-    return plan_cross_fast(Nr, Nc).wide ? 3 : 2;
+    return plan_cross_fast(Nr, Nc, D).wide ? 3 : 2;
 }
 
 // which of the two 256-row engines multiplies the tiles of a path-3 filter pass for rows of D elements (benchmark support:
@@ -1755,7 +1755,7 @@ extern "C" size_t am_prdc_workspace_bytes(int64_t Nr, int64_t Nc, int D) {
     c.take<float>(Nc); c.take<float>(Nc);          // |c|^2, T(r_cand)
     c.take<unsigned>(Nr); c.take<unsigned>(Nr);    // row_min bits, row_any words
     c.take<unsigned>(Nr);                          // row_cover words
-    if (cross_fast_enabled(Nr, Nc, D)) carve_cross_fast(c, Nr, Nc, D, plan_cross_fast(Nr, Nc));
+    if (cross_fast_enabled(Nr, Nc, D)) carve_cross_fast(c, Nr, Nc, D, plan_cross_fast(Nr, Nc, D));
     return c.off;
 }
 
@@ -1780,7 +1780,7 @@ static int prdc_counts_impl(const float* R, int64_t Nr, int64_t ldr, const float
     CrossFastPlan fplan{};
     CrossFastBuffers fbuf{};
     if (fast) {
-        fplan = plan_cross_fast(Nr, Nc);
+        fplan = plan_cross_fast(Nr, Nc, D);
         fbuf = carve_cross_fast(c, Nr, Nc, D, fplan);
     }
     AM_REQUIRE(c.ok(), AM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", c.off, ws_bytes);

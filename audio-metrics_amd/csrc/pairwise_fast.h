@@ -757,7 +757,7 @@ struct CrossFastPlan {
     bool wide;                  // main pass on the 256 x 256 engine (cross_wide_kernel)
 };
 
-static CrossFastPlan plan_cross_fast(int64_t Nr, int64_t Nc) {
+static CrossFastPlan plan_cross_fast(int64_t Nr, int64_t Nc, int D) {
     CrossFastPlan p;
     p.nchunks = choose_chunks(Nr, Nc);
     static const int grp = env_int("AM_FAST_GROUP_ROWS", 8);                     // 0: plain (row block, chunk) order
@@ -766,7 +766,13 @@ static CrossFastPlan plan_cross_fast(int64_t Nr, int64_t Nc) {
     static const int wide = env_int("AM_FAST_WIDE", 1);
     p.wide = wide != 0;
     if (p.wide) {
-        static const int wgrp = env_int("AM_WIDE_GROUP_ROWS", 8);
+        // Row blocks of a group (the 32 workgroups of an XCD = grp_rows row blocks x 32 / grp_rows column chunks).  wide_engine.h
+        // streams the P blocks too: eight of them (2 MB of f16) stay in an XCD's L2 beside the Q window.  The stationary
+        // engines hold P in registers - the L2 only serves Q - so ALL 32 workgroups walk ONE column chunk: every Q tile is
+        // fetched once per 32 row blocks instead of once per 8 (100 000 x 512: 9.22 / 8.87 / 8.79 / 8.54 ms per launch at
+        // 4 / 8 / 16 / 32, CLAP-shaped k = 10 10.56 -> 10.14; D = 128 flat; profiles/r6/wide_bench_cross_group.txt).
+        static const int wgrp_env = env_int("AM_WIDE_GROUP_ROWS", 0);
+        const int wgrp = wgrp_env > 0 ? wgrp_env : (wide_stationary((int)(half_ld(D) / 2)) ? 32 : 8);
         static const int wtarget = env_int("AM_WIDE_WG_TARGET", 6144);               // ~24 rounds of 256 CUs x 1 workgroup
         p.grp_rows = (wgrp == 1 || wgrp == 2 || wgrp == 4 || wgrp == 8 || wgrp == 16 || wgrp == 32) ? wgrp : 8;
         const int grp_chunks = 32 / p.grp_rows;

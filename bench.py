@@ -256,10 +256,11 @@ def process_cold_child(args):
     """`bench.py --process-cold-child` (started by the parent BEFORE it touches the GPU): what a user's process pays for ONE
     evaluate() - VERDICT r5 next-6.  Everything from interpreter start to the floats on the host, split by where it goes;
     the sets are generated on the device (no upload).  Prints one JSON line."""
-    t_proc = float(os.environ.get("AM_BENCH_T0", "0")) or None
-    marks = [("python_start", time.perf_counter())]
+    t_proc = float(os.environ.get("AM_BENCH_T0", "0")) or None        # the parent's clock right before it started this process
+    # (bench.py imports torch at module level: interpreter start + `import torch` + numpy lie between t_proc and this line)
+    marks = [("t0", time.perf_counter())]
+    startup_ms = (time.time() - t_proc) * 1e3 if t_proc else None
     import torch as th
-    marks.append(("import_torch", time.perf_counter()))
     th.cuda.set_device(0)
     th.zeros(1, device="cuda").add_(1)
     th.cuda.synchronize()
@@ -294,7 +295,7 @@ def process_cold_child(args):
     out = {"process_cold_ms": first_ms, "above_warm_step_ms": first_ms - warm_ms, "warm_step_ms": warm_ms,
            "split_ms": {"first_launch_code_objects": first_ms - realloc_ms, "workspace_hipMalloc_and_kd_table": realloc_ms - warm_ms,
                         "step": warm_ms},
-           "before_the_call_ms": phases,
+           "before_the_call_ms": dict({"interpreter_start_and_import_torch": startup_ms}, **phases),
            "interpreter_start_to_first_result_ms": ((time.time() - t_proc) * 1e3 if t_proc else None),
            "what": "a FRESH process: import torch, HIP runtime, import the package + dlopen the library, sets generated on the "
                    "device, then ONE evaluate() (am_evaluate_f32) timed to the floats on the host; the split comes from a "
@@ -360,7 +361,10 @@ def main():
         process_cold_child(args)
         return
     cold = None
-    if args.gpus == 1 and args.config == "evaluate" and not args.no_process_cold and "WORLD_SIZE" not in os.environ:
+    # (never under a profiler: its preloaded library has initialised the GPU in THIS process already, and starting another
+    # program from a process that holds the GPU is what this pool forbids)
+    profiled = any(key.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for key in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if args.gpus == 1 and args.config == "evaluate" and not args.no_process_cold and "WORLD_SIZE" not in os.environ and not profiled:
         # a fresh process's ONE evaluate(), measured in a child BEFORE this process initialises the GPU (the child has the device
         # to itself; a child, never an exec)
         cold = process_cold(["--rows", str(args.rows), "--dim", str(args.dim), "--nearest-k", str(args.nearest_k)])

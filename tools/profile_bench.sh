@@ -14,7 +14,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 STAMP=audio-metrics_amd/lib/libaudio_metrics_hip.so.stamp.json
 cp "$STAMP" "$OUT/library.stamp.json"
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants $*"
+ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-process-cold $*"
 echo "$ARGS" > "$OUT/command.txt"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- python3 $ARGS > "$OUT/trace_stdout.log" 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT \
