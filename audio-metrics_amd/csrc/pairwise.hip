@@ -1523,7 +1523,8 @@ extern "C" int am_prdc_path(int64_t Nr, int64_t Nc, int D) {
 // (knn_pstat_kernel / cross_pstat_kernel)
 extern "C" int am_filter_engine(int D) {
     if (D < 1) return 0;
-    return wide_stationary((int)(half_ld(D) / 2)) ? 1 : 0;
+    const int Dh = (int)(half_ld(D) / 2);
+    return wide_stationary(Dh) ? (pstat64_supported(Dh) ? 2 : 1) : 0;
 }
 
 // ---- partitioned symmetric k-NN (multi-GPU; every rank holds the full set) --------------------------

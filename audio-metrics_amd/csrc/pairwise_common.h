@@ -436,6 +436,7 @@ int launch_knn_wide(int kcap, unsigned nwg, const float* Xb, int64_t N, int64_t 
 
 // ---- the same two kernels on the operand-stationary engine (pairwise_pstat.hip, pstat_engine.h): rows of up to 512 f16
 bool pstat_supported(int Dh);
+bool pstat64_supported(int Dh);              // ... in its 256-thread form (rows of up to two slabs: D <= 128)
 int launch_cross_pstat(bool want_min, unsigned blocks, const float* Rb, int64_t Nr, int64_t ldr, const float* rnorm, const float* rthr,
                        const float* Cb, int64_t Nc, int64_t ldc, const float* cnorm, const float* cthr, int Dh, int nchunks,
                        int grp_rows, const unsigned* maxn, unsigned* rmin_approx, unsigned* row_any, unsigned* row_cover,

@@ -96,6 +96,7 @@ static hipError_t set_pstat_dev_symbols(hipStream_t st) {
 
 // rows of Dh words (Dh % 32 == 0): the stationary form holds KSLABS = Dh / 32 slabs of a row in registers
 bool pstat_supported(int Dh) { return Dh % WROW == 0 && Dh / WROW >= 1 && Dh / WROW <= 8; }
+bool pstat64_supported(int Dh) { return pstat_supported(Dh) && pstat64_takes(Dh / WROW); }
 
 template <int KSLABS, bool WANT_MIN>
 static int launch_cross_pstat64_t(unsigned blocks, const float* Rb, int64_t Nr, int64_t ldr, const float* rnorm, const float* rthr,

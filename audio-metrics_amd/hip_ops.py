@@ -581,7 +581,8 @@ def prdc_path(n_ref, n_cand, d):
 
 
 def filter_engine(d):
-    """Tile engine of the path-3 filter kernels for rows of d elements: 1 operand-stationary (pstat), 0 streamed (wide)."""
+    """Tile engine of the path-3 filter kernels for rows of d elements: 1 operand-stationary (pstat, D <= 512), 2 the same as two
+    256-thread workgroups per CU (pstat64, D <= 128), 0 streamed (wide)."""
     return int(_lib.load().am_filter_engine(int(d)))
 
 

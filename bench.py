@@ -458,22 +458,26 @@ def main():
         elapsed = float(t.item())
     # ---- with several ranks: the OTHER schedule timed the same way, so that one driver run says which is faster
     # (VERDICT r5 next-5b): `value` stays the schedule the flags chose, the line carries both as python_schedule_ms / c_entry_ms
-    other_schedule_ms = None
+    other_schedule_ms = other_schedule_note = None
     if world > 1:
         def other_step():
             return evaluate_sharded(ref_l, cand_l, metrics=("fad", "kd", "prdc"), nearest_k=k, shard_counts=shard_counts,
                                     c_entry=not args.c_entry)
-        for _ in range(max(1, args.warmup)):
-            other_result = other_step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            other_result = other_step()
-        fence()
-        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        other_schedule_ms = float(t.item()) / args.steps * 1e3
-        assert all(abs(other_result[key] - result[key]) <= 1e-9 * max(1.0, abs(result[key])) for key in result), (other_result, result)
+        try:
+            for _ in range(max(1, args.warmup)):
+                other_result = other_step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                other_result = other_step()
+            fence()
+            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            other_schedule_ms = float(t.item()) / args.steps * 1e3
+            agree = all(abs(other_result[key] - result[key]) <= 1e-9 * max(1.0, abs(result[key])) for key in result)
+            other_schedule_note = "same values as the timed schedule" if agree else f"VALUES DIFFER: {other_result} vs {result}"
+        except Exception as exc:                         # the line with `value` must survive a failure of the comparison run
+            other_schedule_note = f"the other schedule failed: {type(exc).__name__}: {exc}"[:400]
 
     # ---- a second, UNTIMED pass of the same step with the clocks on, all HIP events on the stream the kernels run on:
     # KernelTimer brackets each C-ABI entry point from the host side (with one rank the timed step is ONE entry point,
@@ -602,7 +606,7 @@ def main():
         cross_entry = entry("am_prdc_counts_prepared_f32", "am_prdc_counts_f32")
         knn_path = ops.knn_path(n, n, d, k) if (world == 1 or part_form) else 0
         cross_path = ops.prdc_path(rows_local, n, d)
-        engine = "pstat" if ops.filter_engine(d) == 1 else "wide"       # path 3: operand-stationary or streamed tile engine
+        engine = {1: "pstat", 2: "pstat64"}.get(ops.filter_engine(d), "wide")   # path 3: operand-stationary (512 / 2 x 256 threads) or streamed
         knn_kernel = {0: "knn_partial_kernel", 1: "knn_sym_kernel", 2: "knn_fast_kernel", 3: f"knn_{engine}_kernel"}[knn_path]
         cross_kernel = {0: "prdc_cross_kernel", 2: "cross_fast_kernel", 3: f"cross_{engine}_kernel"}[cross_path]
         peak_of = {0: F32_MFMA_PEAK_TFLOPS, 1: F32_MFMA_PEAK_TFLOPS, 2: F16_MFMA_PEAK_TFLOPS, 3: F16_MFMA_PEAK_TFLOPS}
@@ -745,6 +749,8 @@ def main():
         }
         if exchange is not None:
             out["exchange"] = exchange
+        if other_schedule_note is not None:
+            out["schedules_check"] = other_schedule_note
         if other_schedule_ms is not None:
             mine = out["ms_per_step"]
             out["c_entry_ms"] = mine if args.c_entry else other_schedule_ms

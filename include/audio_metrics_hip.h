@@ -450,8 +450,10 @@ int am_kernel_clock_enable(int on);
 int am_kernel_clock_read(int kernel, int64_t* launches, double* total_ms);
 int am_knn_path(int64_t N, int64_t M, int D, int k, int self);
 int am_prdc_path(int64_t Nr, int64_t Nc, int D);
-/* form 3 has two tile engines, chosen by the row length alone: 1 = operand-stationary (csrc/pstat_engine.h: the workgroup's
+/* form 3 has three tile engines, chosen by the row length alone: 1 = operand-stationary (csrc/pstat_engine.h: the workgroup's
  * 256-row block held in registers, kernels knn_pstat_kernel / cross_pstat_kernel; rows of up to 512 elements),
+ * 2 = the same as two independent 256-thread workgroups per CU whose waves own two row tiles (pstat64_pipeline: kernels
+ * knn_pstat64_kernel / cross_pstat64_kernel; rows of up to 128 elements),
  * 0 = both operands streamed through LDS (csrc/wide_engine.h: knn_wide_kernel / cross_wide_kernel) */
 int am_filter_engine(int D);
 

@@ -189,7 +189,7 @@ def test_sets_of_very_different_magnitude(probe, scale_ref, scale_cand, route):
     x = torch.randn(20000, 128, generator=g, device="cuda") * scale_ref
     y = torch.randn(20000, 128, generator=g, device="cuda") * scale_cand
     r, r2 = ops.knn_radii(x, 5), ops.knn_radii(y, 5)
-    assert ops.prdc_path(20000, 20000, 128) == 3 and ops.filter_engine(128) == 1
+    assert ops.prdc_path(20000, 20000, 128) == 3 and ops.filter_engine(128) == 2 and ops.filter_engine(512) == 1 and ops.filter_engine(768) == 0
     ops.filter_stats_read("cuda:0")
     got = ops.prdc_counts(x, y, r, r2)
     s = ops.filter_stats_read("cuda:0")

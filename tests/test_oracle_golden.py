@@ -128,7 +128,9 @@ def test_prdc_blocked_agrees():
         assert abs(full[key] - blk[key]) <= 2.0 / 1000 + 1e-12
 
 
-@pytest.mark.parametrize("name", list(gi.PRDC_LARGE_CASES))
+# (randn_40000_512_k5 - 6 530 inside pairs, 40 s of CPU - is left to the GPU suite, which checks the device against the same
+# reference outputs; unit_40000_512_k10 keeps the 512-wide, 40 000-row shape here with 1.4 M inside pairs)
+@pytest.mark.parametrize("name", [n for n in gi.PRDC_LARGE_CASES if n != "randn_40000_512_k5"])
 def test_prdc_blocked_vs_reference_large(golden, name):
     """Closes the fixture chain of the headline configuration: tests/golden/bench_prdc.npz - what
     bench.py's result_check and the 100k-row GPU tests compare with - is written by oracle.prdc_blocked, because the

@@ -20,7 +20,8 @@ import json, sys
 for line in sys.stdin:
     if line.startswith('{'):
         d = json.loads(line); r = d['result']
-        print(d['n_gpus'], d['n_ranks_seen'], ' '.join(f'{k} {v!r}' for k, v in r.items()), d['result_check']['ok'])
+        print(d['n_gpus'], d['n_ranks_seen'], ' '.join(f'{k} {v!r}' for k, v in r.items()), d['result_check']['ok'],
+              '| python_schedule_ms', round(d.get('python_schedule_ms') or 0, 1), 'c_entry_ms', round(d.get('c_entry_ms') or 0, 1), '|', d.get('schedules_check'))
 "
 done
 python3 -c "
