@@ -86,7 +86,7 @@ class AudioMetrics:
     _need_embeddings = set(ROW_METRICS)
 
     def __init__(self, metrics=["apa", "fad"], n_pca=None, device_indices=None, embedder=None, mix_function=None,
-                 win_dur=5.0, input_sr=None, process_group=None):
+                 win_dur=5.0, input_sr=None, process_group=None, replica_dealing="round_robin"):
         self._devices = _visible_devices(device_indices, process_group is not None, embedder)
         self.device = self._devices[0]                 # where statistics, stored rows and metric kernels live
         self._group = process_group
@@ -99,7 +99,9 @@ class AudioMetrics:
         self.embedder = self.get_embedder(embedder) if embedder is None or isinstance(embedder, str) else embedder
         # resolved (and, for the library's own names, checked for its dependencies) here rather than at the first mix
         self.mix_function = self.get_mix_function(mix_function)
-        self._pool = EmbedderPool(self.embedder, self._devices)
+        # replica_dealing="free": batches go to whichever GPU is free, as in the reference (util/gpu_parallel.py:59-76);
+        # the default deals them round-robin so that the stored row order - and the KD subsets - are reproducible
+        self._pool = EmbedderPool(self.embedder, self._devices, dealing=replica_dealing)
         self.apa_d_x_xp = None
         for name, spec in REFERENCE_SETS.items():
             setattr(self, name, None)

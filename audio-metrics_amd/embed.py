@@ -353,9 +353,20 @@ def _replica(embedder, device):
 class EmbedderPool:
     """Runs the embedder forward and the device-side aggregation on every listed GPU."""
 
-    def __init__(self, embedder, devices):
+    DEALINGS = ("round_robin", "free")
+
+    def __init__(self, embedder, devices, dealing="round_robin"):
+        """dealing: how batches reach the replicas.  "round_robin" (default): batch b goes to replica b mod R - the stored row
+        order is a pure function of the input order and R, so the kernel-distance subsets (drawn by row index) are
+        reproducible; one slow replica stalls the dealer once its inbox is full.  "free": every replica pulls from ONE shared
+        queue, i.e. a batch goes to whichever GPU is free - the reference's scheme (util/gpu_parallel.py:20-76, submit
+        :59-76); no stall, and like the reference's the row order differs from run to run."""
         if not devices:
             raise RuntimeError("No GPUs found, cannot compute audio metrics")
+        if dealing not in self.DEALINGS:
+            raise ValueError(f"dealing must be one of {self.DEALINGS}, got {dealing!r}")
+        self.dealing = dealing
+        self.batches_per_replica = []                                # of the last multi-replica run (diagnostics, tests)
         self.devices = [torch.device(d) for d in devices]
         self.replicas = [_replica(embedder, d) for d in self.devices]
         self.guards = {}                                             # batch-ring slot -> event behind its last device copy
@@ -395,8 +406,13 @@ class EmbedderPool:
         return merge_across_devices([a.data for a in aggregators], self.devices[0])
 
     def _run_threads(self, batches, aggregators):
-        inboxes = [queue.Queue(maxsize=self.QUEUE_DEPTH) for _ in self.devices]
+        if self.dealing == "free":                                   # one shared queue: whoever is free takes the next batch
+            shared = queue.Queue(maxsize=self.QUEUE_DEPTH * len(self.devices))
+            inboxes = [shared] * len(self.devices)
+        else:
+            inboxes = [queue.Queue(maxsize=self.QUEUE_DEPTH) for _ in self.devices]
         failures = []
+        taken = [0] * len(self.devices)
 
         def worker(slot):
             try:
@@ -410,9 +426,10 @@ class EmbedderPool:
                         embedding = self.replicas[slot].forward(batch)["embedding"]
                         self._consumed(batch, self.devices[slot])
                         aggregators[slot].file(embedding, batch["category"])
+                        taken[slot] += 1
             except BaseException as e:                              # surfaced by the dealer below
                 failures.append(e)
-                while inboxes[slot].get() is not None:
+                while inboxes[slot].get() is not None:           # (shared queue: this worker keeps draining until ITS stop mark)
                     pass
 
         threads = [threading.Thread(target=worker, args=(s,), name=f"am-embed-{s}", daemon=True)
@@ -425,10 +442,11 @@ class EmbedderPool:
                     break
                 inboxes[number % len(inboxes)].put(batch)
         finally:
-            for box in inboxes:
+            for box in inboxes:                                     # one stop mark per worker (a shared queue gets all of them)
                 box.put(None)
             for t in threads:
                 t.join()
+            self.batches_per_replica = taken
         if failures:
             raise failures[0]
 

@@ -44,6 +44,44 @@ def _audio():
             gi.e2e_pairs(c["seed"] + 1, c["n_cand"], c["seconds"], c["sr"], stem_gain=1.3))
 
 
+def test_free_gpu_dealing_like_the_reference():
+    """replica_dealing="free": every replica pulls from ONE shared queue - a batch goes to whichever GPU is free, the
+    reference's scheme (util/gpu_parallel.py:20-76, submit :59-76) - so a slow replica does not stall the others: with one of
+    two replicas slowed down it ends up with fewer batches, every row still arrives exactly once, and the row-order-free
+    metrics equal the single-replica run's."""
+    import time
+    import audio_metrics_amd as am
+    ref, cand = _audio()
+    random.seed(5)
+    one = _make(am, ["fad", "prdc"], device_indices=[0])
+    one.add_reference(ref)
+    want = one.evaluate(cand)
+    random.seed(5)
+    two = _make(am, ["fad", "prdc"], device_indices=[0, 0], replica_dealing="free")
+    slow = two._pool.replicas[1]
+    fast_forward = type(slow).forward
+
+    class Slowed(type(slow)):                                  # replica 1 takes 30 ms longer per batch
+        def forward(self, batch):
+            time.sleep(0.03)
+            return fast_forward(self, batch)
+
+    import copy
+    two._pool.replicas[1] = copy.copy(slow)
+    two._pool.replicas[1].__class__ = Slowed
+    two.add_reference(ref)
+    taken = list(two._pool.batches_per_replica)
+    got = two.evaluate(cand)
+    assert sum(taken) > 2 and taken[1] < taken[0], taken         # the free replica took more of the work
+    assert two.stem_reference.n == one.stem_reference.n
+    assert torch.equal(torch.sort(two.stem_reference.embeddings.sum(1))[0], torch.sort(one.stem_reference.embeddings.sum(1))[0])
+    for key in ("precision", "recall", "density", "coverage"):
+        assert got[key] == want[key], key
+    assert abs(got["fad"] - want["fad"]) <= 1e-9 * abs(want["fad"])
+    with pytest.raises(ValueError):
+        _make(am, ["fad"], replica_dealing="whoever")
+
+
 def test_two_replicas_match_one():
     import audio_metrics_amd as am
     ref, cand = _audio()

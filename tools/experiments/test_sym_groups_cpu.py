@@ -10,7 +10,8 @@ import subprocess
 
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))                  # tools/experiments: sym_groups.h lives beside this file
+ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "audio-metrics_amd", "csrc")
 
 PROGRAM = r"""
@@ -78,7 +79,7 @@ def checker(tmp_path_factory):
     src = d / "check.cpp"
     src.write_text(PROGRAM)
     exe = d / "check"
-    r = subprocess.run([gxx, "-O1", "-std=c++17", "-I", CSRC, str(src), "-o", str(exe)], capture_output=True, text=True)
+    r = subprocess.run([gxx, "-O1", "-std=c++17", "-I", HERE, "-I", CSRC, str(src), "-o", str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     return str(exe)
 
