@@ -11,6 +11,7 @@ through am_filter_stats next to the bits:
   scale      operands that cannot be scaled into f16: exact kernels
   budget     membership filter: overflow queue past its budget -> the exact membership kernel takes the call
   overflow   membership filter: entries beyond a region go through the overflow queue and are still verified
+             (test_membership_overflow_queue_route: a construction, on both stationary engines)
   partition  am_knn_bounds / am_knn_sym_part / am_knn_lists_finish against the one-GPU entry point
 
 Exact values without a second library: the k-NN radii of the general entry point (columns = a COPY of the set:
@@ -83,7 +84,8 @@ CASES = {
     "clustered_20k_512": ("clustered", 20000, 20000, 512, 5, 3, "check A", "budget"),
     "shared_20k_512": ("shared", 20000, 20000, 512, 5, 4, "check A", "budget"),
     "lowrank_20k_257": ("lowrank", 20000, 20000, 257, 5, 9, "check A", None),
-    "hub_30k_128": ("hub", 30000, 30000, 128, 3, 6, "check A", "overflow"),
+    "hub_30k_128": ("hub", 30000, 30000, 128, 3, 6, "check A", None),      # (round 6: with 32 row blocks per group its regions hold everything; the
+                                                                           #  overflow-queue route has its own construction below)
     "sparse_16400_64": ("sparse", 16400, 16400, 64, 5, 11, "check A", "budget"),
     "silence_40k_256": ("silence", 40000, 3001, 256, 5, 5, "marking", "plain"),
     "silence_20k_512": ("silence", 20000, 20000, 512, 10, 26, "marking", None),
@@ -136,6 +138,32 @@ def test_route_and_bits(probe, name):
         assert s["prdc_fallback_calls"] == 1, s
         if cross_route == "budget":
             assert s["prdc_overflow_queue"] > 0, s
+
+
+@pytest.mark.parametrize("dim", [128, 512])
+def test_membership_overflow_queue_route(probe, dim):
+    """The `overflow` route by construction (the seeded hub case took it until round 6 changed the work-item shape): 40 identical
+    candidate rows h in ONE column chunk, and the first 256 reference rows given radii equal to their distance to h - 256 x 40
+    pairs that sit ON their thresholds, all queued by one workgroup: past its region (4096 entries) they go through the
+    overflow queue, stay under its budget, and are verified exactly like the rest."""
+    ops = probe.ops
+    n = 20000
+    g = torch.Generator(device="cuda").manual_seed(61 + dim)
+    x = torch.randn(n, dim, generator=g, device="cuda")
+    y = torch.randn(n, dim, generator=g, device="cuda")
+    h = 0.3 * torch.randn(dim, generator=g, device="cuda")
+    y[1000:1040] = h
+    r, r2 = ops.knn_radii(x, 5), ops.knn_radii(y, 5)
+    r[:256] = (x[:256] - h).square().sum(1).sqrt()
+    assert ops.prdc_path(n, n, dim) == 3
+    ops.filter_stats_read("cuda:0")
+    got = ops.prdc_counts(x, y, r, r2)
+    s = ops.filter_stats_read("cuda:0")
+    want = probe.exact_counts(x, y, r, r2, False)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert s["prdc_calls"] == 1 and s["prdc_fallback_calls"] == 0 and s["prdc_overflow_queue"] > 0, s
+    print(f"D = {dim}: queued {s['prdc_queued']}, of them through the overflow queue {s['prdc_overflow_queue']}")
 
 
 @pytest.mark.parametrize("fam,rows,dim,k,world,seed", [

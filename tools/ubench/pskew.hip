@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <initializer_list>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -73,7 +74,17 @@ __global__ void __launch_bounds__(512, 1) ovl(int mode, int iters, const float* 
             }
         }
     } else if ((wave < 4) != ((mode & 8) != 0)) {
-        if (mode & 1)
+        // bit 6: ONE accumulator (every MFMA waits for its predecessor's result: is a not-yet-ready MFMA kinder to the partner's
+        // vector issue than a ready one queued behind a busy pipe?), bit 7: two accumulators alternating
+        if ((mode & 1) && (mode & 64))
+            for (int it = 0; it < iters; ++it)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b0), acc[0], 0, 0, 0);
+        else if ((mode & 1) && (mode & 128))
+            for (int it = 0; it < iters; ++it)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b0), acc[m & 1], 0, 0, 0);
+        else if (mode & 1)
             for (int it = 0; it < iters; ++it)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b0), acc[m], 0, 0, 0);
@@ -511,10 +522,10 @@ static void run_free(const char* name) {
 }
 
 template <int VPER>
-static void run_ovl() {
+static void run_ovl(bool part4 = false) {
     const int iters = 200000;
     static unsigned long long h[256 * 2 * 4];
-    for (int mode : {1, 2, 3, 3 + 16, 3 + 32, 3 + 48, 3 + 8, 3 + 8 + 16, 4}) {
+    for (int mode : part4 ? std::initializer_list<int>{1, 1 + 64, 1 + 128, 2, 3, 3 + 64, 3 + 128, 3 + 8, 3 + 8 + 64} : std::initializer_list<int>{1, 2, 3, 3 + 16, 3 + 32, 3 + 48, 3 + 8, 3 + 8 + 16, 4}) {
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
         hipLaunchKernelGGL(ovl<VPER>, dim3(256), dim3(512), 0, 0, mode, 1000, g_src, g_out, g_clk);
@@ -529,6 +540,8 @@ static void run_ovl() {
         printf("ovl VPER %2d mode %d (%s): kernel %.2f ms", VPER, mode,
                mode == 1 ? "waves 0-3 MFMA x4, 4-7 idle" : mode == 2 ? "waves 4-7 VALU, 0-3 idle" : (mode & 7) == 3 ? ((mode & 8) ? "4-7 MFMA beside 0-3 VALU (vector waves OLDER)" : "0-3 MFMA beside 4-7 VALU") : "all 8: 4 MFMA + VPER VALU interleaved", ms);
         if ((mode & 7) == 3) printf(" prio %d", (mode >> 4) & 3);
+        if (mode & 64) printf(" [ONE accumulator: dependent MFMA chain]");
+        if (mode & 128) printf(" [two accumulators]");
         unsigned long long first = ~0ull, last = 0;
         for (int cls = 0; cls < 2; ++cls) {
             double cyc = 0, dmin = 1e30, dmax = 0, dsum = 0, ghz = 0;
@@ -568,6 +581,10 @@ int main(int argc, char** argv) {
     if (part & 1) {
         run_ovl<16>();
         run_ovl<64>();
+    }
+    if (part & 4) {                                   // dependent MFMA chains beside the partner's vector work
+        run_ovl<16>(true);
+        run_ovl<64>(true);
     }
     if (part & 2) {
         // ---- D = 512 (KS = 8): lockstep, two workgroups (with / without priority in the epilogue), variable epilogues
