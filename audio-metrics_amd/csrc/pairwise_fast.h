@@ -1408,8 +1408,17 @@ __global__ void __launch_bounds__(256) knn_fast_select64_kernel(const double* __
                                                                 const uint2* __restrict__ pairs, const int* __restrict__ pair_start,
                                                                 const int* __restrict__ pair_n, int64_t N, int k1,
                                                                 const unsigned* __restrict__ maxn, double* __restrict__ out_r,
-                                                                int* __restrict__ gate) {
+                                                                int* __restrict__ gate, const float* __restrict__ pair_val,
+                                                                const float* __restrict__ xnorm, float fc,
+                                                                unsigned long long* __restrict__ bound_slots) {
     if (*reinterpret_cast<volatile int*>(gate + 1) != 0) return;     // the general kernels take the call anyway
+    // bound_slots (am_filter_stats_enable; round 6): this route holds both values of every surviving pair too - the
+    // f16 matrix-core value the sweep decided on (computed from the float32-ROUNDED rows) and the float64 sum of squared
+    // differences of the float64 rows - so the widened bound it rests on, |a - t| <= (fast_c(D) + 2^-19) (|x|^2 + G), is
+    // measured like the float32 route's (slot 0 = max ratio as f32 bits, slot 1 = pairs measured).  The row itself (distance 0,
+    // a = rounding noise around 0) is a pair like any other.
+    float worst = 0.f;
+    unsigned long long measured = 0ull;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
@@ -1432,6 +1441,23 @@ __global__ void __launch_bounds__(256) knn_fast_select64_kernel(const double* __
                 sum = fma(t, t, sum);
             }
             v[q] = sum == sum ? sum : __builtin_inf();           // (a NaN distance is nobody's neighbour: clamp0)
+            if (bound_slots != nullptr) {
+                const float bound = fc * (fminf(xnorm[row], xnorm[pairs[start + p].y]) + __uint_as_float(maxn[0]));
+                const float ratio = fabsf(pair_val[start + p] - (float)sum) / bound;
+                if (ratio == ratio && ratio < __builtin_inff()) worst = fmaxf(worst, ratio);
+                ++measured;
+            }
+        }
+    }
+    if (bound_slots != nullptr) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            worst = fmaxf(worst, __shfl_xor(worst, off));
+            measured += __shfl_xor(measured, off);
+        }
+        if (lane == 0 && measured != 0ull) {
+            atomicMax(bound_slots, (unsigned long long)__float_as_uint(worst));
+            atomicAdd(bound_slots + 1, measured);
         }
     }
     double kth = __builtin_inf();
@@ -1755,8 +1781,10 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
     if (h64 != nullptr) {
         AM_REQUIRE(gate != nullptr && out_lists == nullptr, AM_ERR_BAD_ARG, "the float64 route is the single-GPU form");
         clock_begin(AM_KERNEL_KNN_VERIFY, st);
+        long long* stats64 = filter_stats_for_current_device();
         hipLaunchKernelGGL(knn_fast_select64_kernel, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, st, h64->X, h64->ld, D, b.wgq,
-                           h64->pair_start, h64->pair_n, N, k1, maxn, h64->out_r, gate);
+                           h64->pair_start, h64->pair_n, N, k1, maxn, h64->out_r, gate, (const float*)f.wgv, (const float*)b.xn, fc,
+                           stats64 != nullptr ? reinterpret_cast<unsigned long long*>(stats64) + 9 : nullptr);
         clock_end(AM_KERNEL_KNN_VERIFY, st);
         AM_LAUNCH_CHECK();
         // the general f64 kernels behind the route: they return at once unless check A / B or a row without a list gave up

@@ -77,7 +77,7 @@ def test_free_gpu_dealing_like_the_reference():
     assert torch.equal(torch.sort(two.stem_reference.embeddings.sum(1))[0], torch.sort(one.stem_reference.embeddings.sum(1))[0])
     for key in ("precision", "recall", "density", "coverage"):
         assert got[key] == want[key], key
-    assert abs(got["fad"] - want["fad"]) <= 1e-9 * abs(want["fad"])
+    assert abs(got["fad"] - want["fad"]) <= 1e-6 * abs(want["fad"])          # (other merge order of the partial statistics)
     with pytest.raises(ValueError):
         _make(am, ["fad"], replica_dealing="whoever")
 
