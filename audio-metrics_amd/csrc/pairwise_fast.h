@@ -1403,6 +1403,7 @@ struct Knn64Hook {
     int k;
 };
 constexpr int KNN64_PER_LANE = 12;                       // 64 x 12 >= the candidate slots of a row (64 (k + 1), k <= 10)
+constexpr int KNN64_ROWS_PER_WAVE = 8;
 
 __global__ void __launch_bounds__(256) knn_fast_select64_kernel(const double* __restrict__ X, int64_t ld, int D,
                                                                 const uint2* __restrict__ pairs, const int* __restrict__ pair_start,
@@ -1420,34 +1421,66 @@ __global__ void __launch_bounds__(256) knn_fast_select64_kernel(const double* __
     float worst = 0.f;
     unsigned long long measured = 0ull;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= N) return;
-    const int start = pair_start[row], n = pair_n[row];
-    if (start < 0 || n < k1 || n > 64 * KNN64_PER_LANE || !half_scale_ok(maxn[2])) {
-        if (lane == 0) atomicOr(gate + 1, 1);
-        return;
-    }
-    const double* xi = X + row * ld;
-    double v[KNN64_PER_LANE];
+    // a wave takes KNN64_ROWS_PER_WAVE consecutive rows: the two statistics atomics are paid once per wave, not once per row
+    // (100 000 waves on one address cost 2 ms per set)
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * KNN64_ROWS_PER_WAVE;
+    for (int64_t row = row0; row < row0 + KNN64_ROWS_PER_WAVE && row < N; ++row) {
+        const int start = pair_start[row], n = pair_n[row];
+        if (start < 0 || n < k1 || n > 64 * KNN64_PER_LANE || !half_scale_ok(maxn[2])) {
+            if (lane == 0) atomicOr(gate + 1, 1);
+            continue;
+        }
+        const double* xi = X + row * ld;
+        double v[KNN64_PER_LANE];
 #pragma unroll
-    for (int q = 0; q < KNN64_PER_LANE; ++q) {
-        v[q] = __builtin_inf();
-        const int p = lane + 64 * q;
-        if (p < n) {
-            const double* xj = X + (int64_t)pairs[start + p].y * ld;
-            double sum = 0.0;
-            for (int d = 0; d < D; ++d) {
-                const double t = xi[d] - xj[d];
-                sum = fma(t, t, sum);
-            }
-            v[q] = sum == sum ? sum : __builtin_inf();           // (a NaN distance is nobody's neighbour: clamp0)
-            if (bound_slots != nullptr) {
-                const float bound = fc * (fminf(xnorm[row], xnorm[pairs[start + p].y]) + __uint_as_float(maxn[0]));
-                const float ratio = fabsf(pair_val[start + p] - (float)sum) / bound;
-                if (ratio == ratio && ratio < __builtin_inff()) worst = fmaxf(worst, ratio);
-                ++measured;
+        for (int q = 0; q < KNN64_PER_LANE; ++q) {
+            v[q] = __builtin_inf();
+            const int p = lane + 64 * q;
+            if (p < n) {
+                const double* xj = X + (int64_t)pairs[start + p].y * ld;
+                double sum = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    const double t = xi[d] - xj[d];
+                    sum = fma(t, t, sum);
+                }
+                v[q] = sum == sum ? sum : __builtin_inf();           // (a NaN distance is nobody's neighbour: clamp0)
+                if (bound_slots != nullptr) {
+                    const float bound = fc * (fminf(xnorm[row], xnorm[pairs[start + p].y]) + __uint_as_float(maxn[0]));
+                    const float ratio = fabsf(pair_val[start + p] - (float)sum) / bound;
+                    if (ratio == ratio && ratio < __builtin_inff()) worst = fmaxf(worst, ratio);
+                    ++measured;
+                }
             }
         }
+        double kth = __builtin_inf();
+        for (int r = 0; r < k1; ++r) {
+            double m = v[0];
+            int mq = 0;
+#pragma unroll
+            for (int q = 1; q < KNN64_PER_LANE; ++q)
+                if (v[q] < m) {
+                    m = v[q];
+                    mq = q;
+                }
+            double wm = m;
+            int wl = lane;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double om = __shfl_xor(wm, off);
+                const int ol = __shfl_xor(wl, off);
+                if (om < wm || (om == wm && ol < wl)) {
+                    wm = om;
+                    wl = ol;
+                }
+            }
+            kth = wm;
+            if (lane == wl) {
+#pragma unroll
+                for (int q = 0; q < KNN64_PER_LANE; ++q)
+                    if (q == mq) v[q] = __builtin_inf();
+            }
+        }
+        if (lane == 0) out_r[row] = __dsqrt_rn(kth);
     }
     if (bound_slots != nullptr) {
 #pragma unroll
@@ -1460,35 +1493,6 @@ __global__ void __launch_bounds__(256) knn_fast_select64_kernel(const double* __
             atomicAdd(bound_slots + 1, measured);
         }
     }
-    double kth = __builtin_inf();
-    for (int r = 0; r < k1; ++r) {
-        double m = v[0];
-        int mq = 0;
-#pragma unroll
-        for (int q = 1; q < KNN64_PER_LANE; ++q)
-            if (v[q] < m) {
-                m = v[q];
-                mq = q;
-            }
-        double wm = m;
-        int wl = lane;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double om = __shfl_xor(wm, off);
-            const int ol = __shfl_xor(wl, off);
-            if (om < wm || (om == wm && ol < wl)) {
-                wm = om;
-                wl = ol;
-            }
-        }
-        kth = wm;
-        if (lane == wl) {
-#pragma unroll
-            for (int q = 0; q < KNN64_PER_LANE; ++q)
-                if (q == mq) v[q] = __builtin_inf();
-        }
-    }
-    if (lane == 0) out_r[row] = __dsqrt_rn(kth);
 }
 
 template <int KCAP>
@@ -1782,7 +1786,7 @@ static int run_knn_fast(const float* X, int64_t N, int64_t ld, int D, int k1, co
         AM_REQUIRE(gate != nullptr && out_lists == nullptr, AM_ERR_BAD_ARG, "the float64 route is the single-GPU form");
         clock_begin(AM_KERNEL_KNN_VERIFY, st);
         long long* stats64 = filter_stats_for_current_device();
-        hipLaunchKernelGGL(knn_fast_select64_kernel, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, st, h64->X, h64->ld, D, b.wgq,
+        hipLaunchKernelGGL(knn_fast_select64_kernel, dim3((unsigned)ceil_div(N, 4 * KNN64_ROWS_PER_WAVE)), dim3(256), 0, st, h64->X, h64->ld, D, b.wgq,
                            h64->pair_start, h64->pair_n, N, k1, maxn, h64->out_r, gate, (const float*)f.wgv, (const float*)b.xn, fc,
                            stats64 != nullptr ? reinterpret_cast<unsigned long long*>(stats64) + 9 : nullptr);
         clock_end(AM_KERNEL_KNN_VERIFY, st);

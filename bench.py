@@ -573,8 +573,11 @@ def main():
             # data.py:39-44, prdc.py:12-13, kd.py:112-116): the *_f64 entry points, the large sets through the f16 filter with an f64
             # evaluation of the undecided pairs; checked against the reference's own float64 values / the blocked oracle in float64
             vr, vc = (torch.as_tensor(a).to(dev) for a in gi.pair64("randn", gi.BENCH_SEED, n, n, 64))
+            ops.filter_stats_read(dev)
             dt, vres = timed_steps(lambda: evaluate_sharded(vr, vc, metrics=("fad", "kd", "prdc"), nearest_k=k), fence, 5, 2)
+            stats = ops.filter_stats_read(dev)
             variants["pca64_f64"] = {"ms_per_step": dt / 5 * 1e3, "embeddings_per_s": 5 * 2 * n / dt, "dtype": "f64",
+                                     "filter": per_step(stats, 7),      # incl. bound_ratio_max: the float64 route's widened bound, measured
                                      "workload": f"FAD+KD+PRDC(k={k}) cold evaluate() of 2x{n}x64 FLOAT64 randn sets (the shape n_pca = 64 leaves)",
                                      "result": vres, "result_check": check_against_fixture(vres, "randn", n, 64, k, "_f64")}
             del vr, vc
