@@ -19,6 +19,11 @@ Rank 0 prints ONE JSON line.
 Inputs come from numpy's PCG64 (tests/golden/inputs.py: bench_pair), so the CPU oracle can reproduce them:
 tests/golden/bench_prdc.npz holds oracle.prdc_blocked's values for exactly these sets and the line's `result` is
 checked against it (`result_check`).
+
+Beside the contract's keys the line carries `roofline` / `other_tile_kernel` / `cpu_baseline`, `variants`, `filter`, `warm`,
+`first_call`, and (round 6) `process_cold` - with one GPU: ONE evaluate() of a fresh process, started as a child before this
+process touches the GPU (--no-process-cold skips it) - and, with several ranks, `c_entry_ms` beside `python_schedule_ms`: both
+exchange schedules timed back to back (the one the flags chose is `value`).
 """
 import argparse
 import json
