@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Which seeded sets send the membership filter through its overflow queue (am_filter_stats: prdc_overflow_queue) or past its
+budget (prdc_fallback_calls) - how the cases of tests/test_gpu_routes.py were re-checked after round 6 changed the work-item
+shape of the filter (32 row blocks per group).  Usage: python tools/find_overflow_case.py"""
 import sys, os, torch
 sys.path.insert(0, "tools"); sys.path.insert(0, ".")
 import route_probe as rp
