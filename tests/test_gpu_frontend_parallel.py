@@ -61,9 +61,9 @@ def test_free_gpu_dealing_like_the_reference():
     slow = two._pool.replicas[1]
     fast_forward = type(slow).forward
 
-    class Slowed(type(slow)):                                  # replica 1 takes 30 ms longer per batch
+    class Slowed(type(slow)):                                  # replica 1 takes 100 ms longer per batch (six batches in all: [5, 1] or [4, 2])
         def forward(self, batch):
-            time.sleep(0.03)
+            time.sleep(0.1)
             return fast_forward(self, batch)
 
     import copy
