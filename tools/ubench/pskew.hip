@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(NW * 64, (WGS * NW) / 4) stage(const float* __
             advance();
             if (SK == 0 && last) epi.run(acc, u);              // lockstep: in front of the barrier (the shipped order)
             wait_vm<PIECES>();
-            __builtin_amdgcn_s_barrier();
+            if (PRIO != 9 || last) __builtin_amdgcn_s_barrier();   // (PRIO = 9: timing experiment, ONE barrier per unit; data meaningless)
             slot = next_slot;
             if (last) {
                 if (SK != 0) {                                 // skewed: behind it - the partner wave is in the middle of its unit
@@ -581,6 +581,16 @@ int main(int argc, char** argv) {
     if (part & 1) {
         run_ovl<16>();
         run_ovl<64>();
+    }
+    if (part & 8) {                                   // one barrier per unit instead of one per stage (timing only)
+        run<4, 64, 2, 2, 0, 0, 0, 2>("2wg-np2q64");
+        run<4, 64, 2, 2, 0, 0, 0, 2, 9>("2wg-np2q64-bar1");
+        run<4, 64, 2, 2, 4, 0, 0, 2>("2wg-np2q64");
+        run<4, 64, 2, 2, 4, 0, 0, 2, 9>("2wg-np2q64-bar1");
+        run<4, 64, 2, 2, 6, 0, 0, 2>("2wg-np2q64");
+        run<4, 64, 2, 2, 6, 0, 0, 2, 9>("2wg-np2q64-bar1");
+        run<8, 128, 1, 8, 4, 0, 0, 1>("lockstep");
+        run<8, 128, 1, 8, 4, 0, 0, 1, 9>("lockstep-bar1");
     }
     if (part & 4) {                                   // dependent MFMA chains beside the partner's vector work
         run_ovl<16>(true);
